@@ -1,0 +1,151 @@
+/*
+ * smot_emm.h — C ABI of libsmot_emm.so, the MI355X (gfx950) implementation of the SiamMOT
+ * EMM tracker-head hot path.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * amazon-science/siam-mot root; [UPSTREAM] = facebookresearch/maskrcnn-benchmark, the
+ * reference's un-vendored native substrate).
+ *
+ * Conventions:
+ *   - all tensors are contiguous fp32, NCHW; boxes are fp32 xyxy pixels; device pointers unless
+ *     the parameter is documented as a HOST array;
+ *   - the caller owns every buffer (outputs and workspaces included); nothing is allocated,
+ *     nothing persists between calls, no host synchronisation happens inside;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 on success, a negative SMOT_ERR_* for argument/shape errors, or a positive
+ *     hipError_t if the launch failed; smot_last_error() gives a message for the calling thread.
+ *     The Python host layer turns non-zero into RuntimeError (the reference's native ops raise
+ *     RuntimeError through TORCH_CHECK).
+ */
+#ifndef SMOT_EMM_H
+#define SMOT_EMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* smot_stream_t; /* hipStream_t */
+
+#define SMOT_OK 0
+#define SMOT_ERR_BAD_ARG (-1)      /* null pointer, non-positive size, inconsistent shapes */
+#define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
+
+#define SMOT_MAX_LEVELS 8
+#define SMOT_ABI_VERSION 1
+
+/* ABI version of the loaded library (checked by the host layer at load time). */
+int smot_abi_version(void);
+
+/* Message describing the last non-zero return on the calling thread ("" if none). */
+const char* smot_last_error(void);
+
+/*
+ * FPN-level-routed ROIAlign with VIRTUAL zero padding.
+ *
+ * Replaces: SRPooler.forward (siammot/modelling/track_head/EMM/sr_pool.py:53-91) =
+ *   LevelMapper [UPSTREAM modeling/poolers.py] + 4x torch.nonzero + per-level
+ *   ROIAlign.forward -> _C.roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w,
+ *   sampling_ratio) [UPSTREAM csrc/cuda/ROIAlign_cuda.cu, layers/roi_align.py], AND the
+ *   TrackUtils.pad_feature zero-padding (track_head/track_utils.py:87-107) that precedes it in
+ *   EMM.forward (EMM/track_core.py:49): level l is treated as if padded by pad_cells[l] zero
+ *   cells on every side, without materialising the padded map.
+ *
+ *   feats[l]      device [1, C, heights[l], widths[l]]   (HOST array of num_levels device pointers)
+ *   heights, widths, pad_cells, scales : HOST arrays [num_levels]
+ *   rois          device [R,4]  boxes that are pooled, in PADDED-image pixels (xyxy)
+ *   level_boxes   device [R,4]  boxes whose area picks the level (the TEMPLATE boxes in the
+ *                 reference; pass rois again for the template pooler / a plain Pooler)
+ *   out           device [R, C, out_h, out_w]
+ *   levels_out    device [R] int32 or NULL: the level chosen per roi (diagnostics/tests)
+ *
+ * num_levels == 1 skips the level mapping (sr_pool.py:70-71).
+ * Level rule: floor(4 + log2(sqrt(area)/224 + 1e-6)) clamped to
+ *   [-log2(scales[0]), -log2(scales[L-1])], area with the upstream +1 convention.
+ * SMOT_ERR_UNSUPPORTED: sampling_ratio <= 0 (adaptive grid) or > 4.
+ */
+int smot_roi_align_levels_fwd(const float* const* feats, const int* heights, const int* widths,
+                              const int* pad_cells, const float* scales, int num_levels, int C,
+                              const float* rois, const float* level_boxes, int R,
+                              int out_h, int out_w, int sampling_ratio,
+                              float* out, int32_t* levels_out, smot_stream_t stream);
+
+/*
+ * Search-region boxes from template boxes.
+ *
+ * Replaces: TrackUtils.update_boxes_in_pad_images + TrackUtils.extend_bbox
+ *   (track_head/track_utils.py:109-135, :62-85) as called by EMM.extract_cache
+ *   (EMM/track_core.py:94-95).  search_expansion = SEARCH_REGION - 1 (track_utils.py:260).
+ *   boxes device [N,4] -> sr device [N,4] (padded-image coordinates).
+ */
+int smot_search_region_fwd(const float* boxes, int N, float pad_pixels, float search_expansion,
+                           float min_search_wh, float* sr, smot_stream_t stream);
+
+/*
+ * Depthwise (per-track x per-channel) valid cross-correlation.
+ *
+ * Replaces: xcorr_depthwise(x, kernel) (EMM/xcorr.py:37-46; F.conv2d with groups = N*C).
+ *   x [N,C,Rx,Rx], z [N,C,Rz,Rz] -> out [N,C,Ho,Ho], Ho = Rx-Rz+1,
+ *   out[n,c,i,j] = sum_{u,v} x[n,c,i+u,j+v] * z[n,c,u,v]   (u-major, v-minor fp32 FMA chain).
+ * Algorithmic HBM bytes: 4*N*C*(Rx^2 + Rz^2 + Ho^2).
+ */
+int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, int Rx, int Rz,
+                      smot_stream_t stream);
+
+/*
+ * EMM prediction tower + heads.
+ *
+ * Replaces: EMMPredictor.forward (EMM/feature_extractor.py:62-69): cls_tower / reg_tower =
+ *   conv3x3(C->C, pad 1, no bias) + GroupNorm(gn_groups, eps, affine) + ReLU
+ *   [UPSTREAM make_conv3x3(use_gn=True, use_relu=True)], then cls (C->2), center (C->1) on the
+ *   cls tower and reg (C->4, followed by ReLU) on the reg tower, each conv3x3 + bias.
+ *   Weight pointers are the reference state_dict tensors as they are (OIHW, contiguous):
+ *   predictor.{cls_tower.0.weight, cls_tower.1.weight, cls_tower.1.bias, reg_tower.0.weight,
+ *   reg_tower.1.weight, reg_tower.1.bias, cls.weight, cls.bias, center.weight, center.bias,
+ *   reg.weight, reg.bias}.
+ *
+ *   resp      [N, C, Ho, Ho]
+ *   tower_ws  [N, 2C, Ho, Ho] caller-owned workspace (cls tower in channels [0,C), reg in [C,2C))
+ *   logits    [N, 7, Ho, Ho]  channel order: cls0, cls1, center, reg_l, reg_t, reg_r, reg_b
+ * Requires C % gn_groups == 0.
+ */
+int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho,
+                           const float* cls_tower_w, const float* cls_gn_w, const float* cls_gn_b,
+                           const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
+                           const float* cls_w, const float* cls_b,
+                           const float* center_w, const float* center_b,
+                           const float* reg_w, const float* reg_b,
+                           int gn_groups, float gn_eps,
+                           float* tower_ws, float* logits, smot_stream_t stream);
+
+/*
+ * Fused bicubic x`up` up-sampling + location grid + response decode + argmax.
+ *
+ * Replaces, in EMM.forward (EMM/track_core.py:69-77): 3x F.interpolate(scale_factor=16,
+ *   mode='bicubic'), get_locations (:184-225) and decode_response (:101-135, with
+ *   get_scale_penalty :138-152 and get_cosine_window_penalty :155-162).  The up-sampled planes
+ *   and the [N, G*G, 2] location tensor are never materialised.
+ *
+ *   logits  [N,7,Ho,Ho] (layout of smot_emm_predictor_fwd)
+ *   sr      [N,4] search regions (padded-image coords),  boxes [N,4] template boxes
+ *   hann    [G] the 1-D window, G = up*Ho (host layer passes torch.hann_window(G), periodic)
+ *   cand_ws [N * smot_emm_decode_ws_floats(Ho, up)] fp32 workspace, 8-byte aligned
+ *   bb [N,4], conf [N]; idx [N] int64 flat argmax index (y*G+x) or NULL
+ *   rx, rz : search / template pooler resolutions (Ho must equal rx-rz+1; rz odd)
+ *   one_minus_sigma and sigma are passed separately so the host can form 1-sigma in double as
+ *   the reference does.
+ * NaN scores win the argmax and ties go to the lowest index (torch.argmax on CPU).
+ */
+int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
+                        int N, int Ho, int up, int rx, int rz, float pad_pixels,
+                        float one_minus_sigma, float sigma, int use_centerness,
+                        float* cand_ws, float* bb, float* conf, int64_t* idx, smot_stream_t stream);
+
+/* fp32 elements of decode workspace needed PER TRACK. */
+int smot_emm_decode_ws_floats(int Ho, int up);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMOT_EMM_H */

@@ -1,0 +1,49 @@
+"""yacs-free config carrying exactly the keys the EMM path reads.
+
+Reference: siammot/configs/defaults.py:35-82 (values) and the reads at
+EMM/track_core.py:23-26, EMM/feature_extractor.py:17-20,47-52, track_utils.py:258-269.
+A real yacs ``cfg`` from the reference works in its place (attribute access only).
+"""
+
+
+class CfgNode(dict):
+    """Attribute-style nested dict (just enough of yacs.CfgNode for attribute reads/writes)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def clone(self):
+        return CfgNode({k: (v.clone() if isinstance(v, CfgNode) else v) for k, v in self.items()})
+
+
+def get_default_cfg(conv_body="DLA-34-FPN", channels=128):
+    cfg = CfgNode()
+    cfg.INPUT = CfgNode(AMODAL=False)
+    cfg.MODEL = CfgNode()
+    cfg.MODEL.BACKBONE = CfgNode(CONV_BODY=conv_body)
+    cfg.MODEL.DLA = CfgNode(BACKBONE_OUT_CHANNELS=channels)
+    cfg.MODEL.RESNETS = CfgNode(BACKBONE_OUT_CHANNELS=256)
+    cfg.MODEL.GROUP_NORM = CfgNode(DIM_PER_GP=-1, NUM_GROUPS=32, EPSILON=1e-5)
+    th = CfgNode()
+    th.TRACKTOR = False
+    th.POOLER_SCALES = (0.25, 0.125, 0.0625, 0.03125)
+    th.POOLER_RESOLUTION = 15
+    th.POOLER_SAMPLING_RATIO = 2
+    th.PAD_PIXELS = 512
+    th.SEARCH_REGION = 2.0
+    th.MINIMUM_SREACH_REGION = 0
+    th.MODEL = "EMM"
+    th.TRACK_THRESH = 0.4
+    th.START_TRACK_THRESH = 0.6
+    th.RESUME_TRACK_THRESH = 0.4
+    th.MAX_DORMANT_FRAMES = 1
+    th.EMM = CfgNode(USE_CENTERNESS=True, POS_RATIO=0.25, HN_RATIO=0.25, TRACK_LOSS_WEIGHT=1.0,
+                     CLS_POS_REGION=0.8, COSINE_WINDOW_WEIGHT=0.4)
+    cfg.MODEL.TRACK_HEAD = th
+    return cfg

@@ -1,0 +1,282 @@
+// K4 — fused bicubic up-sampling + location grid + response decode + argmax.
+//
+// Replaces, in EMM.forward (reference EMM/track_core.py:69-77): 3 x F.interpolate(scale_factor=16,
+// mode='bicubic') (7 planes of G x G fp32 per track written and re-read ~20 times), get_locations
+// (:184-225, a per-track Python loop materialising [N, G*G, 2]) and decode_response (:101-135).
+// Nothing of size G*G ever reaches HBM here: the 7 x Ho x Ho logits of a track (7 KB) sit in LDS and
+// every up-sampled value is produced in registers, scored, and folded into a running arg-max.
+//
+// Pass 1 (grid N x (Ho+1)): workgroup (n, f) owns the output rows whose bicubic source row is f
+// (`up` rows; up/2 at the two borders).  A lane owns output column X: it first builds, for the
+// four source rows f-1..f+2, the horizontally interpolated values of all 7 channels (28 registers,
+// reused by every output row of the band), then walks the band's rows: vertical 4-tap, softmax /
+// sigmoid / scale penalty / Hann window, compare.  The (score, index) winner of the workgroup is
+// written as one 64-bit key to the caller's workspace — no atomics, no initialisation.
+// Pass 2 (grid N): reduces the Ho+1 keys of a track, re-evaluates the 7 up-sampled channels at the
+// winning cell only, forms the location analytically from the search region and writes box,
+// confidence and flat index.
+//
+// Arithmetic follows the reference op by op in fp32 (separately rounded mul/add where torch runs
+// separate kernels); NaN scores win and ties go to the lowest flat index, as torch.argmax on CPU.
+#include "smot_common.h"
+
+namespace smot {
+
+// torch upsample_bicubic2d coefficients (A = -0.75) for fractional offset t.
+__device__ __forceinline__ void cubic_coeffs(float t, float* w) {
+    const float A = -0.75f;
+    const float x1 = t;
+    w[0] = ((A * (x1 + 1.0f) - 5.0f * A) * (x1 + 1.0f) + 8.0f * A) * (x1 + 1.0f) - 4.0f * A;
+    w[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    const float x2 = 1.0f - t;
+    w[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    w[3] = ((A * (x2 + 1.0f) - 5.0f * A) * (x2 + 1.0f) + 8.0f * A) * (x2 + 1.0f) - 4.0f * A;
+}
+
+// source position of output index d: scale*(d+0.5)-0.5 (align_corners=False), floor and fraction.
+__device__ __forceinline__ void cubic_src(int d, float inv_up, int* base, float* t) {
+    const float src = inv_up * ((float)d + 0.5f) - 0.5f;
+    const float f = floorf(src);
+    *base = (int)f;
+    *t = src - f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
+    return a * w[0] + b * w[1] + c * w[2] + d * w[3];
+}
+
+// Order-preserving key: larger score <-> larger key; NaN above everything; -0 == +0.
+__device__ __forceinline__ unsigned score_key(float s) {
+    if (s != s) return 0xFFFFFFFFu;
+    s = s + 0.0f;   // -0 -> +0
+    const unsigned b = __float_as_uint(s);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__device__ __forceinline__ unsigned long long make_key(float s, unsigned idx) {
+    return ((unsigned long long)score_key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+struct DecodeParams {
+    int Ho, up, G;
+    float inv_up;
+    float one_minus_sigma, sigma;
+    int use_centerness;
+};
+
+// penalised confidence of one up-sampled cell; v = {cls0, cls1, center, l, t, r, b}
+__device__ __forceinline__ float cell_score(const float* v, float box_w, float box_h, float win,
+                                            const DecodeParams& D) {
+    const float m = fmaxf(v[0], v[1]);
+    const float e0 = expf(sub_rn(v[0], m));
+    const float e1 = expf(sub_rn(v[1], m));
+    float conf = div_rn(e1, add_rn(e0, e1));
+    if (D.use_centerness) {
+        const float sig = div_rn(1.0f, add_rn(1.0f, expf(-v[2])));
+        conf = mul_rn(conf, sig);
+    }
+    const float r_w = add_rn(v[5], v[3]);
+    const float r_h = add_rn(v[6], v[4]);
+    float s_w = div_rn(r_w, box_w);
+    float s_h = div_rn(r_h, box_h);
+    s_w = max_nan(s_w, div_rn(1.0f, s_w));
+    s_h = max_nan(s_h, div_rn(1.0f, s_h));
+    const float pen = expf(mul_rn(add_rn(mul_rn(-s_w, s_h), 1.0f), 0.1f));
+    return add_rn(mul_rn(mul_rn(conf, pen), D.one_minus_sigma), mul_rn(D.sigma, win));
+}
+
+constexpr int DEC_MAX_COLS = 4;   // output columns per lane: G <= 1024
+
+__global__ void __launch_bounds__(256)
+decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                   const float* __restrict__ hann, DecodeParams D,
+                   unsigned long long* __restrict__ cand) {
+    extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
+    __shared__ unsigned long long wbest[4];
+    const int n = blockIdx.x;
+    const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
+    const int Ho = D.Ho, up = D.up, G = D.G;
+    const float* __restrict__ src = logits + (size_t)n * 7 * Ho * Ho;
+    for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) lg[e] = src[e];
+    __syncthreads();
+
+    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
+    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
+    const int y_begin = max(0, up * f + up / 2);
+    const int y_end = min(G, up * f + up / 2 + up);
+    int rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
+
+    unsigned long long best = 0ull;
+    bool have = false;
+#pragma unroll 1
+    for (int j = 0; j < DEC_MAX_COLS; ++j) {
+        const int X = threadIdx.x + 256 * j;
+        if (X >= G) break;
+        int bx;
+        float tx, wx[4];
+        cubic_src(X, D.inv_up, &bx, &tx);
+        cubic_coeffs(tx, wx);
+        int cols[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
+        // horizontal pass: h[ch][k] for the band's four source rows
+        float h[7][4];
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float* rowp = lg + (ch * Ho + rows[k]) * Ho;
+                h[ch][k] = interp4(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
+            }
+        const float hx = hann[X];
+        for (int Y = y_begin; Y < y_end; ++Y) {
+            int by;
+            float ty, wy[4];
+            cubic_src(Y, D.inv_up, &by, &ty);
+            cubic_coeffs(ty, wy);
+            float v[7];
+#pragma unroll
+            for (int ch = 0; ch < 7; ++ch) v[ch] = interp4(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
+            const float win = mul_rn(hann[Y], hx);
+            const float s = cell_score(v, box_w, box_h, win, D);
+            const unsigned long long key = make_key(s, (unsigned)(Y * G + X));
+            if (!have || key > best) {
+                best = key;
+                have = true;
+            }
+        }
+    }
+    // lanes without a column carry key 0 (below every real key: real keys have a non-zero low word
+    // unless idx == 0xFFFFFFFF, which cannot occur)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = (o > best) ? o : best;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wbest[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = wbest[0];
+        for (int w = 1; w < 4; ++w) b = (wbest[w] > b) ? wbest[w] : b;
+        cand[(size_t)n * gridDim.y + blockIdx.y] = b;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict__ sr,
+                       const float* __restrict__ boxes, DecodeParams D, int rx, int rz, float pad,
+                       const unsigned long long* __restrict__ cand, int nband,
+                       float* __restrict__ bb, float* __restrict__ conf, long long* __restrict__ idx_out) {
+    const int n = blockIdx.x;
+    const int lane = threadIdx.x;
+    unsigned long long best = 0ull;
+    for (int b = lane; b < nband; b += 64) {
+        const unsigned long long k = cand[(size_t)n * nband + b];
+        best = (k > best) ? k : best;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = (o > best) ? o : best;
+    }
+    if (lane != 0) return;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+    const int Ho = D.Ho, G = D.G;
+    const int Y = (int)(idx / (unsigned)G), X = (int)(idx - (unsigned)Y * (unsigned)G);
+    int bx, by;
+    float tx, ty, wx[4], wy[4];
+    cubic_src(X, D.inv_up, &bx, &tx);
+    cubic_src(Y, D.inv_up, &by, &ty);
+    cubic_coeffs(tx, wx);
+    cubic_coeffs(ty, wy);
+    int cols[4], rows[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
+        rows[k] = clampi(by - 1 + k, 0, Ho - 1);
+    }
+    const float* __restrict__ src = logits + (size_t)n * 7 * Ho * Ho;
+    float v[7];
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) {
+        float h[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float* rowp = src + (ch * Ho + rows[k]) * Ho;
+            h[k] = interp4(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
+        }
+        v[ch] = interp4(h[0], h[1], h[2], h[3], wy);
+    }
+    // get_locations (track_core.py:184-225): x_k = x1 + (st+k)*((x2-x1)/(rx*up-1)), then -= pad
+    const int full = rx * D.up;
+    const int st = (rz / 2) * D.up;
+    const float sx1 = sr[n * 4 + 0], sy1 = sr[n * 4 + 1], sx2 = sr[n * 4 + 2], sy2 = sr[n * 4 + 3];
+    const float stride_w = div_rn(sub_rn(sx2, sx1), (float)(full - 1));
+    const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
+    const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), pad);
+    const float cy = sub_rn(add_rn(sy1, mul_rn((float)(st + Y), stride_h)), pad);
+    bb[n * 4 + 0] = sub_rn(cx, v[3]);
+    bb[n * 4 + 1] = sub_rn(cy, v[4]);
+    bb[n * 4 + 2] = add_rn(cx, v[5]);
+    bb[n * 4 + 3] = add_rn(cy, v[6]);
+    const float m = fmaxf(v[0], v[1]);
+    const float e0 = expf(sub_rn(v[0], m)), e1 = expf(sub_rn(v[1], m));
+    conf[n] = div_rn(e1, add_rn(e0, e1));
+    if (idx_out != nullptr) idx_out[n] = (long long)idx;
+}
+
+}  // namespace smot
+
+extern "C" int smot_emm_decode_ws_floats(int Ho, int up) {
+    (void)up;
+    return 2 * (Ho + 1);
+}
+
+extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
+                                   int N, int Ho, int up, int rx, int rz, float pad_pixels, float one_minus_sigma,
+                                   float sigma, int use_centerness, float* cand_ws, float* bb, float* conf,
+                                   int64_t* idx, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && Ho > 0 && up > 0, "decode: bad sizes N=%d Ho=%d up=%d", N, Ho, up);
+    SMOT_REQUIRE(rx - rz + 1 == Ho && (rz & 1) == 1, "decode: need Ho == rx-rz+1 and odd rz (Ho=%d rx=%d rz=%d)", Ho,
+                 rx, rz);
+    if ((up & (up - 1)) != 0 || up < 2) {
+        set_error("decode: up=%d unsupported (power of two >= 2 required; the reference uses 16)", up);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    const long long G = (long long)Ho * up;
+    SMOT_REQUIRE(G <= 256 * DEC_MAX_COLS, "decode: grid %lld too wide (max %d)", G, 256 * DEC_MAX_COLS);
+    const size_t smem = (size_t)7 * Ho * Ho * sizeof(float);
+    SMOT_REQUIRE(smem <= 64 * 1024, "decode: Ho=%d too large for LDS", Ho);
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(logits && sr && boxes && hann && cand_ws && bb && conf, "decode: null pointer");
+    SMOT_REQUIRE(((uintptr_t)cand_ws & 7) == 0, "decode: cand_ws must be 8-byte aligned");
+    DecodeParams D;
+    D.Ho = Ho;
+    D.up = up;
+    D.G = (int)G;
+    D.inv_up = 1.0f / (float)up;
+    D.one_minus_sigma = one_minus_sigma;
+    D.sigma = sigma;
+    D.use_centerness = use_centerness;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(cand_ws);
+    hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, logits, boxes, hann, D, cand);
+    int rc = check_launch("decode bands");
+    if (rc) return rc;
+    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, logits, sr, boxes, D, rx, rz, pad_pixels,
+                       (const unsigned long long*)cand, Ho + 1, bb, conf, (long long*)idx);
+    return check_launch("decode finalize");
+}

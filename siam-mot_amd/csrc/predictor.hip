@@ -1,0 +1,435 @@
+// K3 — EMM prediction towers (conv3x3 + GroupNorm + ReLU) and heads (conv3x3 + bias).
+//
+// Replaces EMMPredictor.forward (reference EMM/feature_extractor.py:62-69; make_conv3x3 /
+// group_norm [UPSTREAM maskrcnn_benchmark modeling/make_layers.py]).
+//
+// Towers (the only dense contraction of the EMM head): both towers read the same response map,
+// so they are one implicit GEMM per track,  D[2C x Ho*Ho] = W[2C x 9C] * im2col(resp)[9C x Ho*Ho],
+// run on the fp32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32, bitwise a k-ordered fmaf
+// chain — parity with the fp32 reference is kept; no bf16/xf32 shortcut).
+//   workgroup  = (track, 32 output channels) x all 256 positions  -> every GroupNorm group of the
+//                tile is complete inside the workgroup, so GN + ReLU are fused into the epilogue;
+//   wave w     = the 32 channels x positions of rows 4w..4w+3 (2 M-tiles x 4 N-tiles, 32 acc VGPRs);
+//   K order    = input-channel chunk (16) > tap (9) > 4 channels per MFMA;
+//   LDS        = per chunk an A image [36 k-steps][2][64 lanes] (lane-linear, conflict-free
+//                ds_read_b32) and a B image of 16 zero-haloed 18x18 planes at plane stride 336
+//                (336 mod 32 = 16: the two k-rows of a 32-lane group land on disjoint banks);
+//                both double-buffered (79,872 B -> two workgroups per CU), next chunk prefetched
+//                into registers while the current one feeds the matrix cores.
+// Heads: 7 output channels, 4 MFLOP/track — plain VALU from LDS-staged tower planes, head weights
+// as wave-uniform scalar loads.
+// A generic (any Ho / channel count) tower kernel covers shapes the MFMA tiling does not.
+#include "smot_common.h"
+
+namespace smot {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int T_OC = 32;          // output channels per workgroup
+constexpr int T_IC = 16;          // input channels per K chunk
+constexpr int T_STEPS = 9 * (T_IC / 4);          // MFMA k-steps per chunk (36)
+constexpr int T_A_FLOATS = T_STEPS * 2 * 64;     // 4608
+constexpr int T_PLANE = 336;                     // 18*18 = 324 padded to 336
+constexpr int T_B_FLOATS = T_IC * T_PLANE;       // 5376
+constexpr int T_BUF_FLOATS = T_A_FLOATS + T_B_FLOATS;
+constexpr int T_A_PER_THREAD = T_OC * T_IC * 9 / 256;   // 18
+constexpr int T_B_PER_THREAD = T_IC;                    // 16 (one position of each plane)
+
+struct TowerParams {
+    const float* w[2];      // [C, C, 3, 3] cls_tower.0.weight / reg_tower.0.weight
+    const float* gamma[2];  // [C]
+    const float* beta[2];   // [C]
+};
+
+__device__ __forceinline__ float group16_sum(float v) {
+    // sum over the 16 lanes that share lane>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+__global__ void __launch_bounds__(256)
+tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
+                  float* __restrict__ tower_ws) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_per_tower = C / T_OC;
+    const int tiles = 2 * tiles_per_tower;
+    const int n = blockIdx.x / tiles;
+    const int tile = blockIdx.x - n * tiles;
+    const int tower = tile / tiles_per_tower;
+    const int oc0 = (tile - tower * tiles_per_tower) * T_OC;
+    const float* __restrict__ W = P.w[tower];
+    const float* __restrict__ in = resp + (size_t)n * C * 256;
+
+    // zero both buffers once: the B halos stay zero for the whole kernel
+    for (int e = tid; e < 2 * T_BUF_FLOATS; e += 256) sm[e] = 0.0f;
+
+    float pa[T_A_PER_THREAD], pb[T_B_PER_THREAD];
+    auto load_chunk = [&](int ic0) {
+#pragma unroll
+        for (int j = 0; j < T_A_PER_THREAD; ++j) {
+            const int idx = tid + 256 * j;          // over [32 oc][16 ic * 9]
+            const int oc = idx / (T_IC * 9);
+            const int rem = idx - oc * (T_IC * 9);
+            pa[j] = W[((size_t)(oc0 + oc) * C + ic0) * 9 + rem];
+        }
+#pragma unroll
+        for (int j = 0; j < T_B_PER_THREAD; ++j) pb[j] = in[(size_t)(ic0 + j) * 256 + tid];
+    };
+    auto store_chunk = [&](float* buf) {
+        float* A = buf;
+        float* B = buf + T_A_FLOATS;
+#pragma unroll
+        for (int j = 0; j < T_A_PER_THREAD; ++j) {
+            const int idx = tid + 256 * j;
+            const int oc = idx / (T_IC * 9);
+            const int rem = idx - oc * (T_IC * 9);
+            const int ic = rem / 9;
+            const int tap = rem - ic * 9;
+            const int s = tap * (T_IC / 4) + (ic >> 2);
+            A[((s * 2 + (oc >> 4)) * 4 + (ic & 3)) * 16 + (oc & 15)] = pa[j];
+        }
+        const int y = tid >> 4, x = tid & 15;
+#pragma unroll
+        for (int j = 0; j < T_B_PER_THREAD; ++j) B[j * T_PLANE + (y + 1) * 18 + (x + 1)] = pb[j];
+    };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    __syncthreads();                 // zero-fill complete before interior writes
+    store_chunk(sm);
+    __syncthreads();
+
+    const int nchunks = C / T_IC;
+    const int kq = lane >> 4, xl = lane & 15;
+    for (int c = 0; c < nchunks; ++c) {
+        float* buf = sm + (c & 1) * T_BUF_FLOATS;
+        if (c + 1 < nchunks) load_chunk((c + 1) * T_IC);
+        const float* A = buf + lane;
+        const float* B = buf + T_A_FLOATS + kq * T_PLANE + (4 * wave) * 18 + xl;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int icq = 0; icq < T_IC / 4; ++icq) {
+                const int s = tap * (T_IC / 4) + icq;
+                const float a0 = A[(s * 2 + 0) * 64];
+                const float a1 = A[(s * 2 + 1) * 64];
+                const float* Bp = B + (4 * icq) * T_PLANE + dy * 18 + dx;
+                const float b0 = Bp[0 * 18], b1 = Bp[1 * 18], b2 = Bp[2 * 18], b3 = Bp[3 * 18];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc[0][2], 0, 0, 0);
+                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b2, acc[1][2], 0, 0, 0);
+                acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b3, acc[0][3], 0, 0, 0);
+                acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b3, acc[1][3], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * T_BUF_FLOATS);
+        __syncthreads();
+    }
+
+    // ---- fused GroupNorm (two-pass, fp32) + affine + ReLU -----------------------------------
+    // acc[m][t][r] = conv[oc = m*16 + kq*4 + r][pos = (4*wave + t)*16 + xl]
+    float* red = sm;                       // [4 waves][32 channels], reused twice
+    float* stat = sm + 4 * T_OC;           // [32] group mean / rstd per channel
+    const float inv_cnt = 1.0f / (float)(cpg * 256);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = acc[m][0][r] + acc[m][1][r] + acc[m][2][r] + acc[m][3][r];
+            s = group16_sum(s);
+            if (xl == 0) red[wave * T_OC + m * 16 + kq * 4 + r] = s;
+        }
+    __syncthreads();
+    if (tid < T_OC) {
+        const int g0 = (tid / cpg) * cpg;
+        float s = 0.0f;
+        for (int ch = g0; ch < g0 + cpg; ++ch)
+            s += red[0 * T_OC + ch] + red[1 * T_OC + ch] + red[2 * T_OC + ch] + red[3 * T_OC + ch];
+        stat[tid] = s * inv_cnt;
+    }
+    __syncthreads();
+    float mean[2][4];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mean[m][r] = stat[m * 16 + kq * 4 + r];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float d = acc[m][t][r] - mean[m][r];
+                s += d * d;
+            }
+            s = group16_sum(s);
+            if (xl == 0) red[wave * T_OC + m * 16 + kq * 4 + r] = s;
+        }
+    __syncthreads();
+    if (tid < T_OC) {
+        const int g0 = (tid / cpg) * cpg;
+        float s = 0.0f;
+        for (int ch = g0; ch < g0 + cpg; ++ch)
+            s += red[0 * T_OC + ch] + red[1 * T_OC + ch] + red[2 * T_OC + ch] + red[3 * T_OC + ch];
+        stat[tid] = 1.0f / sqrtf(s * inv_cnt + eps);
+    }
+    __syncthreads();
+    const float* __restrict__ gamma = P.gamma[tower];
+    const float* __restrict__ beta = P.beta[tower];
+    float* __restrict__ dst = tower_ws + ((size_t)n * 2 * C + (size_t)tower * C + oc0) * 256;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ocl = m * 16 + kq * 4 + r;
+            const float rstd = stat[ocl];
+            const float ga = gamma[oc0 + ocl], be = beta[oc0 + ocl];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float v = (acc[m][t][r] - mean[m][r]) * rstd * ga + be;
+                v = fmaxf(v, 0.0f);
+                dst[(size_t)ocl * 256 + (4 * wave + t) * 16 + xl] = v;
+            }
+        }
+}
+
+// Any Ho / C: one workgroup per (track, tower, GroupNorm group); direct convolution, outputs kept
+// in LDS for the two-pass GroupNorm.
+__global__ void __launch_bounds__(256)
+tower_generic_kernel(const float* __restrict__ resp, TowerParams P, int C, int Ho, int cpg, float eps,
+                     float* __restrict__ tower_ws) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float red[256];
+    const int HW = Ho * Ho;
+    const int groups = C / cpg;
+    const int n = blockIdx.x / (2 * groups);
+    const int rem = blockIdx.x - n * 2 * groups;
+    const int tower = rem / groups;
+    const int oc0 = (rem - tower * groups) * cpg;
+    const float* __restrict__ W = P.w[tower];
+    const float* __restrict__ in = resp + (size_t)n * C * HW;
+    const int total = cpg * HW;
+    float lsum = 0.0f;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int ocl = e / HW;
+        const int pos = e - ocl * HW;
+        const int y = pos / Ho, x = pos - y * Ho;
+        const float* __restrict__ w = W + (size_t)(oc0 + ocl) * C * 9;
+        float acc = 0.0f;
+        for (int ic = 0; ic < C; ++ic) {
+            const float* __restrict__ pl = in + (size_t)ic * HW;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = y + dy - 1;
+                if (yy < 0 || yy >= Ho) continue;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = x + dx - 1;
+                    if (xx < 0 || xx >= Ho) continue;
+                    acc = fmaf(pl[yy * Ho + xx], w[ic * 9 + dy * 3 + dx], acc);
+                }
+            }
+        }
+        sm[e] = acc;
+        lsum += acc;
+    }
+    auto block_sum = [&](float v) -> float {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        const float r = red[0];
+        __syncthreads();
+        return r;
+    };
+    const float mean = block_sum(lsum) / (float)total;
+    float lvar = 0.0f;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const float d = sm[e] - mean;
+        lvar += d * d;
+    }
+    const float rstd = 1.0f / sqrtf(block_sum(lvar) / (float)total + eps);
+    const float* __restrict__ gamma = P.gamma[tower];
+    const float* __restrict__ beta = P.beta[tower];
+    float* __restrict__ dst = tower_ws + ((size_t)n * 2 * C + (size_t)tower * C + oc0) * HW;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int ocl = e / HW;
+        const float v = (sm[e] - mean) * rstd * gamma[oc0 + ocl] + beta[oc0 + ocl];
+        dst[e] = fmaxf(v, 0.0f);
+    }
+}
+
+struct HeadParams {
+    const float* w[4];   // per output channel: [C*9] filter (device)
+    const float* b[4];   // per output channel: bias scalar (device)
+    int n_out;
+    int relu;
+    int in_ch0;          // first tower_ws channel of this tower
+    int out_ch0;         // first logits channel
+};
+
+// Heads: grid (N, 2).  Tower planes are staged 16 at a time into zero-haloed LDS planes; each
+// thread owns positions pos, pos+256, ... and accumulates up to 4 output channels.
+constexpr int H_IC = 16;
+constexpr int H_MAXPOS = 4;     // positions per thread (Ho*Ho <= 1024)
+
+__global__ void __launch_bounds__(256)
+heads_kernel(const float* __restrict__ tower_ws, HeadParams P0, HeadParams P1, int C, int Ho,
+             float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const HeadParams& P = (blockIdx.y == 0) ? P0 : P1;
+    const int n = blockIdx.x;
+    const int HW = Ho * Ho;
+    const int PW = Ho + 2;
+    const int plane = PW * PW;
+    const float* __restrict__ in = tower_ws + ((size_t)n * 2 * C + P.in_ch0) * HW;
+    float acc[H_MAXPOS][4];
+#pragma unroll
+    for (int p = 0; p < H_MAXPOS; ++p)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[p][o] = 0.0f;
+    for (int e = threadIdx.x; e < H_IC * plane; e += blockDim.x) sm[e] = 0.0f;
+    __syncthreads();
+    for (int ic0 = 0; ic0 < C; ic0 += H_IC) {
+        for (int e = threadIdx.x; e < H_IC * HW; e += blockDim.x) {
+            const int ic = e / HW;
+            const int pos = e - ic * HW;
+            const int y = pos / Ho, x = pos - y * Ho;
+            sm[ic * plane + (y + 1) * PW + (x + 1)] = (ic0 + ic < C) ? in[(size_t)(ic0 + ic) * HW + pos] : 0.0f;
+        }
+        __syncthreads();
+        const int icn = min(H_IC, C - ic0);
+        for (int ic = 0; ic < icn; ++ic) {
+            float wv[4][9];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wv[o][k] = (o < P.n_out) ? P.w[o][(ic0 + ic) * 9 + k] : 0.0f;
+#pragma unroll
+            for (int p = 0; p < H_MAXPOS; ++p) {
+                const int pos = threadIdx.x + p * 256;
+                if (pos < HW) {
+                    const int y = pos / Ho, x = pos - y * Ho;
+                    const float* s = sm + ic * plane + y * PW + x;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const float v = s[(k / 3) * PW + (k % 3)];
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) acc[p][o] = fmaf(v, wv[o][k], acc[p][o]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < H_MAXPOS; ++p) {
+        const int pos = threadIdx.x + p * 256;
+        if (pos < HW) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < P.n_out) {
+                    float v = acc[p][o] + P.b[o][0];
+                    if (P.relu) v = fmaxf(v, 0.0f);
+                    logits[((size_t)n * 7 + P.out_ch0 + o) * HW + pos] = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace smot
+
+extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, const float* cls_tower_w,
+                                      const float* cls_gn_w, const float* cls_gn_b, const float* reg_tower_w,
+                                      const float* reg_gn_w, const float* reg_gn_b, const float* cls_w,
+                                      const float* cls_b, const float* center_w, const float* center_b,
+                                      const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
+                                      float* tower_ws, float* logits, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && C > 0 && Ho > 0 && gn_groups > 0, "predictor: bad sizes N=%d C=%d Ho=%d groups=%d", N, C,
+                 Ho, gn_groups);
+    SMOT_REQUIRE(C % gn_groups == 0, "predictor: C=%d not divisible by gn_groups=%d", C, gn_groups);
+    SMOT_REQUIRE(Ho * Ho <= 256 * H_MAXPOS, "predictor: Ho=%d too large (max %d positions)", Ho, 256 * H_MAXPOS);
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(resp && cls_tower_w && cls_gn_w && cls_gn_b && reg_tower_w && reg_gn_w && reg_gn_b && cls_w &&
+                     cls_b && center_w && center_b && reg_w && reg_b && tower_ws && logits,
+                 "predictor: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    TowerParams T;
+    T.w[0] = cls_tower_w;
+    T.gamma[0] = cls_gn_w;
+    T.beta[0] = cls_gn_b;
+    T.w[1] = reg_tower_w;
+    T.gamma[1] = reg_gn_w;
+    T.beta[1] = reg_gn_b;
+    const int cpg = C / gn_groups;
+    const bool mfma_ok = (Ho == 16) && (C % T_OC == 0) && (C % T_IC == 0) && (cpg <= T_OC) && (T_OC % cpg == 0);
+    if (mfma_ok) {
+        const size_t smem = (size_t)2 * T_BUF_FLOATS * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)tower_mfma_kernel,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) {
+                set_error("predictor: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(tower_mfma_kernel, dim3(N * 2 * (C / T_OC)), dim3(256), smem, st, resp, T, C, cpg,
+                           gn_eps, tower_ws);
+    } else {
+        const size_t smem = (size_t)cpg * Ho * Ho * sizeof(float);
+        SMOT_REQUIRE(smem <= 64 * 1024, "predictor: GroupNorm group too large for the generic tower kernel");
+        hipLaunchKernelGGL(tower_generic_kernel, dim3(N * 2 * gn_groups), dim3(256), smem, st, resp, T, C, Ho, cpg,
+                           gn_eps, tower_ws);
+    }
+    int rc = check_launch("predictor towers");
+    if (rc) return rc;
+
+    HeadParams H0, H1;
+    H0.w[0] = cls_w;
+    H0.w[1] = cls_w + (size_t)C * 9;
+    H0.w[2] = center_w;
+    H0.w[3] = center_w;
+    H0.b[0] = cls_b;
+    H0.b[1] = cls_b + 1;
+    H0.b[2] = center_b;
+    H0.b[3] = center_b;
+    H0.n_out = 3;
+    H0.relu = 0;
+    H0.in_ch0 = 0;
+    H0.out_ch0 = 0;
+    for (int o = 0; o < 4; ++o) {
+        H1.w[o] = reg_w + (size_t)o * C * 9;
+        H1.b[o] = reg_b + o;
+    }
+    H1.n_out = 4;
+    H1.relu = 1;
+    H1.in_ch0 = C;
+    H1.out_ch0 = 3;
+    const size_t hsmem = (size_t)H_IC * (Ho + 2) * (Ho + 2) * sizeof(float);
+    SMOT_REQUIRE(hsmem <= 64 * 1024, "predictor: Ho=%d too large for the heads kernel", Ho);
+    hipLaunchKernelGGL(heads_kernel, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H0, H1, C, Ho, logits);
+    return check_launch("predictor heads");
+}

@@ -1,0 +1,244 @@
+// K1 — FPN-level-routed ROIAlign with virtual zero padding, and the search-region geometry.
+//
+// Replaces (see include/smot_emm.h): SRPooler.forward (reference EMM/sr_pool.py:53-91) incl.
+// LevelMapper and ROIAlign [UPSTREAM maskrcnn_benchmark csrc/cuda/ROIAlign_cuda.cu], the
+// TrackUtils.pad_feature pass (track_head/track_utils.py:87-107) and
+// update_boxes_in_pad_images + extend_bbox (track_utils.py:62-85,109-135).
+//
+// Work decomposition: one workgroup per (roi, group of CH_PER_BLOCK channels).  The per-axis
+// sample bookkeeping of the legacy ROIAlign (validity, clamp, low/high cell, bilinear weights —
+// all channel-independent) is computed once per workgroup into LDS tables; cells that fall in
+// the virtual zero border get weight 0 and a safe index, so the inner loop is branch-free.
+// Lanes walk the flattened (ph,pw) bin index, so stores are fully coalesced and the gathers of
+// neighbouring lanes hit neighbouring cells of one feature row.
+#include "smot_common.h"
+
+namespace smot {
+
+struct LevelParams {
+    const float* feat[SMOT_MAX_LEVELS];
+    int H[SMOT_MAX_LEVELS];
+    int W[SMOT_MAX_LEVELS];
+    int pad[SMOT_MAX_LEVELS];
+    float scale[SMOT_MAX_LEVELS];
+    int num_levels;
+    float k_min, k_max;
+};
+
+// [UPSTREAM] LevelMapper: floor(4 + log2(sqrt(area)/224 + 1e-6)), clamped, 0-based.
+__device__ __forceinline__ int map_level(const float* b, float k_min, float k_max) {
+    const float w = add_rn(sub_rn(b[2], b[0]), 1.0f);
+    const float h = add_rn(sub_rn(b[3], b[1]), 1.0f);
+    const float s = sqrtf(mul_rn(w, h));
+    float lvl = floorf(add_rn(4.0f, log2f(add_rn(div_rn(s, 224.0f), 1e-6f))));
+    lvl = fminf(fmaxf(lvl, k_min), k_max);
+    return (int)lvl - (int)k_min;
+}
+
+// One axis sample of the legacy ROIAlign, evaluated against the PADDED extent `size_p`
+// (= real + 2*pad) and re-expressed as indices into the REAL map.
+__device__ __forceinline__ void axis_sample(float start, float bin, int G, int s, int size_real,
+                                            int pad, int* lo, int* hi, float* w_lo, float* w_hi) {
+    const int p = s / G;
+    const int i = s - p * G;
+    const int size_p = size_real + 2 * pad;
+    // roi_start + p*bin + (i+.5f)*bin/G, each op rounded separately as in the reference
+    float c = add_rn(add_rn(start, mul_rn((float)p, bin)),
+                     div_rn(mul_rn((float)i + 0.5f, bin), (float)G));
+    const bool valid = !(c < -1.0f || c > (float)size_p);
+    if (c <= 0.0f) c = 0.0f;
+    int l = (int)c;
+    int h;
+    if (l >= size_p - 1) {
+        h = l = size_p - 1;
+        c = (float)l;
+    } else {
+        h = l + 1;
+    }
+    const float fl = sub_rn(c, (float)l);   // weight of the high cell
+    const float fh = sub_rn(1.0f, fl);      // weight of the low cell
+    const int lr = l - pad, hr = h - pad;
+    const bool lo_in = valid && lr >= 0 && lr < size_real;
+    const bool hi_in = valid && hr >= 0 && hr < size_real;
+    *lo = lo_in ? lr : 0;
+    *hi = hi_in ? hr : 0;
+    *w_lo = lo_in ? fh : 0.0f;
+    *w_hi = hi_in ? fl : 0.0f;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256)
+roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
+                        const float* __restrict__ level_boxes, int PH, int PW, int ch_per_block,
+                        float* __restrict__ out, int32_t* __restrict__ levels_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ny = PH * G, nx = PW * G;
+    int* y_lo = reinterpret_cast<int*>(smem);
+    int* y_hi = y_lo + ny;
+    float* wy_lo = reinterpret_cast<float*>(y_hi + ny);
+    float* wy_hi = wy_lo + ny;
+    int* x_lo = reinterpret_cast<int*>(wy_hi + ny);
+    int* x_hi = x_lo + nx;
+    float* wx_lo = reinterpret_cast<float*>(x_hi + nx);
+    float* wx_hi = wx_lo + nx;
+
+    const int r = blockIdx.x;
+    const float* roi = rois + (size_t)r * 4;
+    int lvl = 0;
+    if (P.num_levels > 1) lvl = map_level(level_boxes + (size_t)r * 4, P.k_min, P.k_max);
+    if (levels_out != nullptr && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
+
+    const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
+    const float scale = P.scale[lvl];
+    const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
+    const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
+    const float roi_w = fmaxf(sub_rn(x2, x1), 1.0f);
+    const float roi_h = fmaxf(sub_rn(y2, y1), 1.0f);
+    const float bin_h = div_rn(roi_h, (float)PH);
+    const float bin_w = div_rn(roi_w, (float)PW);
+
+    for (int s = threadIdx.x; s < ny + nx; s += blockDim.x) {
+        if (s < ny) {
+            int lo, hi;
+            float wl, wh;
+            axis_sample(y1, bin_h, G, s, H, pad, &lo, &hi, &wl, &wh);
+            y_lo[s] = lo * W;
+            y_hi[s] = hi * W;
+            wy_lo[s] = wl;
+            wy_hi[s] = wh;
+        } else {
+            const int sx = s - ny;
+            int lo, hi;
+            float wl, wh;
+            axis_sample(x1, bin_w, G, sx, W, pad, &lo, &hi, &wl, &wh);
+            x_lo[sx] = lo;
+            x_hi[sx] = hi;
+            wx_lo[sx] = wl;
+            wx_hi[sx] = wh;
+        }
+    }
+    __syncthreads();
+
+    const int c0 = blockIdx.y * ch_per_block;
+    const int c1 = min(C, c0 + ch_per_block);
+    const int bins = PH * PW;
+    const float* __restrict__ f = P.feat[lvl];
+    for (int t = threadIdx.x; t < bins; t += blockDim.x) {
+        const int ph = t / PW;
+        const int pw = t - ph * PW;
+        int ylo[G], yhi[G], xlo[G], xhi[G];
+        float wyl[G], wyh[G], wxl[G], wxh[G];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            ylo[i] = y_lo[ph * G + i];
+            yhi[i] = y_hi[ph * G + i];
+            wyl[i] = wy_lo[ph * G + i];
+            wyh[i] = wy_hi[ph * G + i];
+            xlo[i] = x_lo[pw * G + i];
+            xhi[i] = x_hi[pw * G + i];
+            wxl[i] = wx_lo[pw * G + i];
+            wxh[i] = wx_hi[pw * G + i];
+        }
+        for (int c = c0; c < c1; ++c) {
+            const float* __restrict__ fc = f + (size_t)c * H * W;
+            float acc = 0.0f;
+#pragma unroll
+            for (int iy = 0; iy < G; ++iy) {
+#pragma unroll
+                for (int ix = 0; ix < G; ++ix) {
+                    const float v1 = fc[ylo[iy] + xlo[ix]];
+                    const float v2 = fc[ylo[iy] + xhi[ix]];
+                    const float v3 = fc[yhi[iy] + xlo[ix]];
+                    const float v4 = fc[yhi[iy] + xhi[ix]];
+                    const float w1 = wyl[iy] * wxl[ix], w2 = wyl[iy] * wxh[ix];
+                    const float w3 = wyh[iy] * wxl[ix], w4 = wyh[iy] * wxh[ix];
+                    acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                }
+            }
+            out[((size_t)r * C + c) * bins + t] = acc / (float)(G * G);
+        }
+    }
+}
+
+__global__ void search_region_kernel(const float* __restrict__ boxes, int N, float pad, float half_e,
+                                     float two_e, float min_wh, float* __restrict__ sr) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float x1 = add_rn(boxes[n * 4 + 0], pad), y1 = add_rn(boxes[n * 4 + 1], pad);
+    const float x2 = add_rn(boxes[n * 4 + 2], pad), y2 = add_rn(boxes[n * 4 + 3], pad);
+    const float w = add_rn(sub_rn(x2, x1), 1.0f);
+    const float h = add_rn(sub_rn(y2, y1), 1.0f);
+    const float w_ext = max_nan(div_rn(sub_rn(min_wh, w), two_e), mul_rn(w, half_e));
+    const float h_ext = max_nan(div_rn(sub_rn(min_wh, h), two_e), mul_rn(h, half_e));
+    sr[n * 4 + 0] = sub_rn(x1, w_ext);
+    sr[n * 4 + 1] = sub_rn(y1, h_ext);
+    sr[n * 4 + 2] = add_rn(x2, w_ext);
+    sr[n * 4 + 3] = add_rn(y2, h_ext);
+}
+
+}  // namespace smot
+
+extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* heights,
+                                         const int* widths, const int* pad_cells,
+                                         const float* scales, int num_levels, int C,
+                                         const float* rois, const float* level_boxes, int R,
+                                         int out_h, int out_w, int sampling_ratio, float* out,
+                                         int32_t* levels_out, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(feats && heights && widths && pad_cells && scales, "roi_align: null level array");
+    SMOT_REQUIRE(num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "roi_align: num_levels=%d not in [1,%d]",
+                 num_levels, SMOT_MAX_LEVELS);
+    SMOT_REQUIRE(C > 0 && out_h > 0 && out_w > 0 && R >= 0, "roi_align: bad sizes C=%d out=%dx%d R=%d", C,
+                 out_h, out_w, R);
+    if (sampling_ratio <= 0 || sampling_ratio > 4) {
+        set_error("roi_align: sampling_ratio=%d unsupported (need 1..4; adaptive grid not implemented)",
+                  sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (R == 0) return SMOT_OK;
+    SMOT_REQUIRE(rois && out, "roi_align: null rois/out");
+    SMOT_REQUIRE(num_levels == 1 || level_boxes, "roi_align: level_boxes required for num_levels>1");
+    LevelParams P;
+    for (int l = 0; l < num_levels; ++l) {
+        SMOT_REQUIRE(feats[l] && heights[l] > 0 && widths[l] > 0 && pad_cells[l] >= 0 && scales[l] > 0.f,
+                     "roi_align: bad level %d", l);
+        P.feat[l] = feats[l];
+        P.H[l] = heights[l];
+        P.W[l] = widths[l];
+        P.pad[l] = pad_cells[l];
+        P.scale[l] = scales[l];
+    }
+    P.num_levels = num_levels;
+    P.k_min = -log2f(scales[0]);
+    P.k_max = -log2f(scales[num_levels - 1]);
+
+    const int ch_per_block = 4;
+    dim3 grid(R, (C + ch_per_block - 1) / ch_per_block);
+    const size_t smem = (size_t)(out_h + out_w) * sampling_ratio * 16;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(G)                                                                                       \
+    hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois, level_boxes, \
+                       out_h, out_w, ch_per_block, out, levels_out)
+    switch (sampling_ratio) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return check_launch("roi_align");
+}
+
+extern "C" int smot_search_region_fwd(const float* boxes, int N, float pad_pixels, float search_expansion,
+                                      float min_search_wh, float* sr, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0, "search_region: N=%d", N);
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(boxes && sr, "search_region: null pointer");
+    // the reference forms e/2 and e*2 in Python double before they meet the fp32 tensors
+    const float half_e = (float)((double)search_expansion / 2.0);
+    const float two_e = (float)((double)search_expansion * 2.0);
+    hipLaunchKernelGGL(search_region_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, boxes, N,
+                       pad_pixels, half_e, two_e, min_search_wh, sr);
+    return check_launch("search_region");
+}

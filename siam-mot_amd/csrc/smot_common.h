@@ -1,0 +1,43 @@
+// Shared helpers for libsmot_emm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/smot_emm.h"
+
+namespace smot {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return SMOT_OK;
+}
+
+#define SMOT_REQUIRE(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            smot::set_error(__VA_ARGS__);  \
+            return SMOT_ERR_BAD_ARG;       \
+        }                                  \
+    } while (0)
+
+// fp32 ops that must NOT be contracted into FMAs, so that the rounding sequence matches the
+// reference's separate torch mul / add kernels.
+__device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
+
+// torch.max / torch.maximum semantics: NaN propagates.
+__device__ __forceinline__ float max_nan(float a, float b) {
+    return (a != a) ? a : ((b != b) ? b : fmaxf(a, b));
+}
+
+}  // namespace smot

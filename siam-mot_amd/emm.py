@@ -1,0 +1,195 @@
+"""``EMM`` — the Siamese tracker head behind the reference's plug-in interface, on HIP kernels.
+
+Mirrors reference siammot/modelling/track_head/EMM/track_core.py:14-98 (class ``EMM``, registered
+in ``SIAMESE_TRACKER``), EMM/feature_extractor.py:9-69 (``EMMFeatureExtractor``, ``EMMPredictor``)
+and EMM/sr_pool.py:9-91 (``SRPooler``): same constructor arguments, same ``forward`` /
+``extract_cache`` signatures and return structure, same ``state_dict`` keys
+(``predictor.{cls_tower.0,cls_tower.1,reg_tower.0,reg_tower.1,cls,center,reg}.*``), so
+``TrackHead`` (track_head/track_head.py:8-126) and everything above it run unchanged.
+
+Inference only: the training branch of ``EMM.forward`` (track_core.py:45-47,56-67) is out of scope
+and raises.  All arithmetic happens in ``csrc/libsmot_emm.so``; nothing here falls back to eager.
+
+What differs from the reference on purpose (results are the same):
+  * ``TrackUtils.pad_feature`` is never materialised — the pooler pads virtually;
+  * no ``torch.nonzero`` host syncs for level routing — the kernel maps levels itself;
+  * the up-sampled 7x256x256 planes and the location tensor are never written.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .registry import SIAMESE_TRACKER
+from .structures import cat
+
+
+class SRPooler(nn.Module):
+    """FPN-level-routed pooler (reference EMM/sr_pool.py:9-91).
+
+    ``forward(x, boxes, sr=None)`` keeps the reference contract.  The extra ``pad_pixels`` keyword
+    tells the kernel that ``sr`` coordinates live in an image zero-padded by that many pixels while
+    ``x`` holds the UN-padded maps (what ``EMM.forward`` passes); with the default 0 it behaves
+    exactly like the reference pooler on whatever maps it is given.
+    """
+
+    def __init__(self, output_size, scales, sampling_ratio):
+        super(SRPooler, self).__init__()
+        self.output_size = output_size
+        self.scales = tuple(float(s) for s in scales)
+        self.sampling_ratio = sampling_ratio
+
+    def forward(self, x, boxes, sr=None, pad_pixels=0):
+        if self.output_size[0] != self.output_size[1]:
+            raise RuntimeError("SRPooler: square output expected, got %s" % (self.output_size,))
+        level_boxes = cat([b.bbox for b in boxes], dim=0)
+        rois = level_boxes if sr is None else cat([b.bbox for b in sr], dim=0)
+        if len(boxes) != 1:
+            raise RuntimeError("SRPooler: one image per call (reference track_core.py:75)")
+        pad_cells = [int(pad_pixels / ((2 ** i) * 4)) for i in range(len(self.scales))]
+        return ops.roi_align_levels(x, rois, level_boxes, self.output_size[0], self.scales,
+                                    self.sampling_ratio, pad_cells)
+
+
+class EMMFeatureExtractor(nn.Module):
+    """Template (Rz) and search-region (Rx = int(Rz * SEARCH_REGION)) poolers
+    (reference EMM/feature_extractor.py:9-40)."""
+
+    def __init__(self, cfg):
+        super(EMMFeatureExtractor, self).__init__()
+        th = cfg.MODEL.TRACK_HEAD
+        resolution = th.POOLER_RESOLUTION
+        r = th.SEARCH_REGION
+        self.pooler_z = SRPooler((resolution, resolution), th.POOLER_SCALES, th.POOLER_SAMPLING_RATIO)
+        self.pooler_x = SRPooler((int(resolution * r), int(resolution * r)), th.POOLER_SCALES,
+                                 th.POOLER_SAMPLING_RATIO)
+
+    def forward(self, x, proposals, sr=None, pad_pixels=0):
+        if sr is not None:
+            return self.pooler_x(x, proposals, sr, pad_pixels=pad_pixels)
+        return self.pooler_z(x, proposals)
+
+
+def _conv3x3(in_ch, out_ch, use_gn=False, use_relu=False, gn_groups=32, gn_eps=1e-5):
+    """[UPSTREAM] make_conv3x3(kaiming_init=False): normal(std=0.01) weights, zero bias."""
+    conv = nn.Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1, bias=not use_gn)
+    nn.init.normal_(conv.weight, std=0.01)
+    if not use_gn:
+        nn.init.constant_(conv.bias, 0)
+    mods = [conv]
+    if use_gn:
+        mods.append(nn.GroupNorm(gn_groups, out_ch, gn_eps, affine=True))
+    if use_relu:
+        mods.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*mods) if len(mods) > 1 else conv
+
+
+class EMMPredictor(nn.Module):
+    """Parameter container with the reference's module tree (EMM/feature_extractor.py:43-69); the
+    sub-modules are never called — ``forward`` hands their tensors to the HIP predictor."""
+
+    def __init__(self, cfg):
+        super(EMMPredictor, self).__init__()
+        body = cfg.MODEL.BACKBONE.CONV_BODY
+        if body.startswith("DLA"):
+            in_channels = cfg.MODEL.DLA.BACKBONE_OUT_CHANNELS
+        elif body.startswith("R-"):
+            in_channels = cfg.MODEL.RESNETS.BACKBONE_OUT_CHANNELS
+        else:
+            in_channels = 128
+        gn = getattr(cfg.MODEL, "GROUP_NORM", None)
+        self.gn_groups = gn.NUM_GROUPS if gn is not None else 32
+        self.gn_eps = gn.EPSILON if gn is not None else 1e-5
+        self.cls_tower = _conv3x3(in_channels, in_channels, True, True, self.gn_groups, self.gn_eps)
+        self.reg_tower = _conv3x3(in_channels, in_channels, True, True, self.gn_groups, self.gn_eps)
+        self.cls = _conv3x3(in_channels, 2)
+        self.center = _conv3x3(in_channels, 1)
+        self.reg = _conv3x3(in_channels, 4)
+
+    def forward_logits(self, x):
+        """→ ``[N,7,Ho,Ho]`` (cls0, cls1, center, reg l/t/r/b)."""
+        params = {k: v for k, v in self.named_parameters()}
+        return ops.emm_predictor(x, params, self.gn_groups, self.gn_eps)
+
+    def forward(self, x):
+        logits = self.forward_logits(x)
+        return logits[:, 0:2], logits[:, 2:3], logits[:, 3:7]
+
+
+class EMM(nn.Module):
+    """Drop-in for the reference ``EMM`` (EMM/track_core.py:14-98)."""
+
+    def __init__(self, cfg, track_utils):
+        super(EMM, self).__init__()
+        self.feature_extractor = EMMFeatureExtractor(cfg)
+        self.predictor = EMMPredictor(cfg)
+        self.track_utils = track_utils
+        self.amodal = cfg.INPUT.AMODAL
+        self.use_centerness = cfg.MODEL.TRACK_HEAD.EMM.USE_CENTERNESS
+        self.pad_pixels = cfg.MODEL.TRACK_HEAD.PAD_PIXELS
+        self.sigma = cfg.MODEL.TRACK_HEAD.EMM.COSINE_WINDOW_WEIGHT
+        self.rz = cfg.MODEL.TRACK_HEAD.POOLER_RESOLUTION
+        self.rx = int(self.rz * cfg.MODEL.TRACK_HEAD.SEARCH_REGION)
+
+    def forward(self, features, boxes, sr, targets=None, template_features=None):
+        if self.training:
+            raise NotImplementedError("siammot_amd.EMM is an inference path; training "
+                                      "(track_core.py:45-47,56-67) is out of scope")
+        assert len(boxes) == 1                                           # track_core.py:75
+        sr_features = self.feature_extractor(features, boxes, sr, pad_pixels=self.pad_pixels)
+        response_map = ops.xcorr_depthwise(sr_features, template_features)
+        logits = self.predictor.forward_logits(response_map)
+        bb, bb_conf = ops.emm_decode(logits, cat([b.bbox for b in sr], dim=0), boxes[0].bbox,
+                                     self.rx, self.rz, self.pad_pixels, sigma=self.sigma,
+                                     use_centerness=self.use_centerness)
+        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=self.amodal)
+        return {}, track_result, {}
+
+    def extract_cache(self, features, detection):
+        """(template features, [search regions], [detections]) — track_core.py:81-98."""
+        detection = [detection]
+        x = self.feature_extractor(features, detection)
+        tu = self.track_utils
+        sr_boxes = []
+        for det in detection:
+            w, h = det.size
+            sr_bbox = ops.search_region(det.bbox, tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
+            sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
+            for field in det.fields():
+                sr.add_field(field, det.get_field(field))
+            sr_boxes.append(sr)
+        return x, sr_boxes, detection
+
+
+def wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=False):
+    """reference track_core.py:165-181 (one image per call)."""
+    out = []
+    n0 = 0
+    for _boxes in boxes:
+        n1 = n0 + len(_boxes)
+        tb = _boxes.__class__(bb[n0:n1].reshape(-1, 4), _boxes.size, mode="xyxy")
+        tb.add_field("ids", _boxes.get_field("ids"))
+        tb.add_field("labels", _boxes.get_field("labels"))
+        tb.add_field("scores", bb_conf[n0:n1])
+        if not amodal:
+            # as the reference: the returned (filtered) copy is discarded — boxes are clamped in
+            # place, empty ones are NOT removed (track_core.py:177-178)
+            tb.clip_to_image(remove_empty=True)
+        out.append(tb)
+        n0 = n1
+    return out
+
+
+def register(name="EMM", override=False):
+    """Put this class into ``SIAMESE_TRACKER`` (the dict ``build_track_head`` reads,
+    track_head.py:118-120).  With the reference importable, ``override=True`` replaces its "EMM"."""
+    if name in SIAMESE_TRACKER and not override and SIAMESE_TRACKER[name] is not EMM:
+        raise KeyError("SIAMESE_TRACKER[%r] is already taken; pass override=True" % name)
+    SIAMESE_TRACKER[name] = EMM
+    return EMM
+
+
+SIAMESE_TRACKER["EMM_HIP"] = EMM
+if "EMM" not in SIAMESE_TRACKER:
+    SIAMESE_TRACKER["EMM"] = EMM

@@ -1,0 +1,210 @@
+"""ctypes binding of ``csrc/libsmot_emm.so`` (C ABI: include/smot_emm.h) + tensor-level operators.
+
+This is the ONLY compute path of the package: there is no CPU / eager fallback.  If the HIP
+library is missing or a tensor is not a contiguous fp32 device tensor, the call raises.
+
+Operator ↔ reference map (reference paths relative to amazon-science/siam-mot):
+    roi_align_levels   SRPooler.forward            EMM/sr_pool.py:53-91 (+ track_utils.py:87-107 pad)
+    search_region      update_boxes_in_pad_images  track_head/track_utils.py:109-135 + extend_bbox :62-85
+    xcorr_depthwise    xcorr_depthwise             EMM/xcorr.py:37-46
+    emm_predictor      EMMPredictor.forward        EMM/feature_extractor.py:62-69
+    emm_decode         3x F.interpolate + get_locations + decode_response   EMM/track_core.py:69-77
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
+ABI_VERSION = 1
+UP_SCALE = 16          # reference track_core.py:69-73
+
+_lib = None
+_c_float_p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+_SIGNATURES = {
+    "smot_abi_version": (ctypes.c_int, []),
+    "smot_last_error": (ctypes.c_char_p, []),
+    "smot_roi_align_levels_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i,
+                                                 _vp, _vp, _vp]),
+    "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
+    "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp]),
+    "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i,
+                                           _vp, _vp, _vp, _vp, _vp]),
+    "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+
+
+def load_library(path=None):
+    """dlopen the HIP library (after torch, so both share one libamdhip64) and type its symbols."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "siammot_amd: HIP library %s not found — build it with `python siam-mot_amd/build.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.smot_abi_version() != ABI_VERSION:
+        raise RuntimeError("siammot_amd: %s has ABI %d, host layer expects %d"
+                           % (path, lib.smot_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.smot_last_error().decode("utf-8", "replace")
+        raise RuntimeError("siammot_amd.%s failed (code %d): %s" % (what, rc, msg))
+
+
+def _dev_f32(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("siammot_amd: %s must be a device (ROCm) tensor — no CPU path exists" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("siammot_amd: %s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+# ----------------------------------------------------------------------------------------------
+def roi_align_levels(features, rois, level_boxes, out_size, scales, sampling_ratio, pad_cells=None,
+                     return_levels=False):
+    """Level-routed legacy ROIAlign on one image with virtual zero padding.
+
+    features: sequence of ``[1,C,H_l,W_l]`` tensors (only the first ``len(scales)`` are used, as the
+    reference's ``zip(x, self.poolers)``); rois ``[R,4]`` xyxy in padded-image pixels; level_boxes
+    ``[R,4]`` (template boxes) choose the level; pad_cells: per-level virtual padding in cells.
+    Returns ``[R,C,out_size,out_size]`` (and int32 levels when asked).
+    """
+    lib = load_library()
+    L = len(scales)
+    feats = [_dev_f32(features[l], "features[%d]" % l) for l in range(L)]
+    for f in feats:
+        if f.dim() != 4 or f.shape[0] != 1:
+            raise RuntimeError("siammot_amd.roi_align_levels: one image per call, got feature shape %s"
+                               % (tuple(f.shape),))
+    C = feats[0].shape[1]
+    rois = _dev_f32(rois, "rois")
+    level_boxes = rois if level_boxes is None else _dev_f32(level_boxes, "level_boxes")
+    R = rois.shape[0]
+    if pad_cells is None:
+        pad_cells = [0] * L
+    out = torch.empty((R, C, out_size, out_size), dtype=torch.float32, device=rois.device)
+    levels = torch.empty((R,), dtype=torch.int32, device=rois.device) if return_levels else None
+    fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * L)(*[f.shape[2] for f in feats])
+    ws = (ctypes.c_int * L)(*[f.shape[3] for f in feats])
+    pc = (ctypes.c_int * L)(*[int(p) for p in pad_cells[:L]])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    rc = lib.smot_roi_align_levels_fwd(cast(fp), cast(hs), cast(ws), cast(pc), cast(sc), L, C,
+                                       _ptr(rois), _ptr(level_boxes), R, out_size, out_size,
+                                       int(sampling_ratio), _ptr(out), _ptr(levels), _stream())
+    _check(rc, "roi_align_levels")
+    return (out, levels) if return_levels else out
+
+
+def search_region(boxes, pad_pixels, search_expansion, min_search_wh):
+    """Template boxes ``[N,4]`` → search regions ``[N,4]`` in padded-image coordinates."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    sr = torch.empty_like(boxes)
+    rc = lib.smot_search_region_fwd(_ptr(boxes), boxes.shape[0], float(pad_pixels), float(search_expansion),
+                                    float(min_search_wh), _ptr(sr), _stream())
+    _check(rc, "search_region")
+    return sr
+
+
+def xcorr_depthwise(x, kernel):
+    """Same contract as the reference ``xcorr_depthwise(x, kernel)`` (EMM/xcorr.py:37-46)."""
+    lib = load_library()
+    x = _dev_f32(x, "x")
+    kernel = _dev_f32(kernel, "kernel")
+    if x.dim() != 4 or kernel.dim() != 4 or x.shape[:2] != kernel.shape[:2] \
+            or x.shape[2] != x.shape[3] or kernel.shape[2] != kernel.shape[3]:
+        raise RuntimeError("siammot_amd.xcorr_depthwise: need x [N,C,Rx,Rx] and kernel [N,C,Rz,Rz], got %s, %s"
+                           % (tuple(x.shape), tuple(kernel.shape)))
+    N, C, Rx, _ = x.shape
+    Rz = kernel.shape[2]
+    out = torch.empty((N, C, Rx - Rz + 1, Rx - Rz + 1), dtype=torch.float32, device=x.device)
+    rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, _stream())
+    _check(rc, "xcorr_depthwise")
+    return out
+
+
+PREDICTOR_KEYS = (
+    "cls_tower.0.weight", "cls_tower.1.weight", "cls_tower.1.bias",
+    "reg_tower.0.weight", "reg_tower.1.weight", "reg_tower.1.bias",
+    "cls.weight", "cls.bias", "center.weight", "center.bias", "reg.weight", "reg.bias",
+)
+
+
+def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5):
+    """``resp [N,C,Ho,Ho]`` + reference-keyed ``params`` → logits ``[N,7,Ho,Ho]``
+    (cls0, cls1, center, reg l/t/r/b; reg already ReLU'd)."""
+    lib = load_library()
+    resp = _dev_f32(resp, "resp")
+    N, C, Ho, _ = resp.shape
+    w = [_dev_f32(params[k], k) for k in PREDICTOR_KEYS]
+    expect = {0: (C, C, 3, 3), 3: (C, C, 3, 3), 6: (2, C, 3, 3), 8: (1, C, 3, 3), 10: (4, C, 3, 3)}
+    for i, shp in expect.items():
+        if tuple(w[i].shape) != shp:
+            raise RuntimeError("siammot_amd.emm_predictor: %s has shape %s, expected %s"
+                               % (PREDICTOR_KEYS[i], tuple(w[i].shape), shp))
+    tower_ws = torch.empty((N, 2 * C, Ho, Ho), dtype=torch.float32, device=resp.device)
+    logits = torch.empty((N, 7, Ho, Ho), dtype=torch.float32, device=resp.device)
+    rc = lib.smot_emm_predictor_fwd(_ptr(resp), N, C, Ho, *[_ptr(t) for t in w], int(gn_groups), float(gn_eps),
+                                    _ptr(tower_ws), _ptr(logits), _stream())
+    _check(rc, "emm_predictor")
+    return logits
+
+
+_hann_cache = {}
+
+
+def hann_window(G, device):
+    """``torch.hann_window(G)`` (periodic) evaluated on the CPU — bit-identical to what the CPU
+    reference multiplies in (track_core.py:157-158) — cached per device."""
+    key = (G, str(device))
+    if key not in _hann_cache:
+        _hann_cache[key] = torch.hann_window(G, dtype=torch.float).to(device)
+    return _hann_cache[key]
+
+
+def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=True, return_index=False):
+    """Fused up-sample + decode.  logits ``[N,7,Ho,Ho]``, sr/boxes ``[N,4]`` → (bb ``[N,4]``, conf ``[N]``)."""
+    lib = load_library()
+    logits = _dev_f32(logits, "logits")
+    sr = _dev_f32(sr, "sr")
+    boxes = _dev_f32(boxes, "boxes")
+    N, _, Ho, _ = logits.shape
+    dev = logits.device
+    G = Ho * UP_SCALE
+    ws = torch.empty((max(N, 1) * lib.smot_emm_decode_ws_floats(Ho, UP_SCALE),), dtype=torch.float32, device=dev)
+    bb = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    conf = torch.empty((N,), dtype=torch.float32, device=dev)
+    idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
+    rc = lib.smot_emm_decode_fwd(_ptr(logits), _ptr(sr), _ptr(boxes), _ptr(hann_window(G, dev)), N, Ho, UP_SCALE,
+                                 int(rx), int(rz), float(pad_pixels), float(1 - sigma), float(sigma),
+                                 int(bool(use_centerness)), _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
+    _check(rc, "emm_decode")
+    return (bb, conf, idx) if return_index else (bb, conf)

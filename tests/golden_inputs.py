@@ -1,0 +1,122 @@
+"""Seeded inputs shared by ``oracle/gen_golden.py`` (which runs the reference on them) and the
+parity tests (which run the oracle and the HIP path on them).
+
+Everything comes from ``numpy.random.RandomState`` (legacy MT19937 stream, bit-stable across
+numpy versions and machines), so ``tests/golden/*.npz`` only has to store OUTPUTS.
+"""
+import numpy as np
+
+F32 = np.float32
+
+# ---- full frame-pair cases --------------------------------------------------------------
+EMM_CASES = {
+    # DLA-34-FPN defaults (siammot/configs/defaults.py:35-82) at a reduced channel count / image
+    "default": dict(channels=64, rz=15, search_region=2.0, pad_pixels=512, min_search_wh=0,
+                    use_centerness=True, sigma=0.4, amodal=False,
+                    scales=(0.25, 0.125, 0.0625, 0.03125), image_wh=(512, 384), seed=1234,
+                    boxes=[(40.3, 50.7, 71.9, 114.2),        # 32x64   -> level 0
+                           (150.5, 60.25, 214.0, 187.5),     # 64x128  -> level 0
+                           (250.0, 100.0, 349.5, 299.0),     # 100x200 -> level 1
+                           (300.2, 30.1, 459.7, 349.9),      # 160x320 -> level 2
+                           (5.0, 200.0, 60.0, 380.0),        # hugging the left/bottom border
+                           (-20.0, -30.0, 480.0, 400.0),     # larger than the image -> level 3
+                           (-160.0, 40.0, -100.0, 140.0)]),  # left of the image: SR mostly virtual pad,
+                                                             # result clipped away (remove_empty)
+    # configs/dla/DLA_34_FPN_EMM_AOT.yaml:52-63 shape family: Rz=7, Rx=35, pad 256, no centerness
+    "aot": dict(channels=32, rz=7, search_region=5.0, pad_pixels=256, min_search_wh=64,
+                use_centerness=False, sigma=0.1, amodal=True,
+                scales=(0.25, 0.125, 0.0625, 0.03125), image_wh=(512, 384), seed=4321,
+                boxes=[(100.0, 100.0, 111.5, 123.0),         # tiny: min_search_wh kicks in
+                       (200.5, 50.5, 260.0, 170.0),
+                       (300.0, 150.0, 460.0, 370.0),
+                       (20.0, 20.0, 180.0, 340.0)]),
+}
+
+
+def CHANNEL_SUBSET(C):
+    return [0, C // 3, C - 1]
+
+
+def feature_shapes(image_wh, channels):
+    W, H = image_wh
+    return [(1, channels, H // s, W // s) for s in (4, 8, 16, 32, 64)]
+
+
+def predictor_params(rs, C, boxes):
+    """Reference state_dict keys with structured values (§8d)."""
+    def conv(o, i):
+        return (rs.standard_normal((o, i, 3, 3)) * 0.05).astype(F32)
+    mw = float(np.mean(boxes[:, 2] - boxes[:, 0]))
+    mh = float(np.mean(boxes[:, 3] - boxes[:, 1]))
+    p = {}
+    for t in ("cls_tower", "reg_tower"):
+        p[t + ".0.weight"] = conv(C, C)
+        p[t + ".1.weight"] = rs.uniform(0.5, 1.5, C).astype(F32)
+        p[t + ".1.bias"] = (rs.standard_normal(C) * 0.1).astype(F32)
+    p["cls.weight"] = conv(2, C)
+    p["cls.bias"] = np.array([0.1, -0.1], dtype=F32)
+    p["center.weight"] = conv(1, C)
+    p["center.bias"] = np.array([0.05], dtype=F32)
+    p["reg.weight"] = conv(4, C)
+    p["reg.bias"] = np.array([0.5 * mw, 0.5 * mh, 0.5 * mw, 0.5 * mh], dtype=F32)
+    return p
+
+
+def emm_case_inputs(name):
+    case = EMM_CASES[name]
+    rs = np.random.RandomState(case["seed"])
+    shapes = feature_shapes(case["image_wh"], case["channels"])
+    feats_a = [rs.standard_normal(s).astype(F32) for s in shapes]
+    feats_b = [rs.standard_normal(s).astype(F32) for s in shapes]
+    boxes = np.array(case["boxes"], dtype=F32)
+    params = predictor_params(rs, case["channels"], boxes)
+    return dict(features_a=feats_a, features_b=feats_b, boxes=boxes, params=params)
+
+
+# ---- operator-level cases ---------------------------------------------------------------
+XCORR_CASES = {
+    "c128": dict(n=2, c=128, rx=30, rz=15, seed=11),
+    "aot": dict(n=1, c=32, rx=35, rz=7, seed=12),
+}
+
+
+def xcorr_case_inputs(name):
+    c = XCORR_CASES[name]
+    rs = np.random.RandomState(c["seed"])
+    x = rs.standard_normal((c["n"], c["c"], c["rx"], c["rx"])).astype(F32)
+    z = rs.standard_normal((c["n"], c["c"], c["rz"], c["rz"])).astype(F32)
+    return x, z
+
+
+DECODE_CASES = {
+    "default": dict(n=8, rx=30, rz=15, pad_pixels=512, use_centerness=True, sigma=0.4,
+                    search_expansion=1.0, seed=21),
+    "aot": dict(n=3, rx=35, rz=7, pad_pixels=256, use_centerness=False, sigma=0.1,
+                search_expansion=4.0, seed=22),
+}
+
+
+def np_search_region(boxes, pad_pixels, e, min_wh=0.0):
+    b = (boxes + F32(pad_pixels)).astype(F32)
+    w = b[:, 2] - b[:, 0] + F32(1)
+    h = b[:, 3] - b[:, 1] + F32(1)
+    w_ext = np.maximum((F32(min_wh) - w) / F32(e * 2.0), w * F32(e / 2.0))
+    h_ext = np.maximum((F32(min_wh) - h) / F32(e * 2.0), h * F32(e / 2.0))
+    return np.stack((b[:, 0] - w_ext, b[:, 1] - h_ext, b[:, 2] + w_ext, b[:, 3] + h_ext), 1).astype(F32)
+
+
+def decode_case_inputs(name):
+    """Logits fed directly: cls, center ~ N(0,2); reg ~ |N(0,1)|·0.5·box side."""
+    c = DECODE_CASES[name]
+    rs = np.random.RandomState(c["seed"])
+    n = c["n"]
+    ho = c["rx"] - c["rz"] + 1
+    wh = rs.uniform(24.0, 260.0, (n, 2))
+    xy = rs.uniform(0.0, 900.0, (n, 2))
+    boxes = np.concatenate((xy, xy + wh), 1).astype(F32)
+    cls = (rs.standard_normal((n, 2, ho, ho)) * 2.0).astype(F32)
+    center = (rs.standard_normal((n, 1, ho, ho)) * 2.0).astype(F32)
+    side = np.stack((wh[:, 0], wh[:, 1], wh[:, 0], wh[:, 1]), 1)[:, :, None, None]
+    reg = (np.abs(rs.standard_normal((n, 4, ho, ho))) * 0.5 * side).astype(F32)
+    sr = np_search_region(boxes, c["pad_pixels"], c["search_expansion"])
+    return dict(cls=cls, center=center, reg=reg, boxes=boxes, sr=sr)
