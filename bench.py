@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Benchmark of the EMM tracker-head hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--tracks 30]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one frame pair through the hot path (BASELINE.json north_star):
+``EMM.forward`` on frame t (ROIAlign of the search regions with virtual padding -> depthwise
+cross-correlation -> prediction towers + heads -> fused up-sample/decode) followed by
+``EMM.extract_cache`` on frame t (template ROIAlign + search regions for frame t+1), at
+BASELINE.json configs[1]: DLA-34-FPN feature maps of a 720p frame (net input 704x1280, C=128,
+5 FPN levels), 30 active tracks.  Inputs are synthetic, seeded, and RESIDENT IN HBM before the timed
+region.  The DLA-34-FPN backbone, RPN and box head are NOT in the timed region (they are PyTorch
+modules outside the hot path) — `config.workload` says so.
+
+Multi-GPU (--gpus N): one process per GPU, each running its own independent stream;
+the predictor weights are broadcast once from rank 0 over RCCL before timing; no per-frame
+collective.  Weak scaling: value = N * K / max-over-ranks(elapsed).
+
+The JSON line also carries:
+  roofline     — for the depthwise cross-correlation kernel (the graded kernel): algorithmic bytes
+                 4*N*C*(Rx^2+Rz^2+Ho^2) per launch / average launch duration measured with HIP events
+                 recorded on the launch stream around every xcorr launch of the timed region.
+  cpu_baseline — the CPU oracle (oracle/emm_oracle.py, the reference's torch-CPU ops) timed on this
+                 host's cores on the same workload (rank 0, N=1 only), bounded to ~10-20 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+METRIC = "frame-pairs/sec at 720p, 30 active tracks; EMM xcorr HBM GB/s vs peak"
+NET_HW = (704, 1280)       # 720p under MIN_SIZE_TEST 800 / MAX 1280 / divisibility 32
+CHANNELS = 128
+TRACK_SIZES = [(32, 64), (64, 128), (100, 200), (160, 320)]    # (w,h): FPN levels 0,0,1,2
+
+
+def synthetic_boxes(n, image_wh):
+    """Non-overlapping grid of boxes cycling the four sizes, fully inside the image."""
+    W, H = image_wh
+    cols = max(1, W // 180)
+    boxes = []
+    for i in range(n):
+        w, h = TRACK_SIZES[i % 4]
+        cx = 90 + 180 * (i % cols)
+        cy = 170 + 340 * ((i // cols) % max(1, H // 340))
+        # tracks beyond the grid capacity wrap with a small offset (crowd regime, configs[2])
+        off = 7.0 * (i // (cols * max(1, H // 340)))
+        x1 = min(max(cx - w / 2 + off, 0), W - w - 1)
+        y1 = min(max(cy - h / 2 + off, 0), H - h - 1)
+        boxes.append([x1, y1, x1 + w, y1 + h])
+    return torch.tensor(boxes, dtype=torch.float32)
+
+
+def synthetic_features(seed, device):
+    g = torch.Generator().manual_seed(seed)
+    H, W = NET_HW
+    return tuple(torch.randn((1, CHANNELS, H // s, W // s), generator=g).to(device) for s in (4, 8, 16, 32, 64))
+
+
+def init_predictor(pred, boxes):
+    """Random-init weights of the reference architecture (there are no checkpoints offline), with
+    biases that keep the decode non-degenerate (SURVEY.md §7 'Degenerate synthetic weights')."""
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in pred.named_parameters():
+            if name.endswith("0.weight") or name in ("cls.weight", "center.weight", "reg.weight"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+        mw = float((boxes[:, 2] - boxes[:, 0]).mean())
+        mh = float((boxes[:, 3] - boxes[:, 1]).mean())
+        pred.reg.bias.copy_(torch.tensor([0.5 * mw, 0.5 * mh, 0.5 * mw, 0.5 * mh]))
+
+
+def cpu_baseline(n_tracks, budget_s=12.0):
+    """Time the oracle (reference torch-CPU ops) on the same frame-pair workload."""
+    from oracle import emm_oracle as O            # checker / baseline only — never the product path
+    torch.set_num_threads(os.cpu_count() or 1)
+    feats = synthetic_features(0, "cpu")
+    boxes = synthetic_boxes(n_tracks, (NET_HW[1], NET_HW[0]))
+    cfg = O.EMMConfig(channels=CHANNELS)
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.emm import EMMPredictor
+    pred = EMMPredictor(get_default_cfg(channels=CHANNELS))
+    init_predictor(pred, boxes)
+    params = {k: v.detach() for k, v in pred.named_parameters()}
+
+    def step():
+        z, sr = O.extract_cache(cfg, feats, boxes)
+        return O.emm_forward(cfg, params, feats, boxes, sr, z, (NET_HW[1], NET_HW[0]), reference_ops=True)
+
+    with torch.no_grad():
+        step()
+        t0 = time.perf_counter()
+        step()
+        one = time.perf_counter() - t0
+        reps = int(max(3, min(50, budget_s / max(one, 1e-3))))
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": 1.0 / med, "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frame pairs of the same workload (%d tracks, 720p maps), median; oracle/emm_oracle.py "
+                      "with the reference's torch-CPU ops (grouped conv2d, F.interpolate, physical pad_feature)"
+                      % (reps, n_tracks),
+            "ms_per_step": med * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--tracks", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from siammot_amd import ops, parallel
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.emm import EMM
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_utils import build_track_utils
+
+    rank, world, local_rank = parallel.init_distributed()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ops.load_library()
+
+    n = args.tracks
+    image_wh = (NET_HW[1], NET_HW[0])
+    boxes_cpu = synthetic_boxes(n, image_wh)
+    cfg = get_default_cfg(channels=CHANNELS)
+    emm = EMM(cfg, build_track_utils(cfg)).eval()
+    if rank == 0:
+        init_predictor(emm.predictor, boxes_cpu)
+    emm = emm.to(dev)
+    bcast_bytes = parallel.broadcast_module(emm, src=0)       # one RCCL broadcast over xGMI; 0 at N=1
+    feats = [synthetic_features(100 + rank * 2 + k, dev) for k in range(2)]   # two alternating frames
+    det = BoxList(boxes_cpu.to(dev), image_wh, mode="xyxy")
+    det.add_field("ids", torch.arange(n, device=dev))
+    det.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
+
+    def step(k, state):
+        z, sr, d = state
+        _, result, _ = emm(feats[k & 1], d, sr, template_features=z)       # frame t: track
+        return emm.extract_cache(feats[k & 1], det), result                # frame t: new templates / SRs
+
+    with torch.no_grad():
+        state = emm.extract_cache(feats[1], det)
+        for k in range(args.warmup):
+            state, _ = step(k, state)
+        ops.xcorr_event_sink = []
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            state, result = step(k, state)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        elapsed = time.perf_counter() - t0
+        sink, ops.xcorr_event_sink = ops.xcorr_event_sink, None
+    elapsed = parallel.max_over_ranks(elapsed, dev)
+    xcorr_ms = [a.elapsed_time(b) for a, b in sink]
+    xcorr_avg_s = (sum(xcorr_ms) / max(len(xcorr_ms), 1)) * 1e-3
+
+    if rank != 0:
+        return
+    rx, rz = emm.rx, emm.rz
+    ho = rx - rz + 1
+    xcorr_bytes = 4.0 * n * CHANNELS * (rx * rx + rz * rz + ho * ho)
+    achieved = xcorr_bytes / xcorr_avg_s / 1e9 if xcorr_avg_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "xcorr_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(str(n))
+        except Exception:
+            traffic = None
+    out = {
+        "metric": METRIC,
+        "value": world * args.steps / elapsed,
+        "unit": "frame-pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "EMM tracker-head frame pair (EMM.forward + EMM.extract_cache) on DLA-34-FPN 720p FPN maps "
+                        "(net input 704x1280, C=128, 5 levels), %d tracks, one stream per GPU; hot path only: "
+                        "backbone / RPN / box head / solver are outside the timed region" % n,
+            "tracks": n, "channels": CHANNELS, "rz": rz, "rx": rx,
+            "parallelism": "streams x%d (weights broadcast once: %d B)" % (world, bcast_bytes),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "xcorr_dw_wave_kernel<30,15>",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": xcorr_bytes,
+            "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": len(xcorr_ms),
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

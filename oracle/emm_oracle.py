@@ -176,6 +176,16 @@ def xcorr_depthwise(x, z):
     return out
 
 
+def xcorr_depthwise_conv(x, z):
+    """The reference's own formulation (xcorr.py:37-46): one grouped ``F.conv2d`` with
+    groups = N·C.  Used by bench.py's ``cpu_baseline`` leg so the CPU number times the ops the
+    reference really runs; tests hold it equal to the explicit form above."""
+    n, c = z.shape[:2]
+    out = F.conv2d(x.reshape(1, n * c, x.shape[2], x.shape[3]),
+                   z.reshape(n * c, 1, z.shape[2], z.shape[3]), groups=n * c)
+    return out.reshape(n, c, out.shape[2], out.shape[3])
+
+
 # ----------------------------------------------------------------------------------------
 # predictor (reference EMM/feature_extractor.py:43-69; make_conv3x3 / group_norm [UPSTREAM])
 # ----------------------------------------------------------------------------------------
@@ -239,6 +249,11 @@ def bicubic_upsample(planes, scale=UP_SCALE):
         h = h * wy[k][:, None]
         out = h if out is None else out + h
     return out
+
+
+def bicubic_upsample_torch(planes, scale=UP_SCALE):
+    """``F.interpolate(..., mode='bicubic')`` itself (track_core.py:69-71) — cpu_baseline leg."""
+    return F.interpolate(planes, scale_factor=scale, mode="bicubic")
 
 
 # ----------------------------------------------------------------------------------------
@@ -362,19 +377,24 @@ def extract_cache(cfg, features, det_boxes):
 
 
 def emm_forward(cfg, params, features, boxes, sr_boxes, template_features, image_wh,
-                return_intermediates=False):
+                return_intermediates=False, reference_ops=False):
     """Inference branch of ``EMM.forward`` (track_core.py:28-79).
 
     Returns (bb [N,4], conf [N], nonempty [N] bool) after ``wrap_results_to_boxlist`` clipping
     (clamp only — see clip_boxes), plus a dict of every intermediate when asked.
+    ``reference_ops=True`` swaps in the torch library calls the reference makes (grouped conv2d,
+    F.interpolate) for the explicit restatements — same results to fp32 rounding, much faster on
+    CPU (bench.py's cpu_baseline leg).
     """
+    xcorr = xcorr_depthwise_conv if reference_ops else xcorr_depthwise
+    upsample = bicubic_upsample_torch if reference_ops else bicubic_upsample
     padded = pad_features(features, cfg.pad_pixels)                                   # :49
     x = sr_pool(padded, boxes, sr_boxes, cfg.rx, cfg.scales, cfg.sampling_ratio)      # :51
-    resp = xcorr_depthwise(x, template_features)                                      # :53
+    resp = xcorr(x, template_features)                                                # :53
     cls, center, reg = predictor(resp, params, cfg.gn_groups, cfg.gn_eps)             # :54
-    cls_up = bicubic_upsample(cls)                                                    # :69
-    center_up = bicubic_upsample(center)                                              # :70
-    reg_up = bicubic_upsample(reg)                                                    # :71
+    cls_up = upsample(cls)                                                            # :69
+    center_up = upsample(center)                                                      # :70
+    reg_up = upsample(reg)                                                            # :71
     xs, ys = grid_axes(sr_boxes, cfg.rx, cfg.rz, cfg.pad_pixels)                      # :73
     bb, conf, idx = decode(cls_up, center_up, reg_up, xs, ys, boxes,
                            cfg.use_centerness, cfg.sigma)                             # :76-77

@@ -20,6 +20,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 ABI_VERSION = 1
 UP_SCALE = 16          # reference track_core.py:69-73
 
+# bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs recorded on the launch
+# stream around every xcorr launch (roofline.achieved); None = no instrumentation.
+xcorr_event_sink = None
+
 _lib = None
 _c_float_p = ctypes.POINTER(ctypes.c_float)
 _vp = ctypes.c_void_p
@@ -146,7 +150,15 @@ def xcorr_depthwise(x, kernel):
     N, C, Rx, _ = x.shape
     Rz = kernel.shape[2]
     out = torch.empty((N, C, Rx - Rz + 1, Rx - Rz + 1), dtype=torch.float32, device=x.device)
+    sink = xcorr_event_sink
+    if sink is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, _stream())
+    if sink is not None:
+        e1.record()
+        sink.append((e0, e1))
     _check(rc, "xcorr_depthwise")
     return out
 

@@ -1,0 +1,70 @@
+"""Multi-GPU layout of the EMM path: independent video streams, one process per GPU.
+
+SURVEY.md §8(e): frame pairs of one stream are strictly sequential (track memory of frame t-1 feeds
+frame t: reference rcnn.py:54,57), streams are independent, so the path shards by STREAM with no
+per-frame collective.  The only exchange is a one-time broadcast of the weights from rank 0
+(RCCL over xGMI on the GPU box; gloo in the CPU tests); track state stays per process.
+The reference has no multi-GPU inference at all (README.md:70, engine/inferencer.py:156).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def is_distributed():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0):
+    """Broadcast every parameter and buffer of ``module`` from rank ``src`` as ONE flat fp32
+    buffer (a single collective: xGMI rings are per-link bound, so one large message beats many
+    small ones).  Returns the number of bytes broadcast (0 when not distributed)."""
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = [t for t in tensors if t.is_floating_point()]
+    if not is_distributed() or not tensors:
+        return 0
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src)
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t).to(t.dtype))
+        off += n
+    return flat.numel() * 4
+
+
+def shard_streams(num_streams, rank, world):
+    """Stream ids owned by ``rank``: stream i → rank i mod world."""
+    return list(range(rank, num_streams, world))
+
+
+def max_over_ranks(value, device=None):
+    """MAX all-reduce of a python float (elapsed time): the job is as slow as its slowest rank."""
+    if not is_distributed():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64,
+                     device=device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if is_distributed():
+        dist.barrier()

@@ -1,0 +1,437 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and with the reference's golden
+vectors.  Needs a real MI355X: ``pytest -m gpu``.
+
+Tolerances (fp32 path, stated per check):
+  * geometry (search regions, level routing): bit-exact;
+  * ROIAlign: 1e-5 abs+rel (same op order as the reference, FMA contraction only);
+  * xcorr: |err| <= 1e-6 * sum|x*z| against the fp64 oracle (one fmaf chain of Rz^2 terms);
+  * predictor logits: 1e-4 relative to the logit scale against the fp64 oracle;
+  * decode: arg-max index identical to the fp32 oracle — or, if it differs, the two cells' fp64
+    scores must tie within 1e-6 (adjudication); boxes within 1e-3 IoU (the
+    north-star bar) and 2e-2 px; confidences within 1e-5.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import emm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import siammot_amd.ops as ops_mod
+    ops_mod.load_library()
+    return ops_mod
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dtype)
+
+
+def _d(a):
+    return _t(a).to(DEV)
+
+
+def _cfg(case):
+    return O.EMMConfig(channels=case["channels"], rz=case["rz"], search_region=case["search_region"],
+                       scales=case["scales"], pad_pixels=case["pad_pixels"],
+                       min_search_wh=case["min_search_wh"], use_centerness=case["use_centerness"],
+                       sigma=case["sigma"], amodal=case["amodal"])
+
+
+def _assert_close(got, ref, rtol, atol, what):
+    got = got.detach().cpu().double().numpy() if isinstance(got, torch.Tensor) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (what, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    tol = atol + rtol * np.abs(ref)
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d elements out of tolerance, max err %.3e (ref %.3e) at %s" % (
+        what, bad.sum(), bad.size, err.max(), ref.flat[err.argmax()], np.unravel_index(err.argmax(), err.shape))
+
+
+def iou(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    iw = np.clip(np.minimum(a[:, 2], b[:, 2]) - np.maximum(a[:, 0], b[:, 0]), 0, None)
+    ih = np.clip(np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1]), 0, None)
+    inter = iw * ih
+    ua = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter
+    return np.where(ua > 0, inter / np.maximum(ua, 1e-30), 1.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# K1: ROIAlign + geometry
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", sorted(gi.EMM_CASES))
+def test_search_region_bit_exact(ops, name, golden_dir):
+    case = gi.EMM_CASES[name]
+    cfg = _cfg(case)
+    boxes = _t(gi.emm_case_inputs(name)["boxes"])
+    gold = np.load(os.path.join(golden_dir, "emm_%s.npz" % name))["sr"]
+    sr = ops.search_region(boxes.to(DEV), cfg.pad_pixels, cfg.search_expansion, cfg.min_search_wh)
+    np.testing.assert_array_equal(sr.cpu().numpy(), gold)
+    np.testing.assert_array_equal(sr.cpu().numpy(),
+                                  O.search_region(boxes, cfg.pad_pixels, cfg.search_expansion,
+                                                  cfg.min_search_wh).numpy())
+
+
+@pytest.mark.parametrize("name", sorted(gi.EMM_CASES))
+def test_template_and_sr_pooling(ops, name, golden_dir):
+    case = gi.EMM_CASES[name]
+    cfg = _cfg(case)
+    inp = gi.emm_case_inputs(name)
+    gold = np.load(os.path.join(golden_dir, "emm_%s.npz" % name))
+    boxes = _t(inp["boxes"])
+    feats_a = [_t(f) for f in inp["features_a"]]
+    feats_b = [_t(f) for f in inp["features_b"]]
+    # template pooler: unpadded maps, boxes pick level and roi
+    z, lv = ops.roi_align_levels([f.to(DEV) for f in feats_a], boxes.to(DEV), boxes.to(DEV), cfg.rz, cfg.scales,
+                                 cfg.sampling_ratio, return_levels=True)
+    assert lv.cpu().tolist() == [int(v) for v in gold["levels"]]
+    z_ref, sr = O.extract_cache(cfg, feats_a, boxes)
+    _assert_close(z, z_ref, 1e-5, 1e-5, "template ROIAlign vs oracle")
+    _assert_close(z, gold["z"], 1e-5, 1e-5, "template ROIAlign vs reference golden")
+    # search-region pooler: VIRTUAL padding must equal pooling from physically padded maps
+    pad_cells = [O.pad_cells(cfg.pad_pixels, i) for i in range(len(cfg.scales))]
+    x = ops.roi_align_levels([f.to(DEV) for f in feats_b], sr.to(DEV), boxes.to(DEV), cfg.rx, cfg.scales,
+                             cfg.sampling_ratio, pad_cells)
+    x_ref = O.sr_pool(O.pad_features(feats_b, cfg.pad_pixels), boxes, sr, cfg.rx, cfg.scales, cfg.sampling_ratio)
+    _assert_close(x, x_ref, 1e-5, 1e-5, "SR ROIAlign (virtual pad) vs oracle (physical pad)")
+    sub = gi.CHANNEL_SUBSET(case["channels"])
+    _assert_close(x[:, sub], gold["x_sub"], 1e-5, 1e-5, "SR ROIAlign vs reference golden")
+
+
+def test_roi_align_single_level_and_sampling_ratios(ops):
+    rs = np.random.RandomState(17)
+    feat = _t(rs.standard_normal((1, 6, 23, 31)).astype(np.float32))
+    rois = torch.tensor([[3.0, 2.5, 60.0, 40.0], [-30.0, -20.0, 20.0, 30.0], [100.0, 70.0, 140.0, 95.0],
+                         [10.0, 10.0, 10.2, 10.3]])      # inside, straddling, beyond the map, degenerate
+    for g in (1, 2, 3, 4):
+        out = ops.roi_align_levels([feat.to(DEV)], rois.to(DEV), None, 7, (0.5,), g)
+        r5 = torch.cat((torch.zeros(4, 1), rois), 1)
+        ref = O.roi_align(feat, r5, 0.5, 7, 7, g)
+        _assert_close(out, ref, 1e-5, 1e-5, "single-level ROIAlign g=%d" % g)
+
+
+def test_roi_align_properties_full_size(ops):
+    """BASELINE.json configs[1] shapes (720p, C=128, 30 tracks): size-independent properties."""
+    torch.manual_seed(0)
+    shapes = [(176, 320), (88, 160), (44, 80), (22, 40)]
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    feats = [torch.full((1, 128, h, w), 1.5 + l, device=DEV) for l, (h, w) in enumerate(shapes)]
+    sizes = [(32, 64), (64, 128), (100, 200), (160, 320)]
+    boxes = []
+    for i in range(30):
+        w, h = sizes[i % 4]
+        x0, y0 = 200 + 25.0 * i, 150 + 5.0 * i
+        boxes.append([x0, y0, x0 + w, y0 + h])
+    boxes = torch.tensor(boxes)
+    out, lv = ops.roi_align_levels(feats, boxes.to(DEV), boxes.to(DEV), 15, scales, 2, return_levels=True)
+    lv = lv.cpu()
+    assert lv.tolist() == O.level_mapper(boxes).tolist()
+    # constant maps -> every bin equals the level's constant (bilinear weights sum to 1)
+    expect = (1.5 + lv.float())[:, None, None, None].expand(-1, 128, 15, 15)
+    _assert_close(out, expect, 1e-6, 0, "constant-map ROIAlign")
+    # linearity in the features
+    f1 = [torch.randn_like(f) for f in feats]
+    f2 = [torch.randn_like(f) for f in feats]
+    a = ops.roi_align_levels(f1, boxes.to(DEV), boxes.to(DEV), 15, scales, 2)
+    b = ops.roi_align_levels(f2, boxes.to(DEV), boxes.to(DEV), 15, scales, 2)
+    c = ops.roi_align_levels([u + v for u, v in zip(f1, f2)], boxes.to(DEV), boxes.to(DEV), 15, scales, 2)
+    _assert_close(c, a + b, 1e-5, 1e-5, "ROIAlign linearity")
+    # a search region lying entirely in the virtual border pools to exact zeros
+    far = torch.tensor([[-400.0, -400.0, -300.0, -300.0]]) + 512
+    zero = ops.roi_align_levels(f1, far.to(DEV), torch.tensor([[0.0, 0.0, 50.0, 50.0]]).to(DEV), 30, scales, 2,
+                                [128, 64, 32, 16])
+    assert float(zero.abs().max()) == 0.0
+
+
+def test_roi_align_empty_and_errors(ops):
+    feat = torch.zeros((1, 4, 8, 8), device=DEV)
+    out = ops.roi_align_levels([feat], torch.zeros((0, 4), device=DEV), None, 7, (0.25,), 2)
+    assert tuple(out.shape) == (0, 4, 7, 7)
+    with pytest.raises(RuntimeError, match="sampling_ratio"):
+        ops.roi_align_levels([feat], torch.zeros((1, 4), device=DEV), None, 7, (0.25,), 0)
+    with pytest.raises(RuntimeError, match="device"):
+        ops.roi_align_levels([feat.cpu()], torch.zeros((1, 4)), None, 7, (0.25,), 2)
+
+
+# ------------------------------------------------------------------------------------------------
+# K2: depthwise cross-correlation
+# ------------------------------------------------------------------------------------------------
+def _xcorr_check(ops, x, z, what):
+    out = ops.xcorr_depthwise(x.to(DEV), z.to(DEV)).cpu()
+    ref64 = O.xcorr_depthwise(x.double(), z.double())
+    mag = O.xcorr_depthwise(x.double().abs(), z.double().abs())         # sum |x*z| per output
+    err = (out.double() - ref64).abs()
+    assert bool((err <= 1e-6 * mag + 1e-30).all()), "%s: max err/mag %.3e" % (what, float((err / mag).max()))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(gi.XCORR_CASES))
+def test_xcorr_vs_oracle_and_golden(ops, name, golden_dir):
+    x, z = [_t(a) for a in gi.xcorr_case_inputs(name)]
+    gold = np.load(os.path.join(golden_dir, "xcorr_%s.npz" % name))["out"]
+    out = _xcorr_check(ops, x, z, "xcorr " + name)
+    _assert_close(out, gold, 1e-5, 2e-4, "xcorr vs reference golden")
+
+
+def test_xcorr_ragged_plane_counts(ops):
+    """N*C not a multiple of the 4 planes a workgroup handles; N=0."""
+    rs = np.random.RandomState(23)
+    for n, c in ((1, 1), (1, 3), (3, 5), (2, 7)):
+        x = _t(rs.standard_normal((n, c, 30, 30)).astype(np.float32))
+        z = _t(rs.standard_normal((n, c, 15, 15)).astype(np.float32))
+        _xcorr_check(ops, x, z, "xcorr %dx%d" % (n, c))
+    out = ops.xcorr_depthwise(torch.zeros((0, 8, 30, 30), device=DEV), torch.zeros((0, 8, 15, 15), device=DEV))
+    assert tuple(out.shape) == (0, 8, 16, 16)
+
+
+@pytest.mark.parametrize("n", [30, 100])
+def test_xcorr_full_size_properties(ops, n):
+    """BASELINE.json configs[1]/[2] sizes: delta-template gather (bit-exact) and linearity."""
+    torch.manual_seed(n)
+    x = torch.randn((n, 128, 30, 30), device=DEV)
+    # template = one-hot at (u0,v0) per plane -> output is exactly the shifted crop of x
+    u0 = torch.randint(0, 15, (n, 128), device=DEV)
+    v0 = torch.randint(0, 15, (n, 128), device=DEV)
+    z = torch.zeros((n, 128, 15, 15), device=DEV)
+    z.view(n, 128, -1).scatter_(2, (u0 * 15 + v0).unsqueeze(-1), 1.0)
+    out = ops.xcorr_depthwise(x, z)
+    ii = torch.arange(16, device=DEV)
+    rows = (u0[:, :, None] + ii[None, None, :])                    # [n,128,16]
+    cols = (v0[:, :, None] + ii[None, None, :])
+    crop = x.gather(2, rows[:, :, :, None].expand(-1, -1, -1, 30)).gather(3, cols[:, :, None, :].expand(-1, -1, 16, -1))
+    assert torch.equal(out, crop)
+    z1 = torch.randn((n, 128, 15, 15), device=DEV)
+    z2 = torch.randn((n, 128, 15, 15), device=DEV)
+    lhs = ops.xcorr_depthwise(x, z1 + z2)
+    rhs = ops.xcorr_depthwise(x, z1) + ops.xcorr_depthwise(x, z2)
+    assert float((lhs - rhs).abs().max()) < 5e-4        # ~225 terms of O(1) products in fp32
+    # against torch's own grouped conv on the device (the reference's formulation) on a slice
+    k = min(n, 4)
+    ref = torch.nn.functional.conv2d(x[:k].reshape(1, k * 128, 30, 30), z1[:k].reshape(k * 128, 1, 15, 15),
+                                     groups=k * 128).view(k, 128, 16, 16)
+    assert float((ops.xcorr_depthwise(x[:k].contiguous(), z1[:k].contiguous()) - ref).abs().max()) < 5e-4
+
+
+def test_xcorr_rejects_bad_inputs(ops):
+    with pytest.raises(RuntimeError):
+        ops.xcorr_depthwise(torch.zeros(1, 2, 30, 30), torch.zeros(1, 2, 15, 15))          # CPU tensors
+    with pytest.raises(RuntimeError):
+        ops.xcorr_depthwise(torch.zeros(1, 2, 30, 30, device=DEV).double(), torch.zeros(1, 2, 15, 15, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.xcorr_depthwise(torch.zeros(1, 2, 30, 30, device=DEV), torch.zeros(1, 3, 15, 15, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------------
+# K3: predictor
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,c,ho", [(3, 64, 16), (2, 128, 16), (1, 256, 16), (2, 32, 29), (2, 96, 16)])
+def test_predictor_vs_oracle(ops, n, c, ho):
+    """MFMA tiling (Ho=16, C in {64,128,256}) and the generic kernel (Ho=29; C=96 -> 3 ch/group)."""
+    rs = np.random.RandomState(100 + c + ho)
+    boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+    params = gi.predictor_params(rs, c, boxes)
+    resp = (rs.standard_normal((n, c, ho, ho)) * 15.0).astype(np.float32)
+    logits = ops.emm_predictor(_d(resp), {k: _d(v) for k, v in params.items()}).cpu()
+    p64 = {k: _t(v, torch.float64) for k, v in params.items()}
+    cls, center, reg = O.predictor(_t(resp, torch.float64), p64)
+    ref = torch.cat((cls, center, reg), 1)
+    # logits are O(1) (cls/center) and O(50) (reg, bias-dominated): 1e-4 of the per-channel scale
+    scale = ref.abs().amax(dim=(0, 2, 3), keepdim=True)
+    err = (logits.double() - ref).abs() / scale
+    assert float(err.max()) < 1e-4, "predictor: max scaled err %.3e" % float(err.max())
+    c32, ce32, r32 = O.predictor(_t(resp), {k: _t(v) for k, v in params.items()})
+    ref32 = torch.cat((c32, ce32, r32), 1)
+    assert float(((logits - ref32).abs() / scale.float()).max()) < 2e-4
+
+
+def test_predictor_module_views_and_state_dict(ops):
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.emm import EMMPredictor
+    cfg = get_default_cfg(channels=64)
+    pred = EMMPredictor(cfg).to(DEV).eval()
+    rs = np.random.RandomState(5)
+    params = gi.predictor_params(rs, 64, np.array([[0, 0, 50, 60]], dtype=np.float32))
+    pred.load_state_dict({k: _t(v) for k, v in params.items()})          # reference key names load as-is
+    resp = _d((rs.standard_normal((2, 64, 16, 16)) * 10).astype(np.float32))
+    with torch.no_grad():
+        cls, center, reg = pred(resp)
+    assert cls.shape == (2, 2, 16, 16) and center.shape == (2, 1, 16, 16) and reg.shape == (2, 4, 16, 16)
+    c, ce, r = O.predictor(resp.cpu(), {k: _t(v) for k, v in params.items()})
+    _assert_close(cls, c, 1e-3, 1e-4, "cls view")
+    _assert_close(reg, r, 1e-4, 1e-3, "reg view")
+    assert float(reg.min()) >= 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# K4: fused up-sample + decode
+# ------------------------------------------------------------------------------------------------
+def _decode_oracle(d, case, dtype):
+    cls, center, reg = [_t(d[k], dtype) for k in ("cls", "center", "reg")]
+    up = [O.bicubic_upsample(t) for t in (cls, center, reg)]
+    xs, ys = O.grid_axes(_t(d["sr"], dtype), case["rx"], case["rz"], case["pad_pixels"])
+    bb, conf, idx = O.decode(up[0], up[1], up[2], xs, ys, _t(d["boxes"], dtype), case["use_centerness"],
+                             case["sigma"])
+    score, _ = O.score_map(up[0], up[1], up[2], _t(d["boxes"], dtype), case["use_centerness"], case["sigma"])
+    return bb, conf, idx, score
+
+
+def _check_decode(ops, d, case, what):
+    logits = torch.cat([_t(d[k]) for k in ("cls", "center", "reg")], 1)
+    bb, conf, idx = ops.emm_decode(logits.to(DEV), _d(d["sr"]), _d(d["boxes"]), case["rx"], case["rz"],
+                                   case["pad_pixels"], sigma=case["sigma"], use_centerness=case["use_centerness"],
+                                   return_index=True)
+    bb, conf, idx = bb.cpu(), conf.cpu(), idx.cpu()
+    bb32, conf32, idx32, _ = _decode_oracle(d, case, torch.float32)
+    _, _, _, score64 = _decode_oracle(d, case, torch.float64)
+    n = torch.arange(idx.shape[0])
+    same = idx == idx32
+    tie = (score64[n, idx] - score64[n, idx32]).abs() <= 1e-6
+    assert bool((same | tie).all()), "%s: argmax differs beyond an fp64 tie: hip %s oracle %s" % (
+        what, idx.tolist(), idx32.tolist())
+    exact = same.numpy()
+    if exact.any():
+        _assert_close(bb[exact], bb32[exact], 0, 2e-2, what + " boxes")
+        _assert_close(conf[exact], conf32[exact], 0, 1e-5, what + " conf")
+        ok = np.isfinite(bb32[exact].numpy()).all(1)
+        assert (iou(bb[exact].numpy()[ok], bb32[exact].numpy()[ok]) >= 1 - 1e-3).all()
+    return bb, conf, idx, float(same.float().mean())
+
+
+@pytest.mark.parametrize("name", sorted(gi.DECODE_CASES))
+def test_decode_vs_oracle_and_golden(ops, name, golden_dir):
+    case = gi.DECODE_CASES[name]
+    d = gi.decode_case_inputs(name)
+    gold = np.load(os.path.join(golden_dir, "decode_%s.npz" % name))
+    bb, conf, idx, frac = _check_decode(ops, d, case, "decode " + name)
+    assert frac == 1.0
+    _assert_close(bb, gold["bb"], 0, 2e-2, "decode boxes vs reference golden")
+    _assert_close(conf, gold["conf"], 0, 1e-5, "decode conf vs reference golden")
+
+
+def test_decode_many_tracks_and_edge_values(ops):
+    """100 tracks (configs[2]) of random logits; plus NaN / inf / tie handling like torch.argmax."""
+    case = dict(gi.DECODE_CASES["default"])
+    rs = np.random.RandomState(77)
+    n = 100
+    wh = rs.uniform(20.0, 300.0, (n, 2))
+    xy = rs.uniform(0.0, 900.0, (n, 2))
+    boxes = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    side = np.stack((wh[:, 0], wh[:, 1], wh[:, 0], wh[:, 1]), 1)[:, :, None, None]
+    d = dict(cls=(rs.standard_normal((n, 2, 16, 16)) * 2).astype(np.float32),
+             center=(rs.standard_normal((n, 1, 16, 16)) * 2).astype(np.float32),
+             reg=(np.abs(rs.standard_normal((n, 4, 16, 16))) * 0.5 * side).astype(np.float32),
+             boxes=boxes, sr=gi.np_search_region(boxes, 512, 1.0))
+    _, _, _, frac = _check_decode(ops, d, case, "decode N=100")
+    assert frac >= 0.99
+    # all-equal logits: the Hann window decides -> centre cell (128,128), as in the reference
+    d1 = dict(cls=np.zeros((1, 2, 16, 16), np.float32), center=np.zeros((1, 1, 16, 16), np.float32),
+              reg=np.full((1, 4, 16, 16), 20.0, np.float32), boxes=np.array([[100, 100, 140, 140]], np.float32))
+    d1["sr"] = gi.np_search_region(d1["boxes"], 512, 1.0)
+    _, _, idx, _ = _check_decode(ops, d1, case, "decode flat")
+    assert int(idx[0]) == 128 * 256 + 128
+    # a NaN logit poisons its bicubic footprint: first NaN cell wins, like torch.argmax on CPU
+    d2 = {k: v.copy() for k, v in d1.items()}
+    d2["center"][0, 0, 5, 7] = np.nan
+    logits = torch.cat([_t(d2[k]) for k in ("cls", "center", "reg")], 1)
+    _, _, idx = ops.emm_decode(logits.to(DEV), _d(d2["sr"]), _d(d2["boxes"]), 30, 15, 512, return_index=True)
+    _, _, idx32, _ = _decode_oracle(d2, case, torch.float32)
+    assert int(idx.cpu()[0]) == int(idx32[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# boundary: EMM.forward / EMM.extract_cache through the registry
+# ------------------------------------------------------------------------------------------------
+def _build_emm(case):
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.registry import SIAMESE_TRACKER
+    from siammot_amd.track_utils import build_track_utils
+    import siammot_amd.emm  # noqa: F401  (registers)
+    cfg = get_default_cfg(channels=case["channels"])
+    th = cfg.MODEL.TRACK_HEAD
+    th.POOLER_RESOLUTION = case["rz"]
+    th.SEARCH_REGION = case["search_region"]
+    th.PAD_PIXELS = case["pad_pixels"]
+    th.MINIMUM_SREACH_REGION = case["min_search_wh"]
+    th.POOLER_SCALES = case["scales"]
+    th.EMM.USE_CENTERNESS = case["use_centerness"]
+    th.EMM.COSINE_WINDOW_WEIGHT = case["sigma"]
+    cfg.INPUT.AMODAL = case["amodal"]
+    emm = SIAMESE_TRACKER["EMM_HIP"](cfg, build_track_utils(cfg))
+    return emm.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name", sorted(gi.EMM_CASES))
+def test_emm_frame_pair_vs_reference_golden(ops, name, golden_dir):
+    from siammot_amd.structures import BoxList
+    case = gi.EMM_CASES[name]
+    inp = gi.emm_case_inputs(name)
+    gold = np.load(os.path.join(golden_dir, "emm_%s.npz" % name))
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in inp["params"].items()})
+    n = len(case["boxes"])
+    det = BoxList(_d(inp["boxes"]), case["image_wh"], mode="xyxy")
+    det.add_field("ids", torch.arange(n, device=DEV))
+    det.add_field("labels", torch.ones(n, dtype=torch.int64, device=DEV))
+    with torch.no_grad():
+        z, sr, det_out = emm.extract_cache(tuple(_d(f) for f in inp["features_a"]), det)
+        _assert_close(z, gold["z"], 1e-5, 1e-5, "extract_cache templates")
+        np.testing.assert_array_equal(sr[0].bbox.cpu().numpy(), gold["sr"])
+        assert tuple(sr[0].size) == (case["image_wh"][0] + 2 * case["pad_pixels"],
+                                     case["image_wh"][1] + 2 * case["pad_pixels"])
+        losses, result, _ = emm(tuple(_d(f) for f in inp["features_b"]), det_out, sr, template_features=z)
+    assert losses == {}
+    res = result[0]
+    assert len(res) == n and res.get_field("ids").cpu().tolist() == gold["ids"].tolist()
+    got = res.bbox.cpu().numpy()
+    ious = iou(got, gold["bb"])
+    nonempty = (gold["bb"][:, 2] > gold["bb"][:, 0]) & (gold["bb"][:, 3] > gold["bb"][:, 1])
+    assert (ious[nonempty] >= 1 - 1e-3).all(), "IoU vs reference: %s" % ious
+    _assert_close(got, gold["bb"], 0, 5e-2, "final boxes vs reference golden")
+    _assert_close(res.get_field("scores"), gold["scores"], 0, 1e-4, "scores vs reference golden")
+    assert tuple(res.size) == tuple(case["image_wh"])
+
+
+def test_emm_full_size_against_oracle(ops):
+    """configs[1] geometry (720p FPN maps, C=128) with 8 tracks: whole head vs the CPU oracle."""
+    from siammot_amd.structures import BoxList
+    case = dict(gi.EMM_CASES["default"], channels=128, image_wh=(1280, 704))
+    rs = np.random.RandomState(99)
+    shapes = gi.feature_shapes(case["image_wh"], 128)
+    feats_a = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    feats_b = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    sizes = [(32, 64), (64, 128), (100, 200), (160, 320)]
+    boxes = np.array([[100 + 140 * i, 60 + 30 * i, 100 + 140 * i + sizes[i % 4][0], 60 + 30 * i + sizes[i % 4][1]]
+                      for i in range(8)], dtype=np.float32)
+    params = gi.predictor_params(rs, 128, boxes)
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in params.items()})
+    det = BoxList(_d(boxes), case["image_wh"], mode="xyxy")
+    det.add_field("ids", torch.arange(8, device=DEV))
+    det.add_field("labels", torch.ones(8, dtype=torch.int64, device=DEV))
+    with torch.no_grad():
+        z, sr, det_out = emm.extract_cache(tuple(_d(f) for f in feats_a), det)
+        _, result, _ = emm(tuple(_d(f) for f in feats_b), det_out, sr, template_features=z)
+    cfg = _cfg(case)
+    z_ref, sr_ref = O.extract_cache(cfg, [_t(f) for f in feats_a], _t(boxes))
+    bb, conf, _ = O.emm_forward(cfg, {k: _t(v) for k, v in params.items()}, [_t(f) for f in feats_b], _t(boxes),
+                                sr_ref, z_ref, case["image_wh"])
+    assert (iou(result[0].bbox.cpu().numpy(), bb.numpy()) >= 1 - 1e-3).all()
+    _assert_close(result[0].get_field("scores"), conf, 0, 1e-4, "scores vs oracle")
+
+
+def test_emm_training_mode_is_refused(ops):
+    emm = _build_emm(gi.EMM_CASES["default"])
+    emm.train()
+    with pytest.raises(NotImplementedError):
+        emm((), [None], [None])

@@ -1,0 +1,153 @@
+"""CPU-side checks: the C-ABI library loads and exports everything include/smot_emm.h declares,
+the host mirror keeps the reference's interface, and the product path refuses to run without a
+device (no CPU fallback).  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "smot_emm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smot_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import siammot_amd.ops as ops
+    lib_path = ops.LIB_PATH
+    if not os.path.exists(lib_path):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(lib_path)
+    declared = _header_symbols()
+    assert len(declared) >= 8
+    for name in declared:
+        assert hasattr(lib, name), "libsmot_emm.so lacks %s declared in include/smot_emm.h" % name
+    assert sorted(ops.EXPORTED_SYMBOLS) == declared       # the ctypes table covers the whole header
+    ops.load_library()
+    assert lib.smot_abi_version() == ops.ABI_VERSION
+
+
+def test_argument_errors_are_reported_without_a_device():
+    """Argument validation happens before any launch, so it is testable on CPU."""
+    import siammot_amd.ops as ops
+    lib = ops.load_library()
+    null = ctypes.c_void_p(0)
+    rc = lib.smot_xcorr_dw_fwd(null, null, null, 2, 4, 10, 15, null)          # Rx < Rz
+    assert rc == -1 and b"xcorr" in lib.smot_last_error()
+    rc = lib.smot_xcorr_dw_fwd(null, null, null, 0, 4, 30, 15, null)          # empty batch is fine
+    assert rc == 0
+    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 12, 30, 15, 512.0, 0.6, 0.4, 1,
+                                 null, null, null, null, null)                  # up not a power of two
+    assert rc == -2 and b"up=12" in lib.smot_last_error()
+    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 16, 30, 14, 512.0, 0.6, 0.4, 1,
+                                 null, null, null, null, null)                  # even rz / Ho mismatch
+    assert rc == -1
+    rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null)
+    assert rc == -1 and b"divisible" in lib.smot_last_error()
+    assert lib.smot_emm_decode_ws_floats(16, 16) == 34
+
+
+def test_product_path_has_no_cpu_fallback():
+    import siammot_amd.ops as ops
+    with pytest.raises(RuntimeError, match="device"):
+        ops.xcorr_depthwise(torch.zeros(1, 2, 30, 30), torch.zeros(1, 2, 15, 15))
+    with pytest.raises(RuntimeError, match="device"):
+        ops.search_region(torch.zeros(1, 4), 512, 1.0, 0)
+    with pytest.raises(RuntimeError, match="not found"):
+        ops.load_library("/nonexistent/libsmot_emm.so")
+
+
+def test_product_code_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "siam-mot_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src, "%s mentions the oracle" % f
+
+
+def test_emm_module_mirrors_reference_interface():
+    import inspect
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.emm import EMM, EMMFeatureExtractor, EMMPredictor, SRPooler
+    from siammot_amd.registry import SIAMESE_TRACKER
+    from siammot_amd.track_utils import build_track_utils
+    cfg = get_default_cfg()
+    tu = build_track_utils(cfg)
+    assert (tu.search_expansion, tu.min_search_wh, tu.pad_pixels) == (1.0, 0, 512)
+    emm = SIAMESE_TRACKER["EMM_HIP"](cfg, tu)
+    assert isinstance(emm, EMM)
+    # reference signatures: track_core.py:16,28,81
+    assert list(inspect.signature(EMM.__init__).parameters) == ["self", "cfg", "track_utils"]
+    assert list(inspect.signature(EMM.forward).parameters) == ["self", "features", "boxes", "sr", "targets",
+                                                               "template_features"]
+    assert list(inspect.signature(EMM.extract_cache).parameters) == ["self", "features", "detection"]
+    assert list(inspect.signature(SRPooler.forward).parameters)[:4] == ["self", "x", "boxes", "sr"]
+    assert list(inspect.signature(EMMFeatureExtractor.forward).parameters)[:4] == ["self", "x", "proposals", "sr"]
+    # reference state_dict keys (SURVEY.md §5, Appendix C probe4)
+    keys = sorted(emm.state_dict().keys())
+    assert keys == sorted("predictor." + k for k in (
+        "cls_tower.0.weight", "cls_tower.1.weight", "cls_tower.1.bias", "reg_tower.0.weight",
+        "reg_tower.1.weight", "reg_tower.1.bias", "cls.weight", "cls.bias", "center.weight", "center.bias",
+        "reg.weight", "reg.bias"))
+    assert emm.rx == 30 and emm.rz == 15 and emm.pad_pixels == 512 and emm.sigma == 0.4
+    assert isinstance(emm.predictor, EMMPredictor)
+    sd = emm.state_dict()
+    assert sd["predictor.cls_tower.0.weight"].shape == (128, 128, 3, 3)
+    assert sd["predictor.reg.weight"].shape == (4, 128, 3, 3)
+    # R-50-FPN body picks RESNETS.BACKBONE_OUT_CHANNELS (feature_extractor.py:49-50)
+    cfg2 = get_default_cfg(conv_body="R-50-FPN")
+    assert EMMPredictor(cfg2).cls.weight.shape == (2, 256, 3, 3)
+
+
+def test_boxlist_conventions():
+    from siammot_amd.structures import BoxList, cat_boxlist
+    b = BoxList(torch.tensor([[-5.0, 10.0, 700.0, 20.0], [30.0, 40.0, 30.0, 80.0], [1.0, 2.0, 3.0, 4.0]]),
+                (640, 480), "xyxy")
+    b.add_field("ids", torch.tensor([7, 8, 9]))
+    kept = b.clip_to_image(remove_empty=True)
+    assert b.bbox[0].tolist() == [0.0, 10.0, 639.0, 20.0]          # clamped in place to [0, W-1]
+    assert kept.get_field("ids").tolist() == [7, 9]                 # zero-width box dropped in the copy only
+    assert len(b) == 3
+    assert b.area().tolist()[2] == 9.0                              # +1 convention
+    xywh = b.convert("xywh")
+    assert xywh.bbox[2].tolist() == [1.0, 2.0, 3.0, 3.0]
+    assert torch.equal(xywh.convert("xyxy").bbox, b.bbox)
+    r = b.resize((1280, 960))
+    assert r.bbox[2].tolist() == [2.0, 4.0, 6.0, 8.0] and r.size == (1280, 960)
+    c = cat_boxlist([b[[0]], b[[2]]])
+    assert len(c) == 2 and c.get_field("ids").tolist() == [7, 9]
+
+
+def test_track_utils_matches_oracle_geometry():
+    from oracle import emm_oracle as O
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_utils import TrackUtils
+    tu = TrackUtils(search_expansion=1.0, min_search_wh=0, pad_pixels=512)
+    boxes = torch.tensor([[10.0, 20.0, 73.5, 148.0], [300.0, 100.0, 459.0, 419.0]])
+    bl = BoxList(boxes.clone(), (1280, 704))
+    bl.add_field("ids", torch.tensor([0, 1]))
+    sr = tu.extend_bbox(tu.update_boxes_in_pad_images([bl]))[0]
+    assert sr.size == [2304, 1728] and sr.get_field("ids").tolist() == [0, 1]
+    assert torch.equal(sr.bbox, O.search_region(boxes, 512, 1.0, 0))
+    assert [tu.pad_level_cells(i) for i in range(5)] == [128, 64, 32, 16, 8]
+    f = tu.pad_feature((torch.ones(1, 2, 4, 6), torch.ones(1, 2, 2, 3)))
+    assert f[0].shape == (1, 2, 260, 262) and f[1].shape == (1, 2, 130, 131)
+
+
+def test_bench_workload_definition():
+    import bench
+    b = bench.synthetic_boxes(30, (1280, 704))
+    assert b.shape == (30, 4)
+    assert (b[:, 0] >= 0).all() and (b[:, 1] >= 0).all() and (b[:, 2] < 1280).all() and (b[:, 3] < 704).all()
+    from oracle import emm_oracle as O
+    assert sorted(set(O.level_mapper(b).tolist())) == [0, 1, 2]
+    # algorithmic bytes of the graded kernel: 707,072 B per track at C=128
+    assert 4 * 128 * (30 * 30 + 15 * 15 + 16 * 16) == 707072
