@@ -135,11 +135,15 @@ int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho,
  *   rx, rz : search / template pooler resolutions (Ho must equal rx-rz+1; rz odd)
  *   one_minus_sigma and sigma are passed separately so the host can form 1-sigma in double as
  *   the reference does.
+ *   clip_w, clip_h : image size for the clamp of wrap_results_to_boxlist (track_core.py:177-178:
+ *   BoxList.clip_to_image, x in [0,w-1], y in [0,h-1]; the reference discards the filtered copy, so
+ *   boxes are clamped, never removed); pass clip_w <= 0 for INPUT.AMODAL (no clamp).
  * NaN scores win the argmax and ties go to the lowest index (torch.argmax on CPU).
  */
 int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
                         int N, int Ho, int up, int rx, int rz, float pad_pixels,
                         float one_minus_sigma, float sigma, int use_centerness,
+                        float clip_w, float clip_h,
                         float* cand_ws, float* bb, float* conf, int64_t* idx, smot_stream_t stream);
 
 /* fp32 elements of decode workspace needed PER TRACK. */

@@ -18,7 +18,10 @@ SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of
 # v_pk_fma_f32 + register shuffles (measured: 450 pk_fma + 204 movs vs 900 fma + 4 movs).
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "--offload-arch=" + ARCH]
+# -ffp-contract=off: the reference's torch kernels round every mul/add separately; coordinate and
+# score arithmetic must do the same (a contracted `start + p*bin` moves a bilinear sample point by
+# 1 ulp ~ 1e-5 in the output).  FMAs are written explicitly (fmaf) where they are wanted.
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=off", "--offload-arch=" + ARCH]
 
 
 def _hipcc():

@@ -43,6 +43,11 @@ __device__ __forceinline__ void cubic_src(int d, float inv_up, int* base, float*
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// torch.clamp semantics: NaN stays NaN
+__device__ __forceinline__ float clamp_nan(float v, float lo, float hi) {
+    return (v != v) ? v : fminf(fmaxf(v, lo), hi);
+}
+
 __device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
     return a * w[0] + b * w[1] + c * w[2] + d * w[3];
 }
@@ -177,7 +182,7 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
 __global__ void __launch_bounds__(64)
 decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict__ sr,
                        const float* __restrict__ boxes, DecodeParams D, int rx, int rz, float pad,
-                       const unsigned long long* __restrict__ cand, int nband,
+                       const unsigned long long* __restrict__ cand, int nband, float clip_w, float clip_h,
                        float* __restrict__ bb, float* __restrict__ conf, long long* __restrict__ idx_out) {
     const int n = blockIdx.x;
     const int lane = threadIdx.x;
@@ -227,10 +232,19 @@ decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict
     const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
     const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), pad);
     const float cy = sub_rn(add_rn(sy1, mul_rn((float)(st + Y), stride_h)), pad);
-    bb[n * 4 + 0] = sub_rn(cx, v[3]);
-    bb[n * 4 + 1] = sub_rn(cy, v[4]);
-    bb[n * 4 + 2] = add_rn(cx, v[5]);
-    bb[n * 4 + 3] = add_rn(cy, v[6]);
+    float bx1 = sub_rn(cx, v[3]), by1 = sub_rn(cy, v[4]);
+    float bx2 = add_rn(cx, v[5]), by2 = add_rn(cy, v[6]);
+    if (clip_w > 0.0f) {
+        // BoxList.clip_to_image (TO_REMOVE = 1): x in [0, w-1], y in [0, h-1]; NaN passes through
+        bx1 = clamp_nan(bx1, 0.0f, clip_w - 1.0f);
+        by1 = clamp_nan(by1, 0.0f, clip_h - 1.0f);
+        bx2 = clamp_nan(bx2, 0.0f, clip_w - 1.0f);
+        by2 = clamp_nan(by2, 0.0f, clip_h - 1.0f);
+    }
+    bb[n * 4 + 0] = bx1;
+    bb[n * 4 + 1] = by1;
+    bb[n * 4 + 2] = bx2;
+    bb[n * 4 + 3] = by2;
     const float m = fmaxf(v[0], v[1]);
     const float e0 = expf(sub_rn(v[0], m)), e1 = expf(sub_rn(v[1], m));
     conf[n] = div_rn(e1, add_rn(e0, e1));
@@ -246,8 +260,8 @@ extern "C" int smot_emm_decode_ws_floats(int Ho, int up) {
 
 extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
                                    int N, int Ho, int up, int rx, int rz, float pad_pixels, float one_minus_sigma,
-                                   float sigma, int use_centerness, float* cand_ws, float* bb, float* conf,
-                                   int64_t* idx, smot_stream_t stream) {
+                                   float sigma, int use_centerness, float clip_w, float clip_h, float* cand_ws,
+                                   float* bb, float* conf, int64_t* idx, smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && Ho > 0 && up > 0, "decode: bad sizes N=%d Ho=%d up=%d", N, Ho, up);
     SMOT_REQUIRE(rx - rz + 1 == Ho && (rz & 1) == 1, "decode: need Ho == rx-rz+1 and odd rz (Ho=%d rx=%d rz=%d)", Ho,
@@ -277,6 +291,6 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     int rc = check_launch("decode bands");
     if (rc) return rc;
     hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, logits, sr, boxes, D, rx, rz, pad_pixels,
-                       (const unsigned long long*)cand, Ho + 1, bb, conf, (long long*)idx);
+                       (const unsigned long long*)cand, Ho + 1, clip_w, clip_h, bb, conf, (long long*)idx);
     return check_launch("decode finalize");
 }

@@ -278,79 +278,101 @@ tower_generic_kernel(const float* __restrict__ resp, TowerParams P, int C, int H
     }
 }
 
-struct HeadParams {
-    const float* w[4];   // per output channel: [C*9] filter (device)
-    const float* b[4];   // per output channel: bias scalar (device)
-    int n_out;
-    int relu;
-    int in_ch0;          // first tower_ws channel of this tower
-    int out_ch0;         // first logits channel
+struct HeadsParams {
+    const float* cls_w;      // [2, C, 3, 3]
+    const float* cls_b;      // [2]
+    const float* center_w;   // [1, C, 3, 3]
+    const float* center_b;   // [1]
+    const float* reg_w;      // [4, C, 3, 3]
+    const float* reg_b;      // [4]
 };
 
-// Heads: grid (N, 2).  Tower planes are staged 16 at a time into zero-haloed LDS planes; each
-// thread owns positions pos, pos+256, ... and accumulates up to 4 output channels.
+// Heads: grid (N, 2): y = 0 -> cls0, cls1, center from the cls tower; y = 1 -> reg l/t/r/b (+ReLU) from
+// the reg tower.  Tower planes are staged H_IC at a time into zero-haloed LDS planes; a thread owns
+// NPOS output positions and accumulates 4 output channels per position (the cls side computes the
+// center filter twice and drops the copy).  Filter taps are wave-uniform: addressed only through
+// kernel arguments and loop counters, so they are fetched with scalar loads and used as the SGPR
+// operand of v_fmac — no LDS traffic, no VGPRs, no per-lane global loads for weights.
 constexpr int H_IC = 16;
-constexpr int H_MAXPOS = 4;     // positions per thread (Ho*Ho <= 1024)
+constexpr int H_MAXPOS = 4;     // positions per thread for Ho*Ho up to 1024
 
+template <int NPOS>
 __global__ void __launch_bounds__(256)
-heads_kernel(const float* __restrict__ tower_ws, HeadParams P0, HeadParams P1, int C, int Ho,
-             float* __restrict__ logits) {
+heads_kernel(const float* __restrict__ tower_ws, HeadsParams H, int C, int Ho, float* __restrict__ logits) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const HeadParams& P = (blockIdx.y == 0) ? P0 : P1;
+    const bool reg_side = (blockIdx.y == 1);
     const int n = blockIdx.x;
     const int HW = Ho * Ho;
     const int PW = Ho + 2;
     const int plane = PW * PW;
-    const float* __restrict__ in = tower_ws + ((size_t)n * 2 * C + P.in_ch0) * HW;
-    float acc[H_MAXPOS][4];
+    const int C9 = C * 9;
+    const float* __restrict__ w0 = reg_side ? H.reg_w : H.cls_w;
+    const float* __restrict__ w1 = w0 + C9;
+    const float* __restrict__ w2 = reg_side ? H.reg_w + 2 * C9 : H.center_w;
+    const float* __restrict__ w3 = reg_side ? H.reg_w + 3 * C9 : H.center_w;
+    const float* __restrict__ in = tower_ws + ((size_t)n * 2 * C + (reg_side ? C : 0)) * HW;
+
+    int off[NPOS];
 #pragma unroll
-    for (int p = 0; p < H_MAXPOS; ++p)
+    for (int p = 0; p < NPOS; ++p) {
+        const int pos = min((int)threadIdx.x + p * 256, HW - 1);
+        const int y = pos / Ho, x = pos - y * Ho;
+        off[p] = y * PW + x;
+    }
+    float acc[NPOS][4];
+#pragma unroll
+    for (int p = 0; p < NPOS; ++p)
 #pragma unroll
         for (int o = 0; o < 4; ++o) acc[p][o] = 0.0f;
-    for (int e = threadIdx.x; e < H_IC * plane; e += blockDim.x) sm[e] = 0.0f;
+
+    for (int e = threadIdx.x; e < H_IC * plane; e += 256) sm[e] = 0.0f;   // halos stay zero
     __syncthreads();
     for (int ic0 = 0; ic0 < C; ic0 += H_IC) {
-        for (int e = threadIdx.x; e < H_IC * HW; e += blockDim.x) {
+        const int icn = min(H_IC, C - ic0);
+        for (int e = threadIdx.x; e < icn * HW; e += 256) {
             const int ic = e / HW;
             const int pos = e - ic * HW;
             const int y = pos / Ho, x = pos - y * Ho;
-            sm[ic * plane + (y + 1) * PW + (x + 1)] = (ic0 + ic < C) ? in[(size_t)(ic0 + ic) * HW + pos] : 0.0f;
+            sm[ic * plane + (y + 1) * PW + (x + 1)] = in[(size_t)(ic0 + ic) * HW + pos];
         }
         __syncthreads();
-        const int icn = min(H_IC, C - ic0);
+        // two input channels per trip: the 8 scalar tap loads of both are issued before the single
+        // lgkmcnt(0) wait, halving the exposed scalar-cache latency
+#pragma unroll 2
         for (int ic = 0; ic < icn; ++ic) {
-            float wv[4][9];
+            const int wb = (ic0 + ic) * 9;          // wave-uniform
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
+            for (int k = 0; k < 9; ++k) {
+                const float t0 = w0[wb + k], t1 = w1[wb + k], t2 = w2[wb + k], t3 = w3[wb + k];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) wv[o][k] = (o < P.n_out) ? P.w[o][(ic0 + ic) * 9 + k] : 0.0f;
-#pragma unroll
-            for (int p = 0; p < H_MAXPOS; ++p) {
-                const int pos = threadIdx.x + p * 256;
-                if (pos < HW) {
-                    const int y = pos / Ho, x = pos - y * Ho;
-                    const float* s = sm + ic * plane + y * PW + x;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const float v = s[(k / 3) * PW + (k % 3)];
-#pragma unroll
-                        for (int o = 0; o < 4; ++o) acc[p][o] = fmaf(v, wv[o][k], acc[p][o]);
-                    }
+                for (int p = 0; p < NPOS; ++p) {
+                    const float v = sm[ic * plane + off[p] + (k / 3) * PW + (k % 3)];
+                    acc[p][0] = fmaf(v, t0, acc[p][0]);
+                    acc[p][1] = fmaf(v, t1, acc[p][1]);
+                    acc[p][2] = fmaf(v, t2, acc[p][2]);
+                    acc[p][3] = fmaf(v, t3, acc[p][3]);
                 }
             }
         }
         __syncthreads();
     }
+    const int n_out = reg_side ? 4 : 3;
+    const int out_ch0 = reg_side ? 3 : 0;
+    float bias[4];
+    bias[0] = reg_side ? H.reg_b[0] : H.cls_b[0];
+    bias[1] = reg_side ? H.reg_b[1] : H.cls_b[1];
+    bias[2] = reg_side ? H.reg_b[2] : H.center_b[0];
+    bias[3] = reg_side ? H.reg_b[3] : 0.0f;
 #pragma unroll
-    for (int p = 0; p < H_MAXPOS; ++p) {
+    for (int p = 0; p < NPOS; ++p) {
         const int pos = threadIdx.x + p * 256;
         if (pos < HW) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
-                if (o < P.n_out) {
-                    float v = acc[p][o] + P.b[o][0];
-                    if (P.relu) v = fmaxf(v, 0.0f);
-                    logits[((size_t)n * 7 + P.out_ch0 + o) * HW + pos] = v;
+                if (o < n_out) {
+                    float v = acc[p][o] + bias[o];
+                    if (reg_side) v = fmaxf(v, 0.0f);
+                    logits[((size_t)n * 7 + out_ch0 + o) * HW + pos] = v;
                 }
             }
         }
@@ -407,29 +429,21 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
     int rc = check_launch("predictor towers");
     if (rc) return rc;
 
-    HeadParams H0, H1;
-    H0.w[0] = cls_w;
-    H0.w[1] = cls_w + (size_t)C * 9;
-    H0.w[2] = center_w;
-    H0.w[3] = center_w;
-    H0.b[0] = cls_b;
-    H0.b[1] = cls_b + 1;
-    H0.b[2] = center_b;
-    H0.b[3] = center_b;
-    H0.n_out = 3;
-    H0.relu = 0;
-    H0.in_ch0 = 0;
-    H0.out_ch0 = 0;
-    for (int o = 0; o < 4; ++o) {
-        H1.w[o] = reg_w + (size_t)o * C * 9;
-        H1.b[o] = reg_b + o;
-    }
-    H1.n_out = 4;
-    H1.relu = 1;
-    H1.in_ch0 = C;
-    H1.out_ch0 = 3;
+    HeadsParams H;
+    H.cls_w = cls_w;
+    H.cls_b = cls_b;
+    H.center_w = center_w;
+    H.center_b = center_b;
+    H.reg_w = reg_w;
+    H.reg_b = reg_b;
     const size_t hsmem = (size_t)H_IC * (Ho + 2) * (Ho + 2) * sizeof(float);
     SMOT_REQUIRE(hsmem <= 64 * 1024, "predictor: Ho=%d too large for the heads kernel", Ho);
-    hipLaunchKernelGGL(heads_kernel, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H0, H1, C, Ho, logits);
+    if (Ho * Ho <= 256) {
+        hipLaunchKernelGGL(heads_kernel<1>, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H, C, Ho,
+                           logits);
+    } else {
+        hipLaunchKernelGGL(heads_kernel<H_MAXPOS>, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H, C,
+                           Ho, logits);
+    }
     return check_launch("predictor heads");
 }

@@ -29,7 +29,8 @@ inline int check_launch(const char* what) {
     } while (0)
 
 // fp32 ops that must NOT be contracted into FMAs, so that the rounding sequence matches the
-// reference's separate torch mul / add kernels.
+// reference's separate torch mul / add kernels.  (In ROCm 7.2 __fmul_rn & co. are plain operators,
+// so the guarantee comes from building with -ffp-contract=off — see build.py.)
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, b); }

@@ -20,6 +20,7 @@
 //     oracle/emm_oracle.py:xcorr_depthwise uses the same order).
 // No workgroup barrier is needed: each wave only touches its own LDS slab.
 #include "smot_common.h"
+#include <stdlib.h>
 
 namespace smot {
 
@@ -107,6 +108,159 @@ xcorr_dw_wave_kernel(const float* __restrict__ x, const float* __restrict__ z,
     *reinterpret_cast<float4*>(out + (size_t)plane * (HO * HO) + i * HO + 4 * g) = o;
 }
 
+// Patch kernel (Ho == 16, default fast path): ONE WAVEFRONT PER FOUR PLANES, no scalar memory.
+//   * a 16-lane group owns a plane; lane (q, g) of the group owns the 4x4 output patch rows 4q..4q+3,
+//     cols 4g..4g+3 (16 accumulators);
+//   * the wave walks the 18 window rows t = 0..17 of its patches in lock-step: row 4q+t of the search
+//     plane is read ONCE from LDS (18 floats: 4 x ds_read_b128 + ds_read_b64) and feeds up to four
+//     (output row k, template row u = t-k) combinations = up to 240 FMAs — 4x fewer LDS bytes per FMA
+//     than the wave-per-plane kernel;
+//   * the template row needed at step t is read once per step (4 x ds_read_b128, one address per
+//     16-lane group) and stays in registers for the four steps that use it; taps are ordinary VGPR
+//     operands, so nothing waits on the scalar cache (in the wave-per-plane kernel every template row
+//     was an s_load whose lgkmcnt(0) wait was exposed 15 times per plane);
+//   * LDS image: plane stride 1088 floats, row stride 36 floats -> the four 16-lane groups of a
+//     ds_read_b128 touch 16 distinct 16-byte slots (conflict-free, derivation in DESIGN.md);
+//   * per output the taps are accumulated u-major / v-minor in one fp32 FMA chain: bit-identical to
+//     the wave-per-plane kernel and to the order of oracle/emm_oracle.py:xcorr_depthwise.
+template <int RX, int RZ>
+__global__ void __launch_bounds__(64)
+xcorr_dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                      float* __restrict__ out, int planes) {
+    constexpr int HO = RX - RZ + 1;
+    static_assert(HO == 16, "patch kernel tiles a 16x16 response");
+    constexpr int XS = 36;                  // search-plane row stride (floats)
+    constexpr int XP = 1088;                // search-plane stride (>= RX*XS = 1080, multiple of 64)
+    constexpr int ZS = 16;                  // template row stride
+    constexpr int ZP = RZ * ZS;             // template plane stride (240)
+    constexpr int WIN = RZ + 3;             // 18 floats of a window row feed a 4-wide patch
+    static_assert(RX * XS <= XP && RZ <= ZS && 4 * 3 + WIN <= XS, "LDS image too small");
+    __shared__ __attribute__((aligned(16))) float sm[4 * XP + 4 * ZP];
+    float* xs = sm;
+    float* zs = sm + 4 * XP;
+
+    const int lane = threadIdx.x;
+    const int plane0 = blockIdx.x * 4;
+
+    // ---- stage 4 search planes + 4 templates (coalesced dword loads, conflict-free LDS stores) ----
+    constexpr int NX = (RX * RX + 63) / 64;     // 15
+    constexpr int NZ = (RZ * RZ + 63) / 64;     // 4
+    int xoff[NX], zoff[NZ];
+#pragma unroll
+    for (int t = 0; t < NX; ++t) {
+        const int e = min(lane + 64 * t, RX * RX - 1);
+        const int r = e / RX;
+        xoff[t] = r * XS + (e - r * RX);
+    }
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) {
+        const int e = min(lane + 64 * t, RZ * RZ - 1);
+        const int u = e / RZ;
+        zoff[t] = u * ZS + (e - u * RZ);
+    }
+#pragma unroll
+    for (int pl = 0; pl < 4; ++pl) {
+        const int plane = min(plane0 + pl, planes - 1);      // tail sets re-read the last plane
+        const float* __restrict__ xg = x + (size_t)plane * (RX * RX);
+        const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
+        float sx[NX], sz[NZ];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) sx[t] = xg[min(lane + 64 * t, RX * RX - 1)];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) sz[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+#pragma unroll
+        for (int t = 0; t < NX; ++t) xs[pl * XP + xoff[t]] = sx[t];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) zs[pl * ZP + zoff[t]] = sz[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int p = lane >> 4, q = (lane >> 2) & 3, g = lane & 3;
+    const float* xrow = xs + p * XP + (4 * q) * XS + 4 * g;
+    const float* zrow = zs + p * ZP;
+    float acc[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[k][j] = 0.0f;
+    // Software pipeline: the LDS reads of step t+1 are issued before the FMAs of step t (two named
+    // register windows wa/wb alternate); the sched_barrier at the end of every step keeps hipcc from
+    // hoisting ALL reads of the fully unrolled loop to the top (it otherwise does: scratch spills).
+    float zr[RZ][ZS];
+    float wa[20], wb[20];
+#define SMOT_LOAD_X(T, DST)                                                                 \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                     \
+            const float4 v4 = *reinterpret_cast<const float4*>(xrow + (T) * XS + 4 * m);    \
+            DST[4 * m + 0] = v4.x;                                                          \
+            DST[4 * m + 1] = v4.y;                                                          \
+            DST[4 * m + 2] = v4.z;                                                          \
+            DST[4 * m + 3] = v4.w;                                                          \
+        }                                                                                   \
+        const float2 v2 = *reinterpret_cast<const float2*>(xrow + (T) * XS + 16);           \
+        DST[16] = v2.x;                                                                     \
+        DST[17] = v2.y;                                                                     \
+    }
+#define SMOT_LOAD_Z(T)                                                                      \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                     \
+            const float4 v4 = *reinterpret_cast<const float4*>(zrow + (T) * ZS + 4 * m);    \
+            zr[T][4 * m + 0] = v4.x;                                                        \
+            zr[T][4 * m + 1] = v4.y;                                                        \
+            zr[T][4 * m + 2] = v4.z;                                                        \
+            zr[T][4 * m + 3] = v4.w;                                                        \
+        }                                                                                   \
+    }
+/* register-only FMAs carry no chain: without this pin SelectionDAG linearises ALL of them after the   \
+   last sched_barrier.  An empty volatile asm that "modifies" the accumulators orders them per step. */ \
+#define SMOT_PIN_ACC()                                                                      \
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[0][3]),   \
+                      "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]), "+v"(acc[1][3]),   \
+                      "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[2][2]), "+v"(acc[2][3]),   \
+                      "+v"(acc[3][0]), "+v"(acc[3][1]), "+v"(acc[3][2]), "+v"(acc[3][3]));
+#define SMOT_STEP(T, CUR, NXT)                                                              \
+    {                                                                                       \
+        if ((T) + 1 < RZ + 3) SMOT_LOAD_X((T) + 1, NXT)                                     \
+        if ((T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                              \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
+            const int u = (T) - k;                                                          \
+            if (u >= 0 && u < RZ) {                                                         \
+                _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                           \
+                        acc[k][j] = fmaf(CUR[j + v], zr[u][v], acc[k][j]);                  \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        SMOT_PIN_ACC()                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    SMOT_LOAD_X(0, wa)
+    SMOT_LOAD_Z(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t2 = 0; t2 < RZ + 3; t2 += 2) {
+        SMOT_STEP(t2, wa, wb)
+        if (t2 + 1 < RZ + 3) SMOT_STEP(t2 + 1, wb, wa)
+    }
+#undef SMOT_STEP
+#undef SMOT_PIN_ACC
+#undef SMOT_LOAD_Z
+#undef SMOT_LOAD_X
+    const int plane = plane0 + p;
+    if (plane < planes) {
+        float* o = out + (size_t)plane * (HO * HO) + (4 * q) * HO + 4 * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4 v;
+            v.x = acc[k][0];
+            v.y = acc[k][1];
+            v.z = acc[k][2];
+            v.w = acc[k][3];
+            *reinterpret_cast<float4*>(o + k * HO) = v;
+        }
+    }
+}
+
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.
 __global__ void __launch_bounds__(256)
 xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -142,8 +296,15 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
     const int planes = N * C;
     hipStream_t st = (hipStream_t)stream;
     if (Rx == 30 && Rz == 15) {
-        hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), dim3((planes + 3) / 4), dim3(256), 0, st, x, z, out,
-                           planes);
+        // SMOT_XCORR_VARIANT=wave selects the older wave-per-plane kernel (A/B measurements only)
+        const char* var = getenv("SMOT_XCORR_VARIANT");
+        if (var != nullptr && var[0] == 'w') {
+            hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), dim3((planes + 3) / 4), dim3(256), 0, st, x, z, out,
+                               planes);
+        } else {
+            hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z, out,
+                               planes);
+        }
     } else {
         const size_t smem = (size_t)(Rx * Rx + Rz * Rz) * sizeof(float);
         SMOT_REQUIRE(smem <= 160 * 1024, "xcorr: plane too large for LDS (Rx=%d Rz=%d)", Rx, Rz);

@@ -142,8 +142,10 @@ class EMM(nn.Module):
         logits = self.predictor.forward_logits(response_map)
         bb, bb_conf = ops.emm_decode(logits, cat([b.bbox for b in sr], dim=0), boxes[0].bbox,
                                      self.rx, self.rz, self.pad_pixels, sigma=self.sigma,
-                                     use_centerness=self.use_centerness)
-        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=self.amodal)
+                                     use_centerness=self.use_centerness,
+                                     clip_wh=None if self.amodal else boxes[0].size)
+        # the clamp of clip_to_image already happened inside the decode kernel
+        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)
         return {}, track_result, {}
 
     def extract_cache(self, features, detection):

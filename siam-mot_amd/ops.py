@@ -38,7 +38,7 @@ _SIGNATURES = {
     "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
     "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp]),
-    "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i,
+    "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
                                            _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
 }
@@ -202,8 +202,10 @@ def hann_window(G, device):
     return _hann_cache[key]
 
 
-def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=True, return_index=False):
-    """Fused up-sample + decode.  logits ``[N,7,Ho,Ho]``, sr/boxes ``[N,4]`` → (bb ``[N,4]``, conf ``[N]``)."""
+def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=True, return_index=False,
+               clip_wh=None):
+    """Fused up-sample + decode.  logits ``[N,7,Ho,Ho]``, sr/boxes ``[N,4]`` → (bb ``[N,4]``, conf ``[N]``).
+    ``clip_wh=(W, H)`` also applies the in-place clamp of ``BoxList.clip_to_image`` (non-amodal)."""
     lib = load_library()
     logits = _dev_f32(logits, "logits")
     sr = _dev_f32(sr, "sr")
@@ -217,6 +219,9 @@ def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
     rc = lib.smot_emm_decode_fwd(_ptr(logits), _ptr(sr), _ptr(boxes), _ptr(hann_window(G, dev)), N, Ho, UP_SCALE,
                                  int(rx), int(rz), float(pad_pixels), float(1 - sigma), float(sigma),
-                                 int(bool(use_centerness)), _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
+                                 int(bool(use_centerness)),
+                                 float(clip_wh[0]) if clip_wh is not None else 0.0,
+                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
+                                 _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
     _check(rc, "emm_decode")
     return (bb, conf, idx) if return_index else (bb, conf)

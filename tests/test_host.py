@@ -43,10 +43,10 @@ def test_argument_errors_are_reported_without_a_device():
     assert rc == -1 and b"xcorr" in lib.smot_last_error()
     rc = lib.smot_xcorr_dw_fwd(null, null, null, 0, 4, 30, 15, null)          # empty batch is fine
     assert rc == 0
-    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 12, 30, 15, 512.0, 0.6, 0.4, 1,
+    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 12, 30, 15, 512.0, 0.6, 0.4, 1, 0.0, 0.0,
                                  null, null, null, null, null)                  # up not a power of two
     assert rc == -2 and b"up=12" in lib.smot_last_error()
-    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 16, 30, 14, 512.0, 0.6, 0.4, 1,
+    rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 16, 30, 14, 512.0, 0.6, 0.4, 1, 0.0, 0.0,
                                  null, null, null, null, null)                  # even rz / Ho mismatch
     assert rc == -1
     rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null)
