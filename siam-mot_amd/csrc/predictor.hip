@@ -25,20 +25,20 @@ namespace smot {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int T_OC = 32;          // output channels per workgroup
-constexpr int T_IC = 16;          // input channels per K chunk
-constexpr int T_STEPS = 9 * (T_IC / 4);          // MFMA k-steps per chunk (36)
-constexpr int T_A_FLOATS = T_STEPS * 2 * 64;     // 4608
-constexpr int T_PLANE = 336;                     // 18*18 = 324 padded to 336
-constexpr int T_B_FLOATS = T_IC * T_PLANE;       // 5376
-constexpr int T_BUF_FLOATS = T_A_FLOATS + T_B_FLOATS;
-constexpr int T_A_PER_THREAD = T_OC * T_IC * 9 / 256;   // 18
-constexpr int T_B_PER_THREAD = T_IC;                    // 16 (one position of each plane)
+constexpr int T_IC = 16;                          // input channels per K chunk
+constexpr int T_STEPS = 9 * (T_IC / 4);           // MFMA k-steps per chunk (36)
+constexpr int T_PLANE = 336;                      // 18*18 = 324 padded to 336
+constexpr int T_B_FLOATS = T_IC * T_PLANE;        // 5376
+constexpr int T_B_PER_THREAD = T_IC;              // one position of each plane per thread
 
 struct TowerParams {
     const float* w[2];      // [C, C, 3, 3] cls_tower.0.weight / reg_tower.0.weight
     const float* gamma[2];  // [C]
     const float* beta[2];   // [C]
+    // head filters (fused partial heads): cls [2,C,3,3], center [1,C,3,3], reg [4,C,3,3]
+    const float* cls_w;
+    const float* center_w;
+    const float* reg_w;
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
@@ -50,9 +50,18 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// MT = number of 16-channel M tiles per workgroup (output-channel tile T_OC = 16*MT).
+// MT = 2 halves the B-operand traffic per MFMA; MT = 1 doubles the number of workgroups, which is
+// what fills the chip (and puts two waves on every SIMD) at small track counts.
+template <int MT>
 __global__ void __launch_bounds__(256)
 tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
-                  float* __restrict__ tower_ws) {
+                  float* __restrict__ part) {
+    constexpr int T_OC = 16 * MT;
+    constexpr int A_FLOATS = T_STEPS * MT * 64;
+    constexpr int BUF_FLOATS = A_FLOATS + T_B_FLOATS;
+    constexpr int A_PER_THREAD = T_OC * T_IC * 9 / 256;       // 9 * MT
+    constexpr int HW_PER_THREAD = (T_OC * 36 + 255) / 256;    // head taps staged per thread
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,13 +76,34 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
     const float* __restrict__ in = resp + (size_t)n * C * 256;
 
     // zero both buffers once: the B halos stay zero for the whole kernel
-    for (int e = tid; e < 2 * T_BUF_FLOATS; e += 256) sm[e] = 0.0f;
+    for (int e = tid; e < 2 * BUF_FLOATS; e += 256) sm[e] = 0.0f;
 
-    float pa[T_A_PER_THREAD], pb[T_B_PER_THREAD];
+    // head taps of this tile's channels, fetched now, used in the epilogue: hw[(ocl*9+tap)*4 + o]
+    float hwreg[HW_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < HW_PER_THREAD; ++j) {
+        const int idx = tid + 256 * j;
+        float v = 0.0f;
+        if (idx < T_OC * 36) {
+            const int o = idx / (T_OC * 9);
+            const int rem = idx - o * (T_OC * 9);      // ocl*9 + tap
+            const size_t src = (size_t)oc0 * 9 + rem;
+            if (tower == 1) {
+                v = P.reg_w[(size_t)o * C * 9 + src];
+            } else if (o < 2) {
+                v = P.cls_w[(size_t)o * C * 9 + src];
+            } else if (o == 2) {
+                v = P.center_w[src];
+            }
+        }
+        hwreg[j] = v;
+    }
+
+    float pa[A_PER_THREAD], pb[T_B_PER_THREAD];
     auto load_chunk = [&](int ic0) {
 #pragma unroll
-        for (int j = 0; j < T_A_PER_THREAD; ++j) {
-            const int idx = tid + 256 * j;          // over [32 oc][16 ic * 9]
+        for (int j = 0; j < A_PER_THREAD; ++j) {
+            const int idx = tid + 256 * j;          // over [T_OC][16 ic * 9]
             const int oc = idx / (T_IC * 9);
             const int rem = idx - oc * (T_IC * 9);
             pa[j] = W[((size_t)(oc0 + oc) * C + ic0) * 9 + rem];
@@ -83,25 +113,25 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
     };
     auto store_chunk = [&](float* buf) {
         float* A = buf;
-        float* B = buf + T_A_FLOATS;
+        float* B = buf + A_FLOATS;
 #pragma unroll
-        for (int j = 0; j < T_A_PER_THREAD; ++j) {
+        for (int j = 0; j < A_PER_THREAD; ++j) {
             const int idx = tid + 256 * j;
             const int oc = idx / (T_IC * 9);
             const int rem = idx - oc * (T_IC * 9);
             const int ic = rem / 9;
             const int tap = rem - ic * 9;
             const int s = tap * (T_IC / 4) + (ic >> 2);
-            A[((s * 2 + (oc >> 4)) * 4 + (ic & 3)) * 16 + (oc & 15)] = pa[j];
+            A[((s * MT + (oc >> 4)) * 4 + (ic & 3)) * 16 + (oc & 15)] = pa[j];
         }
         const int y = tid >> 4, x = tid & 15;
 #pragma unroll
         for (int j = 0; j < T_B_PER_THREAD; ++j) B[j * T_PLANE + (y + 1) * 18 + (x + 1)] = pb[j];
     };
 
-    f32x4 acc[2][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[m][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -113,41 +143,52 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
     const int nchunks = C / T_IC;
     const int kq = lane >> 4, xl = lane & 15;
     for (int c = 0; c < nchunks; ++c) {
-        float* buf = sm + (c & 1) * T_BUF_FLOATS;
+        float* buf = sm + (c & 1) * BUF_FLOATS;
         if (c + 1 < nchunks) load_chunk((c + 1) * T_IC);
         const float* A = buf + lane;
-        const float* B = buf + T_A_FLOATS + kq * T_PLANE + (4 * wave) * 18 + xl;
+        const float* B = buf + A_FLOATS + kq * T_PLANE + (4 * wave) * 18 + xl;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
             for (int icq = 0; icq < T_IC / 4; ++icq) {
                 const int s = tap * (T_IC / 4) + icq;
-                const float a0 = A[(s * 2 + 0) * 64];
-                const float a1 = A[(s * 2 + 1) * 64];
+                float a[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = A[(s * MT + m) * 64];
                 const float* Bp = B + (4 * icq) * T_PLANE + dy * 18 + dx;
                 const float b0 = Bp[0 * 18], b1 = Bp[1 * 18], b2 = Bp[2 * 18], b3 = Bp[3 * 18];
-                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
-                acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2, acc[0][2], 0, 0, 0);
-                acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b2, acc[1][2], 0, 0, 0);
-                acc[0][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b3, acc[0][3], 0, 0, 0);
-                acc[1][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b3, acc[1][3], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b0, acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b1, acc[m][1], 0, 0, 0);
+                    acc[m][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b2, acc[m][2], 0, 0, 0);
+                    acc[m][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b3, acc[m][3], 0, 0, 0);
+                }
             }
         }
-        if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * T_BUF_FLOATS);
+        if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
         __syncthreads();
     }
 
     // ---- fused GroupNorm (two-pass, fp32) + affine + ReLU -----------------------------------
     // acc[m][t][r] = conv[oc = m*16 + kq*4 + r][pos = (4*wave + t)*16 + xl]
-    float* red = sm;                       // [4 waves][32 channels], reused twice
-    float* stat = sm + 4 * T_OC;           // [32] group mean / rstd per channel
+    // scratch in the (now free) A image of buffer 0; head taps go to the A image of buffer 1
+    float* red = sm;                       // [4 waves][T_OC]
+    float* stat = sm + 4 * T_OC;           // [T_OC] group mean, then rstd, per channel
+    float* hw = sm + BUF_FLOATS;           // [T_OC*9][4]
+#pragma unroll
+    for (int j = 0; j < HW_PER_THREAD; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < T_OC * 36) {
+            const int o = idx / (T_OC * 9);
+            const int rem = idx - o * (T_OC * 9);
+            hw[rem * 4 + o] = hwreg[j];
+        }
+    }
     const float inv_cnt = 1.0f / (float)(cpg * 256);
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = acc[m][0][r] + acc[m][1][r] + acc[m][2][r] + acc[m][3][r];
@@ -163,14 +204,14 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         stat[tid] = s * inv_cnt;
     }
     __syncthreads();
-    float mean[2][4];
+    float mean[MT][4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mean[m][r] = stat[m * 16 + kq * 4 + r];
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float s = 0.0f;
@@ -191,23 +232,78 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         stat[tid] = 1.0f / sqrtf(s * inv_cnt + eps);
     }
     __syncthreads();
+    // normalised + ReLU'd activations -> zero-haloed LDS planes (interiors of the B images: plane ocl
+    // lives in buffer ocl>>4, slot ocl&15; the halos were zeroed at kernel start and never written)
     const float* __restrict__ gamma = P.gamma[tower];
     const float* __restrict__ beta = P.beta[tower];
-    float* __restrict__ dst = tower_ws + ((size_t)n * 2 * C + (size_t)tower * C + oc0) * 256;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ocl = m * 16 + kq * 4 + r;
             const float rstd = stat[ocl];
             const float ga = gamma[oc0 + ocl], be = beta[oc0 + ocl];
+            float* pl = sm + m * BUF_FLOATS + A_FLOATS + (kq * 4 + r) * T_PLANE;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = (acc[m][t][r] - mean[m][r]) * rstd * ga + be;
                 v = fmaxf(v, 0.0f);
-                dst[(size_t)ocl * 256 + (4 * wave + t) * 16 + xl] = v;
+                pl[(4 * wave + t + 1) * 18 + xl + 1] = v;
             }
         }
+    __syncthreads();
+
+    // ---- fused partial heads: this tile's T_OC channels x 9 taps -> 4 head outputs per position ----
+    // thread = output position; hw rows are read as one broadcast ds_read_b128 per (channel, tap)
+    {
+        const int y = tid >> 4, x = tid & 15;
+        float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const float* pl0 = sm + m * BUF_FLOATS + A_FLOATS + y * 18 + x;
+#pragma unroll 4
+            for (int cl = 0; cl < 16; ++cl) {
+                const float* pl = pl0 + cl * T_PLANE;
+                const float4* wrow = reinterpret_cast<const float4*>(hw + (m * 16 + cl) * 36);
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const float a = pl[(tap / 3) * 18 + (tap % 3)];
+                    const float4 w = wrow[tap];
+                    h0 = fmaf(a, w.x, h0);
+                    h1 = fmaf(a, w.y, h1);
+                    h2 = fmaf(a, w.z, h2);
+                    h3 = fmaf(a, w.w, h3);
+                }
+            }
+        }
+        float* __restrict__ dst = part + ((size_t)n * tiles + tile) * 4 * 256 + tid;
+        dst[0 * 256] = h0;
+        dst[1 * 256] = h1;
+        dst[2 * 256] = h2;
+        dst[3 * 256] = h3;
+    }
+}
+
+// logits[n][ch][pos] = bias[ch] + sum over the tiles of ch's tower of part[n][tile][o][pos]
+// (tile order, fixed), ReLU on the four reg channels.  Ho == 16 only (MFMA path).
+__global__ void __launch_bounds__(256)
+heads_combine_kernel(const float* __restrict__ part, int tiles_per_tower, const float* __restrict__ cls_b,
+                     const float* __restrict__ center_b, const float* __restrict__ reg_b,
+                     float* __restrict__ logits) {
+    const int n = blockIdx.x;
+    const int pos = threadIdx.x;
+    const float* __restrict__ p = part + (size_t)n * 2 * tiles_per_tower * 4 * 256 + pos;
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) {
+        const int side = ch >= 3;
+        const int o = side ? ch - 3 : ch;
+        float s = 0.0f;
+        for (int t = 0; t < tiles_per_tower; ++t) s += p[((size_t)(side * tiles_per_tower + t) * 4 + o) * 256];
+        const float b = (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
+        s += b;
+        if (side) s = fmaxf(s, 0.0f);
+        logits[((size_t)n * 7 + ch) * 256 + pos] = s;
+    }
 }
 
 // Any Ho / C: one workgroup per (track, tower, GroupNorm group); direct convolution, outputs kept
@@ -405,22 +501,43 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
     T.gamma[1] = reg_gn_w;
     T.beta[1] = reg_gn_b;
     const int cpg = C / gn_groups;
-    const bool mfma_ok = (Ho == 16) && (C % T_OC == 0) && (C % T_IC == 0) && (cpg <= T_OC) && (T_OC % cpg == 0);
+    T.cls_w = cls_w;
+    T.center_w = center_w;
+    T.reg_w = reg_w;
+    const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && (cpg <= 16) && (16 % cpg == 0);
     if (mfma_ok) {
-        const size_t smem = (size_t)2 * T_BUF_FLOATS * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void*)tower_mfma_kernel,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
+        // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
+        const int blocks32 = N * 2 * (C / 32);
+        const bool narrow = blocks32 < 2 * 256;
+        const int mt = narrow ? 1 : 2;
+        const int tiles_per_tower = C / (16 * mt);
+        const size_t smem = (size_t)2 * (T_STEPS * mt * 64 + T_B_FLOATS) * sizeof(float);
+        static bool attr_set[3] = {false, false, false};
+        const void* fn = narrow ? (const void*)tower_mfma_kernel<1> : (const void*)tower_mfma_kernel<2>;
+        if (!attr_set[mt]) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) {
                 set_error("predictor: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return (int)e;
             }
-            attr_set = true;
+            attr_set[mt] = true;
         }
-        hipLaunchKernelGGL(tower_mfma_kernel, dim3(N * 2 * (C / T_OC)), dim3(256), smem, st, resp, T, C, cpg,
-                           gn_eps, tower_ws);
-    } else {
+        // tower_ws holds the per-tile partial head sums [N][2*tiles_per_tower][4][256] (<= N*2C*256 floats)
+        if (narrow) {
+            hipLaunchKernelGGL(tower_mfma_kernel<1>, dim3(N * 2 * tiles_per_tower), dim3(256), smem, st, resp, T, C,
+                               cpg, gn_eps, tower_ws);
+        } else {
+            hipLaunchKernelGGL(tower_mfma_kernel<2>, dim3(N * 2 * tiles_per_tower), dim3(256), smem, st, resp, T, C,
+                               cpg, gn_eps, tower_ws);
+        }
+        int rc = check_launch("predictor towers");
+        if (rc) return rc;
+        hipLaunchKernelGGL(heads_combine_kernel, dim3(N), dim3(256), 0, st, (const float*)tower_ws, tiles_per_tower,
+                           cls_b, center_b, reg_b, logits);
+        return check_launch("predictor heads combine");
+    }
+    {
         const size_t smem = (size_t)cpg * Ho * Ho * sizeof(float);
         SMOT_REQUIRE(smem <= 64 * 1024, "predictor: GroupNorm group too large for the generic tower kernel");
         hipLaunchKernelGGL(tower_generic_kernel, dim3(N * 2 * gn_groups), dim3(256), smem, st, resp, T, C, Ho, cpg,

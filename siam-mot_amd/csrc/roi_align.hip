@@ -9,8 +9,13 @@
 // sample bookkeeping of the legacy ROIAlign (validity, clamp, low/high cell, bilinear weights —
 // all channel-independent) is computed once per workgroup into LDS tables; cells that fall in
 // the virtual zero border get weight 0 and a safe index, so the inner loop is branch-free.
-// Lanes walk the flattened (ph,pw) bin index, so stores are fully coalesced and the gathers of
-// neighbouring lanes hit neighbouring cells of one feature row.
+// The bounding window of the cells a roi really touches (<= ~58x58 cells when the level matches
+// the box; found with two LDS atomics per table entry) is staged per channel into LDS with
+// coalesced row reads — every feature cell is fetched from HBM/L2 once instead of being gathered
+// 16x per output; co-resident workgroups (2-3 per CU) overlap one's staging with another's pooling.
+// Lanes walk the flattened (ph,pw) bin index (tables of one bin in registers, channels inner), so
+// stores are fully coalesced.  Windows that exceed the LDS budget
+// (degenerate aspect ratios) fall back to direct gathers from the map, same arithmetic.
 #include "smot_common.h"
 
 namespace smot {
@@ -66,14 +71,19 @@ __device__ __forceinline__ void axis_sample(float start, float bin, int G, int s
     *w_hi = hi_in ? fl : 0.0f;
 }
 
+constexpr int RA_WIN_FLOATS = 4096;   // LDS window budget per channel (16 KiB)
+constexpr int RA_CH = 4;              // channels per workgroup (windows staged together: 64 KiB)
+
 template <int G>
 __global__ void __launch_bounds__(256)
 roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
                         const float* __restrict__ level_boxes, int PH, int PW, int ch_per_block,
                         float* __restrict__ out, int32_t* __restrict__ levels_out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int wbound[4];              // ymin, ymax, xmin, xmax of the cells with non-zero weight
     const int ny = PH * G, nx = PW * G;
-    int* y_lo = reinterpret_cast<int*>(smem);
+    float* win = reinterpret_cast<float*>(smem);
+    int* y_lo = reinterpret_cast<int*>(win + RA_CH * RA_WIN_FLOATS);
     int* y_hi = y_lo + ny;
     float* wy_lo = reinterpret_cast<float*>(y_hi + ny);
     float* wy_hi = wy_lo + ny;
@@ -97,33 +107,86 @@ roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
     const float bin_h = div_rn(roi_h, (float)PH);
     const float bin_w = div_rn(roi_w, (float)PW);
 
+    if (threadIdx.x == 0) {
+        wbound[0] = 0x7fffffff;
+        wbound[1] = -1;
+        wbound[2] = 0x7fffffff;
+        wbound[3] = -1;
+    }
+    __syncthreads();
     for (int s = threadIdx.x; s < ny + nx; s += blockDim.x) {
+        int lo, hi;
+        float wl, wh;
         if (s < ny) {
-            int lo, hi;
-            float wl, wh;
             axis_sample(y1, bin_h, G, s, H, pad, &lo, &hi, &wl, &wh);
-            y_lo[s] = lo * W;
-            y_hi[s] = hi * W;
+            y_lo[s] = lo;
+            y_hi[s] = hi;
             wy_lo[s] = wl;
             wy_hi[s] = wh;
         } else {
             const int sx = s - ny;
-            int lo, hi;
-            float wl, wh;
             axis_sample(x1, bin_w, G, sx, W, pad, &lo, &hi, &wl, &wh);
             x_lo[sx] = lo;
             x_hi[sx] = hi;
             wx_lo[sx] = wl;
             wx_hi[sx] = wh;
         }
+        const int b = (s < ny) ? 0 : 2;
+        if (wl != 0.0f) {
+            atomicMin(&wbound[b], lo);
+            atomicMax(&wbound[b + 1], lo);
+        }
+        if (wh != 0.0f) {
+            atomicMin(&wbound[b], hi);
+            atomicMax(&wbound[b + 1], hi);
+        }
     }
     __syncthreads();
-
+    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
     const int c0 = blockIdx.y * ch_per_block;
     const int c1 = min(C, c0 + ch_per_block);
     const int bins = PH * PW;
     const float* __restrict__ f = P.feat[lvl];
-    for (int t = threadIdx.x; t < bins; t += blockDim.x) {
+    if (ymax < ymin || xmax < xmin) {
+        // every sample lies in the virtual zero border (or outside the padded map): exact zeros
+        for (int c = c0; c < c1; ++c)
+            for (int t = threadIdx.x; t < bins; t += blockDim.x) out[((size_t)r * C + c) * bins + t] = 0.0f;
+        return;
+    }
+    const int wh_ = ymax - ymin + 1, ww = xmax - xmin + 1;
+    const bool staged = (wh_ * ww <= RA_WIN_FLOATS);     // workgroup-uniform
+    // re-base the tables: window-relative when staged, map-relative row offsets otherwise
+    __syncthreads();
+    for (int s = threadIdx.x; s < ny + nx; s += blockDim.x) {
+        if (s < ny) {
+            const int lo = (wy_lo[s] != 0.0f) ? y_lo[s] : ymin;
+            const int hi = (wy_hi[s] != 0.0f) ? y_hi[s] : ymin;
+            y_lo[s] = staged ? (lo - ymin) * ww : lo * W;
+            y_hi[s] = staged ? (hi - ymin) * ww : hi * W;
+        } else {
+            const int sx = s - ny;
+            const int lo = (wx_lo[sx] != 0.0f) ? x_lo[sx] : xmin;
+            const int hi = (wx_hi[sx] != 0.0f) ? x_hi[sx] : xmin;
+            x_lo[sx] = staged ? lo - xmin : lo;
+            x_hi[sx] = staged ? hi - xmin : hi;
+        }
+    }
+    __syncthreads();
+
+    const int nch = c1 - c0;
+    if (staged) {
+        // ---- stage the (wh x ww) windows of all channels of this workgroup: contiguous row segments,
+        // coalesced; other resident workgroups cover the load latency ----
+        const int wcount = wh_ * ww;
+        for (int i = threadIdx.x; i < wcount; i += 256) {
+            const int row = i / ww;
+            const int g = (ymin + row) * W + xmin + (i - row * ww);
+            for (int cl = 0; cl < nch; ++cl) win[cl * RA_WIN_FLOATS + i] = f[(size_t)(c0 + cl) * H * W + g];
+        }
+        __syncthreads();
+    }
+    // bins outer (tables of one bin in registers), channels inner
+    for (int t = threadIdx.x; t < bins; t += 256) {
         const int ph = t / PW;
         const int pw = t - ph * PW;
         int ylo[G], yhi[G], xlo[G], xhi[G];
@@ -139,23 +202,25 @@ roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
             wxl[i] = wx_lo[pw * G + i];
             wxh[i] = wx_hi[pw * G + i];
         }
-        for (int c = c0; c < c1; ++c) {
-            const float* __restrict__ fc = f + (size_t)c * H * W;
+        for (int cl = 0; cl < nch; ++cl) {
+            // window larger than the LDS budget (degenerate aspect ratios): gather straight from the map
+            const float* __restrict__ src = staged ? (const float*)(win + cl * RA_WIN_FLOATS)
+                                                   : f + (size_t)(c0 + cl) * H * W;
             float acc = 0.0f;
 #pragma unroll
             for (int iy = 0; iy < G; ++iy) {
 #pragma unroll
                 for (int ix = 0; ix < G; ++ix) {
-                    const float v1 = fc[ylo[iy] + xlo[ix]];
-                    const float v2 = fc[ylo[iy] + xhi[ix]];
-                    const float v3 = fc[yhi[iy] + xlo[ix]];
-                    const float v4 = fc[yhi[iy] + xhi[ix]];
+                    const float v1 = src[ylo[iy] + xlo[ix]];
+                    const float v2 = src[ylo[iy] + xhi[ix]];
+                    const float v3 = src[yhi[iy] + xlo[ix]];
+                    const float v4 = src[yhi[iy] + xhi[ix]];
                     const float w1 = wyl[iy] * wxl[ix], w2 = wyl[iy] * wxh[ix];
                     const float w3 = wyh[iy] * wxl[ix], w4 = wyh[iy] * wxh[ix];
                     acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
                 }
             }
-            out[((size_t)r * C + c) * bins + t] = acc / (float)(G * G);
+            out[((size_t)r * C + c0 + cl) * bins + t] = acc / (float)(G * G);
         }
     }
 }
@@ -212,13 +277,27 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
     P.k_min = -log2f(scales[0]);
     P.k_max = -log2f(scales[num_levels - 1]);
 
-    const int ch_per_block = 4;
+    const int ch_per_block = RA_CH;
     dim3 grid(R, (C + ch_per_block - 1) / ch_per_block);
-    const size_t smem = (size_t)(out_h + out_w) * sampling_ratio * 16;
+    SMOT_REQUIRE(out_h * out_w <= 1024, "roi_align: out %dx%d too large (max 1024 bins)", out_h, out_w);
+    const size_t smem = (size_t)(out_h + out_w) * sampling_ratio * 16 + (size_t)RA_CH * RA_WIN_FLOATS * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(G)                                                                                       \
-    hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois, level_boxes, \
-                       out_h, out_w, ch_per_block, out, levels_out)
+#define LAUNCH(G)                                                                                        \
+    {                                                                                                    \
+        static bool attr_done = false;                                                                   \
+        if (!attr_done) { /* > 64 KiB of dynamic LDS needs the opt-in */                                 \
+            hipError_t e = hipFuncSetAttribute((const void*)roi_align_levels_kernel<G>,                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   \
+            if (e != hipSuccess) {                                                                       \
+                set_error("roi_align: hipFuncSetAttribute: %s", hipGetErrorString(e));                   \
+                return (int)e;                                                                           \
+            }                                                                                            \
+            attr_done = true;                                                                            \
+        }                                                                                                \
+        hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois, level_boxes, \
+                           out_h, out_w, ch_per_block, out, levels_out);                                 \
+    }
+    SMOT_REQUIRE(smem <= 96 * 1024, "roi_align: pooled size %dx%d needs too much LDS", out_h, out_w);
     switch (sampling_ratio) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -123,7 +123,9 @@ xcorr_dw_wave_kernel(const float* __restrict__ x, const float* __restrict__ z,
 //     ds_read_b128 touch 16 distinct 16-byte slots (conflict-free, derivation in DESIGN.md);
 //   * per output the taps are accumulated u-major / v-minor in one fp32 FMA chain: bit-identical to
 //     the wave-per-plane kernel and to the order of oracle/emm_oracle.py:xcorr_depthwise.
-template <int RX, int RZ>
+// MODE 0 = the kernel; 1 = staging + stores only (no FMAs); 2 = FMAs + stores only (no global loads):
+// ablation builds selected with SMOT_XCORR_VARIANT=fill|compute for phase timing (tools/kernel_bench.py).
+template <int RX, int RZ, int MODE>
 __global__ void __launch_bounds__(64)
 xcorr_dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ z,
                       float* __restrict__ out, int planes) {
@@ -142,36 +144,58 @@ xcorr_dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ z,
     const int lane = threadIdx.x;
     const int plane0 = blockIdx.x * 4;
 
-    // ---- stage 4 search planes + 4 templates (coalesced dword loads, conflict-free LDS stores) ----
-    constexpr int NX = (RX * RX + 63) / 64;     // 15
-    constexpr int NZ = (RZ * RZ + 63) / 64;     // 4
-    int xoff[NX], zoff[NZ];
+    // ---- stage 4 search planes + 4 templates ------------------------------------------------
+    // The 4 search planes of a set are contiguous in HBM (3600 floats = 900 float4, 16-B aligned):
+    // 15 x global_load_dwordx4 per lane; a float4 never straddles a plane (900 % 4 == 0) and splits
+    // into two aligned float2 that land in one or two LDS rows (30 % 2 == 0): 2 x ds_write_b64.
+    // Templates (225 floats per plane, odd) use dword loads.
+    constexpr int NX4 = (4 * RX * RX / 4 + 63) / 64;     // 15
+    constexpr int NZ = (RZ * RZ + 63) / 64;              // 4
+    if (MODE != 2) {
+        const long long last4 = (long long)planes * (RX * RX / 4) - 1;     // last valid float4 of x
+        const float4* __restrict__ xg4 = reinterpret_cast<const float4*>(x);
+        float4 sx[NX4];
 #pragma unroll
-    for (int t = 0; t < NX; ++t) {
-        const int e = min(lane + 64 * t, RX * RX - 1);
-        const int r = e / RX;
-        xoff[t] = r * XS + (e - r * RX);
-    }
+        for (int t = 0; t < NX4; ++t) {
+            const int k = lane + 64 * t;
+            long long gk = (long long)plane0 * (RX * RX / 4) + k;
+            gk = gk < last4 ? gk : last4;                  // tail sets re-read valid memory
+            sx[t] = xg4[gk];
+        }
+        int zoff[NZ];
 #pragma unroll
-    for (int t = 0; t < NZ; ++t) {
-        const int e = min(lane + 64 * t, RZ * RZ - 1);
-        const int u = e / RZ;
-        zoff[t] = u * ZS + (e - u * RZ);
-    }
+        for (int t = 0; t < NZ; ++t) {
+            const int e = min(lane + 64 * t, RZ * RZ - 1);
+            const int u = e / RZ;
+            zoff[t] = u * ZS + (e - u * RZ);
+        }
+        float sz[4][NZ];
 #pragma unroll
-    for (int pl = 0; pl < 4; ++pl) {
-        const int plane = min(plane0 + pl, planes - 1);      // tail sets re-read the last plane
-        const float* __restrict__ xg = x + (size_t)plane * (RX * RX);
-        const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
-        float sx[NX], sz[NZ];
+        for (int pl = 0; pl < 4; ++pl) {
+            const int plane = min(plane0 + pl, planes - 1);
+            const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
 #pragma unroll
-        for (int t = 0; t < NX; ++t) sx[t] = xg[min(lane + 64 * t, RX * RX - 1)];
+            for (int t = 0; t < NZ; ++t) sz[pl][t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+        }
 #pragma unroll
-        for (int t = 0; t < NZ; ++t) sz[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+        for (int t = 0; t < NX4; ++t) {
+            const int k = lane + 64 * t;
+            if (k < 4 * RX * RX / 4) {
+                const int e0 = 4 * k;
+                const int pl = e0 / (RX * RX);
+                const int el = e0 - pl * (RX * RX);
+                const int r = el / RX;
+                const int c0 = el - r * RX;
+                const int o0 = pl * XP + r * XS + c0;
+                const int o1 = (c0 + 2 < RX) ? o0 + 2 : o0 + XS - c0;      // (r, c0+2) or (r+1, 0)
+                *reinterpret_cast<float2*>(xs + o0) = make_float2(sx[t].x, sx[t].y);
+                *reinterpret_cast<float2*>(xs + o1) = make_float2(sx[t].z, sx[t].w);
+            }
+        }
 #pragma unroll
-        for (int t = 0; t < NX; ++t) xs[pl * XP + xoff[t]] = sx[t];
+        for (int pl = 0; pl < 4; ++pl)
 #pragma unroll
-        for (int t = 0; t < NZ; ++t) zs[pl * ZP + zoff[t]] = sz[t];
+            for (int t = 0; t < NZ; ++t) zs[pl * ZP + zoff[t]] = sz[pl][t];
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -224,7 +248,9 @@ xcorr_dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ z,
         if ((T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                              \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
             const int u = (T) - k;                                                          \
-            if (u >= 0 && u < RZ) {                                                         \
+            if (MODE == 1) {                                                                \
+                if (u >= 0 && u < RZ) acc[k][0] += CUR[k] + zr[u][k];                       \
+            } else if (u >= 0 && u < RZ) {                                                  \
                 _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
                     _Pragma("unroll") for (int j = 0; j < 4; ++j)                           \
                         acc[k][j] = fmaf(CUR[j + v], zr[u][v], acc[k][j]);                  \
@@ -296,14 +322,22 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
     const int planes = N * C;
     hipStream_t st = (hipStream_t)stream;
     if (Rx == 30 && Rz == 15) {
-        // SMOT_XCORR_VARIANT=wave selects the older wave-per-plane kernel (A/B measurements only)
+        // SMOT_XCORR_VARIANT = wave | fill | compute: A/B and phase-ablation builds (measurements only)
         const char* var = getenv("SMOT_XCORR_VARIANT");
         if (var != nullptr && var[0] == 'w') {
             hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), dim3((planes + 3) / 4), dim3(256), 0, st, x, z, out,
                                planes);
         } else {
-            hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z, out,
-                               planes);
+            if (var != nullptr && var[0] == 'f') {
+                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 1>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            } else if (var != nullptr && var[0] == 'c') {
+                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 2>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            } else {
+                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            }
         }
     } else {
         const size_t smem = (size_t)(Rx * Rx + Rz * Rz) * sizeof(float);
