@@ -203,6 +203,9 @@ def main():
         state = emm.extract_cache(feats[1], det)
         for k in range(args.warmup):
             state, _ = step(k, state)
+        # (start, end) event pairs are created BEFORE the timed region (hipEventCreate is slow)
+        ops.xcorr_event_pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                for _ in range(args.steps)]
         ops.xcorr_event_sink = []
         parallel.barrier()
         torch.cuda.synchronize()

@@ -99,15 +99,23 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         hwreg[j] = v;
     }
 
+    // A image element d = ((s*MT + m)*4 + kq)*16 + i  <->  W[oc0 + m*16 + i][ic0 + 4*(s%4) + kq][tap = s/4].
+    // Threads walk the DESTINATION index, so LDS stores are lane-linear (conflict-free); the global
+    // reads are 16 rows x 576-byte runs per chunk that the L1/L2 serve across the 9*MT passes.
     float pa[A_PER_THREAD], pb[T_B_PER_THREAD];
+    int asrc[A_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < A_PER_THREAD; ++j) {
+        const int d = tid + 256 * j;
+        const int i = d & 15, kq_ = (d >> 4) & 3;
+        const int sm_ = d >> 6;                 // s*MT + m
+        const int s = sm_ / MT, m = sm_ - s * MT;
+        const int tap = s >> 2, icl = 4 * (s & 3) + kq_;
+        asrc[j] = ((oc0 + m * 16 + i) * C + icl) * 9 + tap;
+    }
     auto load_chunk = [&](int ic0) {
 #pragma unroll
-        for (int j = 0; j < A_PER_THREAD; ++j) {
-            const int idx = tid + 256 * j;          // over [T_OC][16 ic * 9]
-            const int oc = idx / (T_IC * 9);
-            const int rem = idx - oc * (T_IC * 9);
-            pa[j] = W[((size_t)(oc0 + oc) * C + ic0) * 9 + rem];
-        }
+        for (int j = 0; j < A_PER_THREAD; ++j) pa[j] = W[asrc[j] + ic0 * 9];
 #pragma unroll
         for (int j = 0; j < T_B_PER_THREAD; ++j) pb[j] = in[(size_t)(ic0 + j) * 256 + tid];
     };
@@ -115,15 +123,7 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         float* A = buf;
         float* B = buf + A_FLOATS;
 #pragma unroll
-        for (int j = 0; j < A_PER_THREAD; ++j) {
-            const int idx = tid + 256 * j;
-            const int oc = idx / (T_IC * 9);
-            const int rem = idx - oc * (T_IC * 9);
-            const int ic = rem / 9;
-            const int tap = rem - ic * 9;
-            const int s = tap * (T_IC / 4) + (ic >> 2);
-            A[((s * MT + (oc >> 4)) * 4 + (ic & 3)) * 16 + (oc & 15)] = pa[j];
-        }
+        for (int j = 0; j < A_PER_THREAD; ++j) A[tid + 256 * j] = pa[j];
         const int y = tid >> 4, x = tid & 15;
 #pragma unroll
         for (int j = 0; j < T_B_PER_THREAD; ++j) B[j * T_PLANE + (y + 1) * 18 + (x + 1)] = pb[j];
@@ -285,25 +285,27 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
 }
 
 // logits[n][ch][pos] = bias[ch] + sum over the tiles of ch's tower of part[n][tile][o][pos]
-// (tile order, fixed), ReLU on the four reg channels.  Ho == 16 only (MFMA path).
+// (tile order, fixed), ReLU on the four reg channels.  Ho == 16 only (MFMA path).  grid (N, 7).
+template <int TPT>
 __global__ void __launch_bounds__(256)
-heads_combine_kernel(const float* __restrict__ part, int tiles_per_tower, const float* __restrict__ cls_b,
+heads_combine_kernel(const float* __restrict__ part, const float* __restrict__ cls_b,
                      const float* __restrict__ center_b, const float* __restrict__ reg_b,
                      float* __restrict__ logits) {
     const int n = blockIdx.x;
+    const int ch = blockIdx.y;
     const int pos = threadIdx.x;
-    const float* __restrict__ p = part + (size_t)n * 2 * tiles_per_tower * 4 * 256 + pos;
+    const int side = ch >= 3;
+    const int o = side ? ch - 3 : ch;
+    const float* __restrict__ p = part + ((size_t)n * 2 * TPT + side * TPT) * 4 * 256 + (size_t)o * 256 + pos;
+    float v[TPT];
 #pragma unroll
-    for (int ch = 0; ch < 7; ++ch) {
-        const int side = ch >= 3;
-        const int o = side ? ch - 3 : ch;
-        float s = 0.0f;
-        for (int t = 0; t < tiles_per_tower; ++t) s += p[((size_t)(side * tiles_per_tower + t) * 4 + o) * 256];
-        const float b = (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
-        s += b;
-        if (side) s = fmaxf(s, 0.0f);
-        logits[((size_t)n * 7 + ch) * 256 + pos] = s;
-    }
+    for (int t = 0; t < TPT; ++t) v[t] = p[(size_t)t * 4 * 256];      // all loads in flight at once
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TPT; ++t) s += v[t];
+    s += (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
+    if (side) s = fmaxf(s, 0.0f);
+    logits[((size_t)n * 7 + ch) * 256 + pos] = s;
 }
 
 // Any Ho / C: one workgroup per (track, tower, GroupNorm group); direct convolution, outputs kept
@@ -504,7 +506,8 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
     T.cls_w = cls_w;
     T.center_w = center_w;
     T.reg_w = reg_w;
-    const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && (cpg <= 16) && (16 % cpg == 0);
+    const bool pow2 = (C & (C - 1)) == 0;      // tile counts 1,2,4,...: what heads_combine is built for
+    const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && pow2 && (C <= 512) && (cpg <= 16) && (16 % cpg == 0);
     if (mfma_ok) {
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
@@ -533,8 +536,21 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
         }
         int rc = check_launch("predictor towers");
         if (rc) return rc;
-        hipLaunchKernelGGL(heads_combine_kernel, dim3(N), dim3(256), 0, st, (const float*)tower_ws, tiles_per_tower,
-                           cls_b, center_b, reg_b, logits);
+#define SMOT_COMBINE(TPT)                                                                                \
+    hipLaunchKernelGGL(heads_combine_kernel<TPT>, dim3(N, 7), dim3(256), 0, st, (const float*)tower_ws, cls_b, \
+                       center_b, reg_b, logits)
+        switch (tiles_per_tower) {
+            case 1: SMOT_COMBINE(1); break;
+            case 2: SMOT_COMBINE(2); break;
+            case 4: SMOT_COMBINE(4); break;
+            case 8: SMOT_COMBINE(8); break;
+            case 16: SMOT_COMBINE(16); break;
+            case 32: SMOT_COMBINE(32); break;
+            default:
+                set_error("predictor: unsupported tile count %d (C=%d)", tiles_per_tower, C);
+                return SMOT_ERR_UNSUPPORTED;
+        }
+#undef SMOT_COMBINE
         return check_launch("predictor heads combine");
     }
     {

@@ -175,13 +175,33 @@ roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
 
     const int nch = c1 - c0;
     if (staged) {
-        // ---- stage the (wh x ww) windows of all channels of this workgroup: contiguous row segments,
-        // coalesced; other resident workgroups cover the load latency ----
-        const int wcount = wh_ * ww;
-        for (int i = threadIdx.x; i < wcount; i += 256) {
-            const int row = i / ww;
-            const int g = (ymin + row) * W + xmin + (i - row * ww);
-            for (int cl = 0; cl < nch; ++cl) win[cl * RA_WIN_FLOATS + i] = f[(size_t)(c0 + cl) * H * W + g];
+        // ---- stage the (wh x ww) windows of all channels of this workgroup.  Wave w takes rows
+        // w, w+4, ...; lanes take columns (contiguous, coalesced row segments).  All loads of a pass
+        // (up to 16 rows x RA_CH channels per lane) are issued before the first LDS store, so one
+        // memory round trip covers the whole pass; co-resident workgroups cover the rest. ----
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        for (int col0 = 0; col0 < ww; col0 += 64) {
+            const int col = col0 + tx;
+            for (int row0 = 0; row0 < wh_; row0 += 64) {
+                float tmp[RA_CH][16];
+#pragma unroll
+                for (int cl = 0; cl < RA_CH; ++cl) {
+                    const float* __restrict__ fc = f + (size_t)(c0 + min(cl, nch - 1)) * H * W;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int row = row0 + ty + 4 * k;
+                        tmp[cl][k] = (row < wh_ && col < ww) ? fc[(ymin + row) * W + xmin + col] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int cl = 0; cl < RA_CH; ++cl) {
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int row = row0 + ty + 4 * k;
+                        if (row < wh_ && col < ww) win[cl * RA_WIN_FLOATS + row * ww + col] = tmp[cl][k];
+                    }
+                }
+            }
         }
         __syncthreads();
     }
@@ -279,7 +299,6 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
 
     const int ch_per_block = RA_CH;
     dim3 grid(R, (C + ch_per_block - 1) / ch_per_block);
-    SMOT_REQUIRE(out_h * out_w <= 1024, "roi_align: out %dx%d too large (max 1024 bins)", out_h, out_w);
     const size_t smem = (size_t)(out_h + out_w) * sampling_ratio * 16 + (size_t)RA_CH * RA_WIN_FLOATS * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(G)                                                                                        \

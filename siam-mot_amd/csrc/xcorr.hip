@@ -287,6 +287,189 @@ xcorr_dw_patch_kernel(const float* __restrict__ x, const float* __restrict__ z,
     }
 }
 
+// Packed kernel (default fast path, Ho == 16): the patch decomposition above on v_pk_fma_f32.
+// gfx950 retires fp32 FMAs at full rate only as packed pairs (measured here: the plain-FMA patch
+// kernel needs ~3.6 SIMD cycles per wave64 v_fmac; v_pk_fma_f32 does two FMAs per lane in the same
+// slot).  A lane still owns a 4x4 patch, but its accumulators are the row pairs (0,2) and (1,3):
+//     A0[j] = (out[4q+0][j], out[4q+2][j])      A1[j] = (out[4q+1][j], out[4q+3][j])
+// At window row t both halves of A0 consume the SAME search value w[j+v] (broadcast through op_sel)
+// and the tap pair ZZ[t][v] = (z[t][v], z[t-2][v]); A1 uses ZZ[t-1].  The template is therefore kept
+// in LDS as 17 rows of such pairs (rows -2,-1,15,16 of z are zero), built while staging: every tap
+// is written twice.  Per output the taps are still added u-major / v-minor in one fp32 FMA chain, so
+// results are bit-identical to the other kernels and to the oracle's order.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int RX, int RZ, int MODE>
+__global__ void __launch_bounds__(64)
+xcorr_dw_pk_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                   float* __restrict__ out, int planes) {
+    constexpr int HO = RX - RZ + 1;
+    static_assert(HO == 16 && RZ == 15, "packed kernel is specialised for the 30/15/16 geometry");
+    constexpr int XS = 36;                  // search-plane row stride (floats)
+    constexpr int XP = 1088;                // search-plane stride
+    constexpr int ZR = RZ + 2;              // 17 rows of tap pairs
+    constexpr int ZRS = 32;                 // floats per pair row (16 pairs, 15 used)
+    constexpr int ZPP = ZR * ZRS + 16;      // 560: staggers the four planes over distinct 16-B slots
+    __shared__ __attribute__((aligned(16))) float sm[4 * XP + 4 * ZPP];
+    float* xs = sm;
+    float* zz = sm + 4 * XP;
+
+    const int lane = threadIdx.x;
+    const int plane0 = blockIdx.x * 4;
+
+    // ---- staging --------------------------------------------------------------------------
+    constexpr int NX4 = (RX * RX + 63) / 64;             // 15 float4 per lane cover 4 planes
+    constexpr int NZ = (RZ * RZ + 63) / 64;              // 4 dwords per lane per plane
+    if (MODE != 2) {
+        const long long last4 = (long long)planes * (RX * RX / 4) - 1;
+        const float4* __restrict__ xg4 = reinterpret_cast<const float4*>(x);
+        float4 sx[NX4];
+#pragma unroll
+        for (int t = 0; t < NX4; ++t) {
+            long long gk = (long long)plane0 * (RX * RX / 4) + lane + 64 * t;
+            gk = gk < last4 ? gk : last4;
+            sx[t] = xg4[gk];
+        }
+        float sz[4][NZ];
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) {
+            const int plane = min(plane0 + pl, planes - 1);
+            const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
+#pragma unroll
+            for (int t = 0; t < NZ; ++t) sz[pl][t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+        }
+        // zero the pair image (rows/halves that have no tap stay zero)
+        for (int e = lane; e < 4 * ZPP / 4; e += 64)
+            reinterpret_cast<float4*>(zz)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < NX4; ++t) {
+            const int k = lane + 64 * t;
+            if (k < RX * RX) {
+                const int e0 = 4 * k;
+                const int pl = e0 / (RX * RX);
+                const int el = e0 - pl * (RX * RX);
+                const int r = el / RX;
+                const int c0 = el - r * RX;
+                const int o0 = pl * XP + r * XS + c0;
+                const int o1 = (c0 + 2 < RX) ? o0 + 2 : o0 + XS - c0;
+                *reinterpret_cast<float2*>(xs + o0) = make_float2(sx[t].x, sx[t].y);
+                *reinterpret_cast<float2*>(xs + o1) = make_float2(sx[t].z, sx[t].w);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int e = lane + 64 * t;
+            if (e < RZ * RZ) {
+                const int u = e / RZ;
+                const int v = e - u * RZ;
+#pragma unroll
+                for (int pl = 0; pl < 4; ++pl) {
+                    zz[pl * ZPP + u * ZRS + 2 * v] = sz[pl][t];                 // .x of row u
+                    zz[pl * ZPP + (u + 2) * ZRS + 2 * v + 1] = sz[pl][t];       // .y of row u+2
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int p = lane >> 4, q = (lane >> 2) & 3, g = lane & 3;
+    const float* xrow = xs + p * XP + (4 * q) * XS + 4 * g;
+    const float* zrow = zz + p * ZPP;
+    v2f a0[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a0[j] = (v2f){0.f, 0.f};
+        a1[j] = (v2f){0.f, 0.f};
+    }
+    float wa[20], wb[20];
+    v2f za[16], zb[16], zc[16];       // three pair rows rotate: (cur, prev, next)
+#define SMOT_LOAD_X(T, DST)                                                                 \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                     \
+            const float4 v4 = *reinterpret_cast<const float4*>(xrow + (T) * XS + 4 * m);    \
+            DST[4 * m + 0] = v4.x;                                                          \
+            DST[4 * m + 1] = v4.y;                                                          \
+            DST[4 * m + 2] = v4.z;                                                          \
+            DST[4 * m + 3] = v4.w;                                                          \
+        }                                                                                   \
+        const float2 v2 = *reinterpret_cast<const float2*>(xrow + (T) * XS + 16);           \
+        DST[16] = v2.x;                                                                     \
+        DST[17] = v2.y;                                                                     \
+    }
+#define SMOT_LOAD_ZZ(U, DST)                                                                \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 8; ++m) {                                     \
+            const float4 v4 = *reinterpret_cast<const float4*>(zrow + (U) * ZRS + 4 * m);   \
+            DST[2 * m] = (v2f){v4.x, v4.y};                                                 \
+            DST[2 * m + 1] = (v2f){v4.z, v4.w};                                             \
+        }                                                                                   \
+    }
+#define SMOT_PIN_ACC()                                                                      \
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]),                   \
+                      "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]));
+    // step T: window row CUR (prefetch NXT); A0 uses pair row ZT = ZZ[T], A1 uses ZP = ZZ[T-1];
+    // ZN receives ZZ[T+1]
+#define SMOT_STEP(T, CUR, NXT, ZT, ZP, ZN)                                                  \
+    {                                                                                       \
+        if ((T) + 1 < RZ + 3) SMOT_LOAD_X((T) + 1, NXT)                                     \
+        if ((T) + 1 < ZR) SMOT_LOAD_ZZ((T) + 1, ZN)                                         \
+        if (MODE == 1) {                                                                    \
+            a0[0] += (v2f){CUR[0], CUR[17]} + ZT[0] + ZP[14];                               \
+        } else {                                                                            \
+            if ((T) < ZR) {                                                                 \
+                _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                           \
+                        a0[j] = __builtin_elementwise_fma((v2f){CUR[j + v], CUR[j + v]}, ZT[v], a0[j]); \
+                }                                                                           \
+            }                                                                               \
+            if ((T) >= 1) {                                                                 \
+                _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                           \
+                        a1[j] = __builtin_elementwise_fma((v2f){CUR[j + v], CUR[j + v]}, ZP[v], a1[j]); \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        SMOT_PIN_ACC()                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    SMOT_LOAD_X(0, wa)
+    SMOT_LOAD_ZZ(0, za)
+    __builtin_amdgcn_sched_barrier(0);
+    // 18 steps; window registers alternate (wa, wb); pair rows rotate with period 3
+    SMOT_STEP(0, wa, wb, za, zc, zb)
+    SMOT_STEP(1, wb, wa, zb, za, zc)
+    SMOT_STEP(2, wa, wb, zc, zb, za)
+    SMOT_STEP(3, wb, wa, za, zc, zb)
+    SMOT_STEP(4, wa, wb, zb, za, zc)
+    SMOT_STEP(5, wb, wa, zc, zb, za)
+    SMOT_STEP(6, wa, wb, za, zc, zb)
+    SMOT_STEP(7, wb, wa, zb, za, zc)
+    SMOT_STEP(8, wa, wb, zc, zb, za)
+    SMOT_STEP(9, wb, wa, za, zc, zb)
+    SMOT_STEP(10, wa, wb, zb, za, zc)
+    SMOT_STEP(11, wb, wa, zc, zb, za)
+    SMOT_STEP(12, wa, wb, za, zc, zb)
+    SMOT_STEP(13, wb, wa, zb, za, zc)
+    SMOT_STEP(14, wa, wb, zc, zb, za)
+    SMOT_STEP(15, wb, wa, za, zc, zb)
+    SMOT_STEP(16, wa, wb, zb, za, zc)
+    SMOT_STEP(17, wb, wa, zc, zb, za)
+#undef SMOT_STEP
+#undef SMOT_PIN_ACC
+#undef SMOT_LOAD_ZZ
+#undef SMOT_LOAD_X
+
+    const int plane = plane0 + p;
+    if (plane < planes) {
+        float* o = out + (size_t)plane * (HO * HO) + (4 * q) * HO + 4 * g;
+        *reinterpret_cast<float4*>(o + 0 * HO) = make_float4(a0[0].x, a0[1].x, a0[2].x, a0[3].x);
+        *reinterpret_cast<float4*>(o + 1 * HO) = make_float4(a1[0].x, a1[1].x, a1[2].x, a1[3].x);
+        *reinterpret_cast<float4*>(o + 2 * HO) = make_float4(a0[0].y, a0[1].y, a0[2].y, a0[3].y);
+        *reinterpret_cast<float4*>(o + 3 * HO) = make_float4(a1[0].y, a1[1].y, a1[2].y, a1[3].y);
+    }
+}
+
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.
 __global__ void __launch_bounds__(256)
 xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -322,7 +505,8 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
     const int planes = N * C;
     hipStream_t st = (hipStream_t)stream;
     if (Rx == 30 && Rz == 15) {
-        // SMOT_XCORR_VARIANT = wave | fill | compute: A/B and phase-ablation builds (measurements only)
+        // SMOT_XCORR_VARIANT = wave | patch | fill | compute (patch kernel phases) | Fill | Compute (packed
+        // kernel phases): A/B and phase-ablation builds, measurements only; default = packed kernel
         const char* var = getenv("SMOT_XCORR_VARIANT");
         if (var != nullptr && var[0] == 'w') {
             hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), dim3((planes + 3) / 4), dim3(256), 0, st, x, z, out,
@@ -334,8 +518,17 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
             } else if (var != nullptr && var[0] == 'c') {
                 hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 2>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
                                    out, planes);
-            } else {
+            } else if (var != nullptr && var[0] == 'p' && var[1] == 'a') {
                 hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            } else if (var != nullptr && var[0] == 'F') {
+                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 1>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            } else if (var != nullptr && var[0] == 'C') {
+                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 2>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
+                                   out, planes);
+            } else {
+                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 0>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
                                    out, planes);
             }
         }

@@ -23,6 +23,7 @@ UP_SCALE = 16          # reference track_core.py:69-73
 # bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs recorded on the launch
 # stream around every xcorr launch (roofline.achieved); None = no instrumentation.
 xcorr_event_sink = None
+xcorr_event_pool = None      # optional pre-created event pairs (event creation is slow)
 
 _lib = None
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -152,8 +153,11 @@ def xcorr_depthwise(x, kernel):
     out = torch.empty((N, C, Rx - Rz + 1, Rx - Rz + 1), dtype=torch.float32, device=x.device)
     sink = xcorr_event_sink
     if sink is not None:
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
+        if xcorr_event_pool:
+            e0, e1 = xcorr_event_pool.pop()
+        else:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
     rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, _stream())
     if sink is not None:

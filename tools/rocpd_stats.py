@@ -10,13 +10,14 @@ import argparse
 import sqlite3
 
 
-def kernel_stats(db, skip=0):
+def kernel_stats(db, skip=0, by_grid=False):
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, lds_size, vgpr_count, "
                        "accum_vgpr_count, sgpr_count from kernels order by start").fetchall()
     per = {}
     for r in rows:
-        per.setdefault(r[0], []).append(r)
+        key = r[0] if not by_grid else "%s  [grid %dx%dx%d]" % (r[0], r[3], r[4], r[5])
+        per.setdefault(key, []).append(r)
     out = []
     for name, rs in per.items():
         rs = rs[skip:] if len(rs) > skip else rs
@@ -37,7 +38,7 @@ def to_markdown(stats, title):
              "|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in stats:
         lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %.1f | %s | %d | %d | %d | %d | %d |" % (
-            r["name"][:110], r["calls"], r["avg_us"], r["min_us"], r["max_us"], r["pct"],
+            r["name"][:150], r["calls"], r["avg_us"], r["min_us"], r["max_us"], r["pct"],
             "x".join(str(g) for g in r["grid"]), r["wg"], r["lds"], r["vgpr"], r["agpr"], r["sgpr"]))
     return "\n".join(lines) + "\n"
 
@@ -48,8 +49,9 @@ if __name__ == "__main__":
     ap.add_argument("--md")
     ap.add_argument("--skip", type=int, default=0)
     ap.add_argument("--title", default=None)
+    ap.add_argument("--by-grid", action="store_true", help="separate rows per launch grid (problem size)")
     a = ap.parse_args()
-    st = kernel_stats(a.db, a.skip)
+    st = kernel_stats(a.db, a.skip, a.by_grid)
     md = to_markdown(st, a.title or ("rocprofv3 --kernel-trace --stats summary of %s" % a.db))
     if a.md:
         open(a.md, "w").write(md)
