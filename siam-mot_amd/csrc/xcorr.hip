@@ -470,6 +470,154 @@ xcorr_dw_pk_kernel(const float* __restrict__ x, const float* __restrict__ z,
     }
 }
 
+// Two-planes-per-wave patch kernel (DEFAULT fast path, Ho == 16).
+// Measured on MI355X (tools/ubench/fma_rate.hip): one wave per SIMD issues a v_fmac_f32 only every
+// ~5.6 cycles, two or more waves reach ~2.8-3.0; an SGPR multiplicand costs ~4.3 cycles whatever the
+// occupancy; v_pk_fma_f32 is ~5 cycles (+13 % FLOPs at best).  So the FMA stream wants plain
+// VGPR-operand v_fmac and >= 2 waves per SIMD even at 30 tracks (3840 planes): a wave takes TWO
+// planes (1920 waves, ~2 per SIMD), 32 lanes each; lane (q, g) owns the 4x2 output patch rows
+// 4q..4q+3, cols 2g..2g+1.  Everything else is the four-plane patch kernel: window row 4q+t is
+// read once (8 x ds_read_b64, 8-byte aligned, conflict-free at row stride 36) and feeds up to four
+// (output row k, template row t-k) pairs; template rows come from LDS as broadcast ds_read_b128 and
+// live in VGPRs; reads of step t+1 are issued before the FMAs of step t; same FMA order per output.
+template <int RX, int RZ, int MODE>
+__global__ void __launch_bounds__(64, 4)       // <= 128 VGPRs: four waves per SIMD
+xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
+                       float* __restrict__ out, int planes) {
+    constexpr int HO = RX - RZ + 1;
+    static_assert(HO == 16, "patch kernel tiles a 16x16 response");
+    constexpr int XS = 36;                  // row stride: 4*XS mod 64 == 16 -> the four q land on disjoint banks
+    constexpr int XP = 1088;
+    constexpr int ZS = 16;
+    constexpr int ZP = RZ * ZS;
+    constexpr int WIN = RZ + 1;             // 16 floats of a window row feed a 2-wide patch
+    static_assert(RX * XS <= XP && 2 * 7 + WIN <= XS && RZ <= ZS, "LDS image too small");
+    __shared__ __attribute__((aligned(16))) float sm[2 * XP + 2 * ZP];
+    float* xs = sm;
+    float* zs = sm + 2 * XP;
+
+    const int lane = threadIdx.x;
+    const int plane0 = blockIdx.x * 2;
+
+    constexpr int NX4 = (2 * RX * RX / 4 + 63) / 64;     // 8 float4 per lane cover 2 planes
+    constexpr int NZ = (2 * RZ * RZ + 63) / 64;          // 8 dwords per lane cover 2 templates
+    if (MODE != 2) {
+        const long long last4 = (long long)planes * (RX * RX / 4) - 1;
+        const float4* __restrict__ xg4 = reinterpret_cast<const float4*>(x);
+        float4 sx[NX4];
+#pragma unroll
+        for (int t = 0; t < NX4; ++t) {
+            long long gk = (long long)plane0 * (RX * RX / 4) + lane + 64 * t;
+            gk = gk < last4 ? gk : last4;                  // odd plane counts: re-read valid memory
+            sx[t] = xg4[gk];
+        }
+        const long long lastz = (long long)planes * (RZ * RZ) - 1;
+        float sz[NZ];
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            long long ge = (long long)plane0 * (RZ * RZ) + lane + 64 * t;
+            ge = ge < lastz ? ge : lastz;
+            sz[t] = z[ge];
+        }
+#pragma unroll
+        for (int t = 0; t < NX4; ++t) {
+            const int k = lane + 64 * t;
+            if (k < 2 * RX * RX / 4) {
+                const int e0 = 4 * k;
+                const int pl = e0 / (RX * RX);
+                const int el = e0 - pl * (RX * RX);
+                const int r = el / RX;
+                const int c0 = el - r * RX;
+                const int o0 = pl * XP + r * XS + c0;
+                const int o1 = (c0 + 2 < RX) ? o0 + 2 : o0 + XS - c0;
+                *reinterpret_cast<float2*>(xs + o0) = make_float2(sx[t].x, sx[t].y);
+                *reinterpret_cast<float2*>(xs + o1) = make_float2(sx[t].z, sx[t].w);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 2 * RZ * RZ) {
+                const int pl = e / (RZ * RZ);
+                const int el = e - pl * (RZ * RZ);
+                const int u = el / RZ;
+                zs[pl * ZP + u * ZS + (el - u * RZ)] = sz[t];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int p = lane >> 5, q = (lane >> 3) & 3, g = lane & 7;
+    const float* xrow = xs + p * XP + (4 * q) * XS + 2 * g;
+    const float* zrow = zs + p * ZP;
+    float acc[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = 0.0f;
+    float zr[RZ][RZ];
+    float wa[WIN], wb[WIN];
+#define SMOT_LOAD_X(T, DST)                                                                 \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < WIN / 2; ++m) {                               \
+            const float2 v2 = *reinterpret_cast<const float2*>(xrow + (T) * XS + 2 * m);    \
+            DST[2 * m + 0] = v2.x;                                                          \
+            DST[2 * m + 1] = v2.y;                                                          \
+        }                                                                                   \
+    }
+#define SMOT_LOAD_Z(T)                                                                      \
+    {                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                     \
+            const float4 v4 = *reinterpret_cast<const float4*>(zrow + (T) * ZS + 4 * m);    \
+            zr[T][4 * m + 0] = v4.x;                                                        \
+            zr[T][4 * m + 1] = v4.y;                                                        \
+            zr[T][4 * m + 2] = v4.z;                                                        \
+            zr[T][4 * m + 3] = v4.w;                                                        \
+        }                                                                                   \
+        zr[T][12] = zrow[(T) * ZS + 12];                                                    \
+        zr[T][13] = zrow[(T) * ZS + 13];                                                    \
+        zr[T][14] = zrow[(T) * ZS + 14];                                                    \
+    }
+#define SMOT_PIN_ACC()                                                                      \
+    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),   \
+                      "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
+#define SMOT_STEP(T, CUR, NXT)                                                              \
+    {                                                                                       \
+        if ((T) + 1 < RZ + 3) SMOT_LOAD_X((T) + 1, NXT)                                     \
+        if ((T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                              \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
+            const int u = (T) - k;                                                          \
+            if (MODE == 1) {                                                                \
+                if (u >= 0 && u < RZ) acc[k][0] += CUR[k] + zr[u][k];                       \
+            } else if (u >= 0 && u < RZ) {                                                  \
+                _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
+                    acc[k][0] = fmaf(CUR[v], zr[u][v], acc[k][0]);                          \
+                    acc[k][1] = fmaf(CUR[v + 1], zr[u][v], acc[k][1]);                      \
+                }                                                                           \
+            }                                                                               \
+        }                                                                                   \
+        SMOT_PIN_ACC()                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+    }
+    SMOT_LOAD_X(0, wa)
+    SMOT_LOAD_Z(0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t2 = 0; t2 < RZ + 3; t2 += 2) {
+        SMOT_STEP(t2, wa, wb)
+        if (t2 + 1 < RZ + 3) SMOT_STEP(t2 + 1, wb, wa)
+    }
+#undef SMOT_STEP
+#undef SMOT_PIN_ACC
+#undef SMOT_LOAD_Z
+#undef SMOT_LOAD_X
+
+    const int plane = plane0 + p;
+    if (plane < planes) {
+        float* o = out + (size_t)plane * (HO * HO) + (4 * q) * HO + 2 * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(o + k * HO) = make_float2(acc[k][0], acc[k][1]);
+    }
+}
+
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.
 __global__ void __launch_bounds__(256)
 xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -505,32 +653,23 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
     const int planes = N * C;
     hipStream_t st = (hipStream_t)stream;
     if (Rx == 30 && Rz == 15) {
-        // SMOT_XCORR_VARIANT = wave | patch | fill | compute (patch kernel phases) | Fill | Compute (packed
-        // kernel phases): A/B and phase-ablation builds, measurements only; default = packed kernel
+        // SMOT_XCORR_VARIANT = wave | patch | pk (older kernels, A/B) | fill | compute (phase ablations of
+        // the default two-planes-per-wave kernel): measurements only
         const char* var = getenv("SMOT_XCORR_VARIANT");
-        if (var != nullptr && var[0] == 'w') {
-            hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), dim3((planes + 3) / 4), dim3(256), 0, st, x, z, out,
-                               planes);
+        const char v0 = var ? var[0] : 0, v1 = var ? var[1] : 0;
+        const dim3 g4((planes + 3) / 4), g2((planes + 1) / 2), b64(64);
+        if (v0 == 'w') {
+            hipLaunchKernelGGL((xcorr_dw_wave_kernel<30, 15>), g4, dim3(256), 0, st, x, z, out, planes);
+        } else if (v0 == 'p' && v1 == 'a') {        // "patch": four planes per wave, plain FMA
+            hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
+        } else if (v0 == 'p' && v1 == 'k') {        // "pk": four planes per wave, packed FMA
+            hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
+        } else if (v0 == 'f') {                     // "fill": default kernel without FMAs
+            hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 1>), g2, b64, 0, st, x, z, out, planes);
+        } else if (v0 == 'c') {                     // "compute": default kernel without global loads
+            hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 2>), g2, b64, 0, st, x, z, out, planes);
         } else {
-            if (var != nullptr && var[0] == 'f') {
-                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 1>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            } else if (var != nullptr && var[0] == 'c') {
-                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 2>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            } else if (var != nullptr && var[0] == 'p' && var[1] == 'a') {
-                hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            } else if (var != nullptr && var[0] == 'F') {
-                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 1>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            } else if (var != nullptr && var[0] == 'C') {
-                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 2>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            } else {
-                hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 0>), dim3((planes + 3) / 4), dim3(64), 0, st, x, z,
-                                   out, planes);
-            }
+            hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 0>), g2, b64, 0, st, x, z, out, planes);
         }
     } else {
         const size_t smem = (size_t)(Rx * Rx + Rz * Rz) * sizeof(float);
