@@ -149,6 +149,50 @@ int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes
 /* fp32 elements of decode workspace needed PER TRACK. */
 int smot_emm_decode_ws_floats(int Ho, int up);
 
+/*
+ * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd launch —
+ * direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
+ * stream (events are created in _begin, outside any timed region; at most max_launches pairs).
+ * _end synchronises them and returns the summed kernel spans and the number of launches timed.
+ * Not thread-safe; one timing session at a time.
+ */
+int smot_xcorr_timer_begin(int max_launches);
+int smot_xcorr_timer_end(double* total_ms, int* launches);
+
+/*
+ * One-call halves of a frame pair (same kernels, one FFI crossing each).
+ *
+ * smot_emm_track_fwd replaces the inference branch of EMM.forward (EMM/track_core.py:28-79):
+ *   pad_feature (virtual) + SRPooler on the search regions -> xcorr_depthwise -> EMMPredictor ->
+ *   bicubic x`up` + get_locations + decode_response -> clip of wrap_results_to_boxlist.
+ *   boxes     [N,4] template boxes (pick the FPN level, scale penalty), sr [N,4] search regions
+ *   templates [N,C,rz,rz] (track memory), predictor_params: HOST array of the 12 device pointers in
+ *   the order cls_tower.0.weight, cls_tower.1.weight, cls_tower.1.bias, reg_tower.0.weight,
+ *   reg_tower.1.weight, reg_tower.1.bias, cls.weight, cls.bias, center.weight, center.bias,
+ *   reg.weight, reg.bias.   ws: smot_emm_track_ws_floats(N,C,rx,rz) floats, 16-byte aligned.
+ *   Remaining arguments as in the per-operator calls above.
+ *
+ * smot_emm_extract_cache_fwd replaces EMM.extract_cache (EMM/track_core.py:81-98): template pooling
+ *   on the un-padded maps (boxes pick level and roi) + search regions for the next frame.
+ */
+long long smot_emm_track_ws_floats(int N, int C, int rx, int rz);
+
+int smot_emm_track_fwd(const float* const* feats, const int* heights, const int* widths,
+                       const int* pad_cells, const float* scales, int num_levels, int C,
+                       const float* boxes, const float* sr, const float* templates, int N,
+                       int rx, int rz, int sampling_ratio,
+                       const float* const* predictor_params, int gn_groups, float gn_eps,
+                       const float* hann, int up, float pad_pixels,
+                       float one_minus_sigma, float sigma, int use_centerness,
+                       float clip_w, float clip_h,
+                       float* ws, float* bb, float* conf, int64_t* idx, smot_stream_t stream);
+
+int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,
+                               const float* scales, int num_levels, int C,
+                               const float* boxes, int N, int rz, int sampling_ratio,
+                               float pad_pixels, float search_expansion, float min_search_wh,
+                               float* templates, float* sr, smot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,62 @@
+// One-call entry points for the two halves of a frame pair (host-side fusion: one FFI crossing and
+// one argument validation per call instead of five; the kernels are the ones in the other files and
+// run back-to-back on `stream`).
+//
+//   smot_emm_track_fwd         == the inference branch of EMM.forward          (reference EMM/track_core.py:28-79)
+//   smot_emm_extract_cache_fwd == EMM.extract_cache                             (reference EMM/track_core.py:81-98)
+#include "smot_common.h"
+
+extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
+    if (N < 0 || C <= 0 || rz <= 0 || rx < rz) return -1;
+    const long long ho = rx - rz + 1;
+    const long long n = N > 0 ? N : 1;
+    // x | response | tower workspace | logits | decode candidates (8-byte aligned: all terms even)
+    return n * C * rx * rx + n * C * ho * ho + n * 2 * C * ho * ho + n * 8 * ho * ho +
+           n * smot_emm_decode_ws_floats((int)ho, 16);
+}
+
+extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights, const int* widths,
+                                  const int* pad_cells, const float* scales, int num_levels, int C,
+                                  const float* boxes, const float* sr, const float* templates, int N, int rx,
+                                  int rz, int sampling_ratio, const float* const* predictor_params, int gn_groups,
+                                  float gn_eps, const float* hann, int up, float pad_pixels,
+                                  float one_minus_sigma, float sigma, int use_centerness, float clip_w,
+                                  float clip_h, float* ws, float* bb, float* conf, int64_t* idx,
+                                  smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && C > 0 && rz > 0 && rx >= rz, "emm_track: bad sizes N=%d C=%d rx=%d rz=%d", N, C, rx, rz);
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(predictor_params && ws && boxes && sr && templates, "emm_track: null pointer");
+    SMOT_REQUIRE(((uintptr_t)ws & 15) == 0, "emm_track: workspace must be 16-byte aligned");
+    const int ho = rx - rz + 1;
+    float* x = ws;
+    float* resp = x + (size_t)N * C * rx * rx;
+    float* tower = resp + (size_t)N * C * ho * ho;
+    float* logits = tower + (size_t)N * 2 * C * ho * ho;
+    float* cand = logits + (size_t)N * 8 * ho * ho;       // 7 planes used; 8 keeps the 8-byte alignment
+    int rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,
+                                       sampling_ratio, x, nullptr, stream);
+    if (rc) return rc;
+    rc = smot_xcorr_dw_fwd(x, templates, resp, N, C, rx, rz, stream);
+    if (rc) return rc;
+    const float* const* p = predictor_params;
+    rc = smot_emm_predictor_fwd(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10],
+                                p[11], gn_groups, gn_eps, tower, logits, stream);
+    if (rc) return rc;
+    return smot_emm_decode_fwd(logits, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma,
+                               use_centerness, clip_w, clip_h, cand, bb, conf, idx, stream);
+}
+
+extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,
+                                          const float* scales, int num_levels, int C, const float* boxes, int N,
+                                          int rz, int sampling_ratio, float pad_pixels, float search_expansion,
+                                          float min_search_wh, float* templates, float* sr, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache: bad sizes");
+    if (N == 0) return SMOT_OK;
+    int zero_pad[SMOT_MAX_LEVELS] = {0};
+    int rc = smot_roi_align_levels_fwd(feats, heights, widths, zero_pad, scales, num_levels, C, boxes, boxes, N, rz, rz,
+                                       sampling_ratio, templates, nullptr, stream);
+    if (rc) return rc;
+    return smot_search_region_fwd(boxes, N, pad_pixels, search_expansion, min_search_wh, sr, stream);
+}

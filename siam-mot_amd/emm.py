@@ -107,10 +107,18 @@ class EMMPredictor(nn.Module):
         self.center = _conv3x3(in_channels, 1)
         self.reg = _conv3x3(in_channels, 4)
 
+    def param_dict(self):
+        """Reference-keyed Parameter objects, collected once (``.to()`` / ``load_state_dict`` update
+        the same Parameter objects in place, so the pointers read at call time are always current)."""
+        cache = self.__dict__.get("_param_cache")
+        if cache is None:
+            cache = dict(self.named_parameters())
+            self.__dict__["_param_cache"] = cache
+        return cache
+
     def forward_logits(self, x):
         """→ ``[N,7,Ho,Ho]`` (cls0, cls1, center, reg l/t/r/b)."""
-        params = {k: v for k, v in self.named_parameters()}
-        return ops.emm_predictor(x, params, self.gn_groups, self.gn_eps)
+        return ops.emm_predictor(x, self.param_dict(), self.gn_groups, self.gn_eps)
 
     def forward(self, x):
         logits = self.forward_logits(x)
@@ -137,31 +145,30 @@ class EMM(nn.Module):
             raise NotImplementedError("siammot_amd.EMM is an inference path; training "
                                       "(track_core.py:45-47,56-67) is out of scope")
         assert len(boxes) == 1                                           # track_core.py:75
-        sr_features = self.feature_extractor(features, boxes, sr, pad_pixels=self.pad_pixels)
-        response_map = ops.xcorr_depthwise(sr_features, template_features)
-        logits = self.predictor.forward_logits(response_map)
-        bb, bb_conf = ops.emm_decode(logits, cat([b.bbox for b in sr], dim=0), boxes[0].bbox,
-                                     self.rx, self.rz, self.pad_pixels, sigma=self.sigma,
-                                     use_centerness=self.use_centerness,
-                                     clip_wh=None if self.amodal else boxes[0].size)
-        # the clamp of clip_to_image already happened inside the decode kernel
-        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)
+        fe = self.feature_extractor.pooler_x
+        # one library call: pooling -> xcorr -> predictor -> decode (+ the clamp of clip_to_image)
+        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, cat([b.bbox for b in sr], dim=0),
+                                    template_features, self.predictor.param_dict(), self.rx, self.rz,
+                                    fe.scales, fe.sampling_ratio, self.pad_pixels, sigma=self.sigma,
+                                    use_centerness=self.use_centerness,
+                                    clip_wh=None if self.amodal else boxes[0].size,
+                                    gn_groups=self.predictor.gn_groups, gn_eps=self.predictor.gn_eps)
+        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
         return {}, track_result, {}
 
     def extract_cache(self, features, detection):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""
         detection = [detection]
-        x = self.feature_extractor(features, detection)
         tu = self.track_utils
-        sr_boxes = []
-        for det in detection:
-            w, h = det.size
-            sr_bbox = ops.search_region(det.bbox, tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
-            sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
-            for field in det.fields():
-                sr.add_field(field, det.get_field(field))
-            sr_boxes.append(sr)
-        return x, sr_boxes, detection
+        fz = self.feature_extractor.pooler_z
+        det = detection[0]
+        x, sr_bbox = ops.emm_extract_cache(features, det.bbox, self.rz, fz.scales, fz.sampling_ratio,
+                                           tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
+        w, h = det.size
+        sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
+        for field in det.fields():
+            sr.add_field(field, det.get_field(field))
+        return x, [sr], detection
 
 
 def wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=False):

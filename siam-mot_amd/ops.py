@@ -20,10 +20,6 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 ABI_VERSION = 1
 UP_SCALE = 16          # reference track_core.py:69-73
 
-# bench.py sets this to a list to collect (start, end) torch.cuda.Event pairs recorded on the launch
-# stream around every xcorr launch (roofline.achieved); None = no instrumentation.
-xcorr_event_sink = None
-xcorr_event_pool = None      # optional pre-created event pairs (event creation is slow)
 
 _lib = None
 _c_float_p = ctypes.POINTER(ctypes.c_float)
@@ -42,6 +38,13 @@ _SIGNATURES = {
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
                                            _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
+    "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
+    "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
+    "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
+    "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
+                                          _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+    "smot_emm_extract_cache_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f,
+                                                  _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 
@@ -151,18 +154,7 @@ def xcorr_depthwise(x, kernel):
     N, C, Rx, _ = x.shape
     Rz = kernel.shape[2]
     out = torch.empty((N, C, Rx - Rz + 1, Rx - Rz + 1), dtype=torch.float32, device=x.device)
-    sink = xcorr_event_sink
-    if sink is not None:
-        if xcorr_event_pool:
-            e0, e1 = xcorr_event_pool.pop()
-        else:
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
     rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, _stream())
-    if sink is not None:
-        e1.record()
-        sink.append((e0, e1))
     _check(rc, "xcorr_depthwise")
     return out
 
@@ -229,3 +221,101 @@ def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=
                                  _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
     _check(rc, "emm_decode")
     return (bb, conf, idx) if return_index else (bb, conf)
+
+
+# ----------------------------------------------------------------------------------------------
+# one-call halves of a frame pair
+# ----------------------------------------------------------------------------------------------
+_cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+
+
+def _level_arrays(features, scales):
+    L = len(scales)
+    feats = [_dev_f32(features[l], "features[%d]" % l) for l in range(L)]
+    for f in feats:
+        if f.dim() != 4 or f.shape[0] != 1:
+            raise RuntimeError("siammot_amd: one image per call, got feature shape %s" % (tuple(f.shape),))
+    fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * L)(*[f.shape[2] for f in feats])
+    ws = (ctypes.c_int * L)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * L)(*[float(s) for s in scales])
+    return feats, fp, hs, ws, sc
+
+
+_ws_cache = {}
+
+
+def _workspace(device, n_floats):
+    """Grow-only fp32 scratch per device (intermediates never leave the library; nothing persists
+    semantically between calls)."""
+    key = str(device)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty((int(n_floats * 1.25) + 1024,), dtype=torch.float32, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_ratio, pad_pixels,
+              sigma=0.4, use_centerness=True, clip_wh=None, gn_groups=32, gn_eps=1e-5, return_index=False):
+    """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``)."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    sr = _dev_f32(sr, "sr")
+    templates = _dev_f32(templates, "template_features")
+    N = boxes.shape[0]
+    dev = boxes.device
+    feats, fp, hs, ws_, sc = _level_arrays(features, scales)
+    C = feats[0].shape[1]
+    if tuple(templates.shape) != (N, C, rz, rz) or tuple(sr.shape) != (N, 4):
+        raise RuntimeError("siammot_amd.emm_track: %d boxes, templates %s, sr %s do not agree"
+                           % (N, tuple(templates.shape), tuple(sr.shape)))
+    L = len(scales)
+    pc = (ctypes.c_int * L)(*[int(pad_pixels / ((2 ** i) * 4)) for i in range(L)])
+    w = [_dev_f32(params[k], k) for k in PREDICTOR_KEYS]
+    pp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in w])
+    ho = rx - rz + 1
+    work = _workspace(dev, lib.smot_emm_track_ws_floats(N, C, rx, rz))
+    bb = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    conf = torch.empty((N,), dtype=torch.float32, device=dev)
+    idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
+    rc = lib.smot_emm_track_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C,
+                                _ptr(boxes), _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
+                                _cast(pp), int(gn_groups), float(gn_eps), _ptr(hann_window(ho * UP_SCALE, dev)),
+                                UP_SCALE, float(pad_pixels), float(1 - sigma), float(sigma),
+                                int(bool(use_centerness)),
+                                float(clip_wh[0]) if clip_wh is not None else 0.0,
+                                float(clip_wh[1]) if clip_wh is not None else 0.0,
+                                _ptr(work), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
+    _check(rc, "emm_track")
+    return (bb, conf, idx) if return_index else (bb, conf)
+
+
+def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh):
+    """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``)."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    N = boxes.shape[0]
+    feats, fp, hs, ws_, sc = _level_arrays(features, scales)
+    C = feats[0].shape[1]
+    templates = torch.empty((N, C, rz, rz), dtype=torch.float32, device=boxes.device)
+    sr = torch.empty((N, 4), dtype=torch.float32, device=boxes.device)
+    rc = lib.smot_emm_extract_cache_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(sc), len(scales), C, _ptr(boxes), N,
+                                        int(rz), int(sampling_ratio), float(pad_pixels), float(search_expansion),
+                                        float(min_search_wh), _ptr(templates), _ptr(sr), _stream())
+    _check(rc, "emm_extract_cache")
+    return templates, sr
+
+
+def xcorr_timer_begin(max_launches):
+    """Start bracketing every xcorr launch with HIP events on its launch stream (bench.py)."""
+    _check(load_library().smot_xcorr_timer_begin(int(max_launches)), "xcorr_timer_begin")
+
+
+def xcorr_timer_end():
+    """→ (total milliseconds inside xcorr kernels, launches timed)."""
+    tot = ctypes.c_double(0.0)
+    n = ctypes.c_int(0)
+    _check(load_library().smot_xcorr_timer_end(ctypes.cast(ctypes.byref(tot), ctypes.c_void_p),
+                                               ctypes.cast(ctypes.byref(n), ctypes.c_void_p)), "xcorr_timer_end")
+    return tot.value, n.value

@@ -435,3 +435,37 @@ def test_emm_training_mode_is_refused(ops):
     emm.train()
     with pytest.raises(NotImplementedError):
         emm((), [None], [None])
+
+
+def test_one_call_entry_points_equal_operator_composition(ops):
+    """smot_emm_track_fwd / smot_emm_extract_cache_fwd launch the same kernels as the per-operator
+    calls: results must be bit-identical; the xcorr event timer brackets the launch inside them."""
+    case = gi.EMM_CASES["default"]
+    cfg = _cfg(case)
+    inp = gi.emm_case_inputs("default")
+    feats_a = [_d(f) for f in inp["features_a"]]
+    feats_b = [_d(f) for f in inp["features_b"]]
+    boxes = _d(inp["boxes"])
+    params = {k: _d(v) for k, v in inp["params"].items()}
+    z, sr = ops.emm_extract_cache(feats_a, boxes, cfg.rz, cfg.scales, cfg.sampling_ratio, cfg.pad_pixels,
+                                  cfg.search_expansion, cfg.min_search_wh)
+    assert torch.equal(z, ops.roi_align_levels(feats_a, boxes, boxes, cfg.rz, cfg.scales, cfg.sampling_ratio))
+    assert torch.equal(sr, ops.search_region(boxes, cfg.pad_pixels, cfg.search_expansion, cfg.min_search_wh))
+    ops.xcorr_timer_begin(4)
+    bb, conf, idx = ops.emm_track(feats_b, boxes, sr, z, params, cfg.rx, cfg.rz, cfg.scales, cfg.sampling_ratio,
+                                  cfg.pad_pixels, sigma=cfg.sigma, use_centerness=cfg.use_centerness,
+                                  clip_wh=case["image_wh"], return_index=True)
+    pad_cells = [O.pad_cells(cfg.pad_pixels, i) for i in range(len(cfg.scales))]
+    x = ops.roi_align_levels(feats_b, sr, boxes, cfg.rx, cfg.scales, cfg.sampling_ratio, pad_cells)
+    logits = ops.emm_predictor(ops.xcorr_depthwise(x, z), params)
+    total_ms, launches = ops.xcorr_timer_end()
+    assert launches == 2 and 0.0 < total_ms < 50.0
+    bb2, conf2, idx2 = ops.emm_decode(logits, sr, boxes, cfg.rx, cfg.rz, cfg.pad_pixels, sigma=cfg.sigma,
+                                      use_centerness=cfg.use_centerness, return_index=True,
+                                      clip_wh=case["image_wh"])
+    assert torch.equal(bb, bb2) and torch.equal(conf, conf2) and torch.equal(idx, idx2)
+    # zero tracks: nothing is launched, shapes are preserved
+    e = torch.zeros((0, 4), device=DEV)
+    bb0, conf0 = ops.emm_track(feats_b, e, e, torch.zeros((0, case["channels"], cfg.rz, cfg.rz), device=DEV), params,
+                               cfg.rx, cfg.rz, cfg.scales, cfg.sampling_ratio, cfg.pad_pixels)
+    assert tuple(bb0.shape) == (0, 4) and tuple(conf0.shape) == (0,)

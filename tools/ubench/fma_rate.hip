@@ -46,18 +46,18 @@ __global__ void __launch_bounds__(256) k_fma(float* out, float a, float b) {
 template <int MODE>
 void run(const char* name, int blocks, float* d, double flops_per_inst, int insts_per_iter) {
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
     hipLaunchKernelGGL(k_fma<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.9999f);
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int r = 0; r < 5; ++r) {
-        hipEventRecord(e0, 0);
+        (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(k_fma<MODE>, dim3(blocks), dim3(256), 0, 0, d, 1.0001f, 0.9999f);
-        hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
         float ms;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         best = ms < best ? ms : best;
     }
     const double waves = (double)blocks * 4;
@@ -69,10 +69,43 @@ void run(const char* name, int blocks, float* d, double flops_per_inst, int inst
            blocks, best, tf, cyc);
 }
 
+// shader clock during a kernel: s_memtime (shader cycles) against the constant-rate wall clock
+__global__ void k_clock(unsigned long long* out, int iters) {
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+    float a = threadIdx.x;
+    for (int i = 0; i < iters; ++i) asm volatile("v_fmac_f32 %0, %0, %0" : "+v"(a));
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        out[0] = c1 - c0;
+        out[1] = w1 - w0;
+    }
+    if (a == 12345.f) out[2] = 1;
+}
+
+static void clock_probe(const char* label, int iters) {
+    unsigned long long* d;
+    (void)hipMalloc(&d, 32);
+    hipLaunchKernelGGL(k_clock, dim3(1024), dim3(256), 0, 0, d, iters);
+    (void)hipDeviceSynchronize();
+    unsigned long long h[2];
+    (void)hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
+    int wall_khz = 0;
+    (void)hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    const double secs = (double)h[1] / (wall_khz * 1e3);
+    printf("{\"probe\": \"%s\", \"shader_cycles\": %llu, \"wall_ticks\": %llu, \"wall_khz\": %d, \"kernel_us\": %.1f, "
+           "\"shader_MHz\": %.0f}\n", label, h[0], h[1], wall_khz, secs * 1e6, h[0] / secs / 1e6);
+    (void)hipFree(d);
+}
+
 int main() {
     float* d;
-    hipMalloc(&d, 4096 * 256 * sizeof(float));
-    for (int blocks : {256, 512, 1024, 2048}) {   // 1, 2, 4, 8 waves per SIMD
+    (void)hipMalloc(&d, 4096 * 256 * sizeof(float));
+    clock_probe("cold 10us kernel", 1000);
+    clock_probe("second 10us kernel", 1000);
+    clock_probe("1ms kernel", 100000);
+    clock_probe("10ms kernel", 1000000);
+    clock_probe("10us kernel right after load", 1000);
+    for (int blocks : {256, 512, 1024}) {   // 1, 2, 4, 8 waves per SIMD
         run<0>("v_fmac_f32 vgpr", blocks, d, 128, 16);
         run<1>("v_fmac_f32 sgpr", blocks, d, 128, 16);
         run<2>("v_pk_fma_f32", blocks, d, 256, 8);
