@@ -94,6 +94,22 @@ int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, 
                       smot_stream_t stream);
 
 /*
+ * Search-region pooling fused with the cross-correlation (the [N,C,Rx,Rx] tensor stays on chip).
+ *
+ * Replaces, in EMM.forward (EMM/track_core.py:49-53): pad_feature -> SRPooler(sr) -> xcorr_depthwise.
+ *   Arguments as smot_roi_align_levels_fwd (rois = sr, level_boxes = boxes) and smot_xcorr_dw_fwd
+ *   (z = templates [N,C,rz,rz]); resp [N,C,Ho,Ho].  x_debug: NULL, or a [N,C,rx,rx] buffer that
+ *   receives the pooled planes (tests).  Responses are bit-identical to smot_xcorr_dw_fwd applied to the
+ *   pooled planes; the pooling itself is separable (fp32-rounding-level differences to ROIAlign).
+ * SMOT_ERR_UNSUPPORTED unless rx == 30, rz == 15, sampling_ratio == 2 (use the two unfused calls).
+ */
+int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
+                            const int* pad_cells, const float* scales, int num_levels, int C,
+                            const float* boxes, const float* sr, const float* templates, int N,
+                            int rx, int rz, int sampling_ratio,
+                            float* resp, float* x_debug, smot_stream_t stream);
+
+/*
  * EMM prediction tower + heads.
  *
  * Replaces: EMMPredictor.forward (EMM/feature_extractor.py:62-69): cls_tower / reg_tower =

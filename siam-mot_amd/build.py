@@ -14,7 +14,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
-SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "emm_fused.hip"]
+SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip",
+           "emm_fused.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of
 # v_pk_fma_f32 + register shuffles (measured: 450 pk_fma + 204 movs vs 900 fma + 4 movs).
@@ -37,6 +38,8 @@ def _stale():
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [
         os.path.join(CSRC, "smot_common.h"),
+        os.path.join(CSRC, "roi_common.h"),
+        os.path.join(CSRC, "xcorr_patch2.h"),
         os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"),
         os.path.abspath(__file__),
     ]

@@ -5,6 +5,7 @@
 //   smot_emm_track_fwd         == the inference branch of EMM.forward          (reference EMM/track_core.py:28-79)
 //   smot_emm_extract_cache_fwd == EMM.extract_cache                             (reference EMM/track_core.py:81-98)
 #include "smot_common.h"
+#include <stdlib.h>
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
     if (N < 0 || C <= 0 || rz <= 0 || rx < rz) return -1;
@@ -34,11 +35,20 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     float* tower = resp + (size_t)N * C * ho * ho;
     float* logits = tower + (size_t)N * 2 * C * ho * ho;
     float* cand = logits + (size_t)N * 8 * ho * ho;       // 7 planes used; 8 keeps the 8-byte alignment
-    int rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,
+    int rc;
+    const bool no_fuse = getenv("SMOT_NO_FUSE") != nullptr;             // A/B measurements only
+    if (rx == 30 && rz == 15 && sampling_ratio == 2 && !no_fuse) {
+        // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
+        rc = smot_sr_xcorr_fused_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
+                                     rx, rz, sampling_ratio, resp, nullptr, stream);
+        if (rc) return rc;
+    } else {
+        rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,
                                        sampling_ratio, x, nullptr, stream);
-    if (rc) return rc;
-    rc = smot_xcorr_dw_fwd(x, templates, resp, N, C, rx, rz, stream);
-    if (rc) return rc;
+        if (rc) return rc;
+        rc = smot_xcorr_dw_fwd(x, templates, resp, N, C, rx, rz, stream);
+        if (rc) return rc;
+    }
     const float* const* p = predictor_params;
     rc = smot_emm_predictor_fwd(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10],
                                 p[11], gn_groups, gn_eps, tower, logits, stream);

@@ -16,60 +16,9 @@
 // Lanes walk the flattened (ph,pw) bin index (tables of one bin in registers, channels inner), so
 // stores are fully coalesced.  Windows that exceed the LDS budget
 // (degenerate aspect ratios) fall back to direct gathers from the map, same arithmetic.
-#include "smot_common.h"
+#include "roi_common.h"
 
 namespace smot {
-
-struct LevelParams {
-    const float* feat[SMOT_MAX_LEVELS];
-    int H[SMOT_MAX_LEVELS];
-    int W[SMOT_MAX_LEVELS];
-    int pad[SMOT_MAX_LEVELS];
-    float scale[SMOT_MAX_LEVELS];
-    int num_levels;
-    float k_min, k_max;
-};
-
-// [UPSTREAM] LevelMapper: floor(4 + log2(sqrt(area)/224 + 1e-6)), clamped, 0-based.
-__device__ __forceinline__ int map_level(const float* b, float k_min, float k_max) {
-    const float w = add_rn(sub_rn(b[2], b[0]), 1.0f);
-    const float h = add_rn(sub_rn(b[3], b[1]), 1.0f);
-    const float s = sqrtf(mul_rn(w, h));
-    float lvl = floorf(add_rn(4.0f, log2f(add_rn(div_rn(s, 224.0f), 1e-6f))));
-    lvl = fminf(fmaxf(lvl, k_min), k_max);
-    return (int)lvl - (int)k_min;
-}
-
-// One axis sample of the legacy ROIAlign, evaluated against the PADDED extent `size_p`
-// (= real + 2*pad) and re-expressed as indices into the REAL map.
-__device__ __forceinline__ void axis_sample(float start, float bin, int G, int s, int size_real,
-                                            int pad, int* lo, int* hi, float* w_lo, float* w_hi) {
-    const int p = s / G;
-    const int i = s - p * G;
-    const int size_p = size_real + 2 * pad;
-    // roi_start + p*bin + (i+.5f)*bin/G, each op rounded separately as in the reference
-    float c = add_rn(add_rn(start, mul_rn((float)p, bin)),
-                     div_rn(mul_rn((float)i + 0.5f, bin), (float)G));
-    const bool valid = !(c < -1.0f || c > (float)size_p);
-    if (c <= 0.0f) c = 0.0f;
-    int l = (int)c;
-    int h;
-    if (l >= size_p - 1) {
-        h = l = size_p - 1;
-        c = (float)l;
-    } else {
-        h = l + 1;
-    }
-    const float fl = sub_rn(c, (float)l);   // weight of the high cell
-    const float fh = sub_rn(1.0f, fl);      // weight of the low cell
-    const int lr = l - pad, hr = h - pad;
-    const bool lo_in = valid && lr >= 0 && lr < size_real;
-    const bool hi_in = valid && hr >= 0 && hr < size_real;
-    *lo = lo_in ? lr : 0;
-    *hi = hi_in ? hr : 0;
-    *w_lo = lo_in ? fh : 0.0f;
-    *w_hi = hi_in ? fl : 0.0f;
-}
 
 constexpr int RA_WIN_FLOATS = 4096;   // LDS window budget per channel (16 KiB)
 constexpr int RA_CH = 4;              // channels per workgroup (windows staged together: 64 KiB)
@@ -270,9 +219,6 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
                                          int out_h, int out_w, int sampling_ratio, float* out,
                                          int32_t* levels_out, smot_stream_t stream) {
     using namespace smot;
-    SMOT_REQUIRE(feats && heights && widths && pad_cells && scales, "roi_align: null level array");
-    SMOT_REQUIRE(num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "roi_align: num_levels=%d not in [1,%d]",
-                 num_levels, SMOT_MAX_LEVELS);
     SMOT_REQUIRE(C > 0 && out_h > 0 && out_w > 0 && R >= 0, "roi_align: bad sizes C=%d out=%dx%d R=%d", C,
                  out_h, out_w, R);
     if (sampling_ratio <= 0 || sampling_ratio > 4) {
@@ -284,18 +230,10 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
     SMOT_REQUIRE(rois && out, "roi_align: null rois/out");
     SMOT_REQUIRE(num_levels == 1 || level_boxes, "roi_align: level_boxes required for num_levels>1");
     LevelParams P;
-    for (int l = 0; l < num_levels; ++l) {
-        SMOT_REQUIRE(feats[l] && heights[l] > 0 && widths[l] > 0 && pad_cells[l] >= 0 && scales[l] > 0.f,
-                     "roi_align: bad level %d", l);
-        P.feat[l] = feats[l];
-        P.H[l] = heights[l];
-        P.W[l] = widths[l];
-        P.pad[l] = pad_cells[l];
-        P.scale[l] = scales[l];
+    {
+        const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "roi_align");
+        if (rc) return rc;
     }
-    P.num_levels = num_levels;
-    P.k_min = -log2f(scales[0]);
-    P.k_max = -log2f(scales[num_levels - 1]);
 
     const int ch_per_block = RA_CH;
     dim3 grid(R, (C + ch_per_block - 1) / ch_per_block);

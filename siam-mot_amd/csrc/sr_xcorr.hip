@@ -1,0 +1,252 @@
+// K1+K2 fused — search-region pooling straight into the cross-correlation.
+//
+// Replaces, inside EMM.forward (reference EMM/track_core.py:49-53): TrackUtils.pad_feature
+// (track_head/track_utils.py:87-107) -> SRPooler on the search regions (EMM/sr_pool.py:53-91, legacy
+// ROIAlign [UPSTREAM]) -> xcorr_depthwise (EMM/xcorr.py:37-46).  The [N,C,30,30] search-region tensor
+// (13.8 MB @30 tracks, written once and read once by the unfused path) never leaves the CU.
+//
+// Workgroup = (track, 8 channels); 4 waves, each owning 2 channels (planes).
+//   1. The per-axis sample tables of the roi are built once per workgroup in LDS exactly as in
+//      roi_align.hip (reference rounding sequence, padded extent, cells in the virtual border get
+//      weight 0) together with the bounding window [ymin..ymax] x [xmin..xmax] of touched real cells.
+//   2. Pooling is SEPARABLE: bin(ph,pw) = 1/g^2 * sum_iy sum_ix [ hx*col_iy(xlo) + lx*col_iy(xhi) ] with
+//      col_iy(wx) = hy*V[ylo][wx] + ly*V[yhi][wx].  A lane owns window column wx: for every pooled row it
+//      loads the (up to) four feature rows of the two y-samples — contiguous row segments, coalesced,
+//      no LDS window — forms the two column values, and lane pw gathers its four column values with
+//      ds_bpermute (cross-lane, no LDS storage).  Terms are added in the reference's (iy, ix) order; only
+//      the factorisation (hy*hx)*v -> hx*(hy*v) differs (fp32 rounding level, tested to 1e-5).
+//   3. The pooled 30x30 planes land in the same LDS image the xcorr kernel stages from HBM
+//      (xcorr_patch2.h), the templates are staged next to them, and the FMA phase is the shared
+//      xcorr_patch2_compute: responses are bit-identical to smot_xcorr_dw_fwd on the pooled planes.
+// Windows wider than 64 columns (search regions far larger than their FPN level suggests: degenerate
+// aspect ratios) take a workgroup-uniform slow path: per-bin gathers, same arithmetic as roi_align.hip.
+#include "roi_common.h"
+#include "xcorr_patch2.h"
+
+namespace smot {
+
+constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
+
+template <int RX, int RZ, int G>
+__global__ void __launch_bounds__(256)
+sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
+                      const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug) {
+    constexpr int HO = RX - RZ + 1;
+    constexpr int NS = RX * G;                   // samples per axis (60)
+    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
+    static_assert(HO == 16 && RX <= 32 && G == 2, "fused kernel is specialised for the 30/15/16, g=2 geometry");
+    __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
+    __shared__ int y_lo[NS], y_hi[NS], x_lo[NS], x_hi[NS];
+    __shared__ float wy_lo[NS], wy_hi[NS], wx_lo[NS], wx_hi[NS];
+    __shared__ int wbound[4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x;
+    const int c0 = blockIdx.y * FX_CH;
+    float* xs = sm + wave * (2 * XP + 2 * ZP);
+    float* zs = xs + 2 * XP;
+
+    // ---- roi geometry (same sequence as roi_align_levels_kernel) ----------------------------
+    const float* roi = sr + (size_t)n * 4;
+    int lvl = 0;
+    if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
+    const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
+    const float scale = P.scale[lvl];
+    const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
+    const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
+    const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
+    const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
+    if (tid == 0) {
+        wbound[0] = 0x7fffffff;
+        wbound[1] = -1;
+        wbound[2] = 0x7fffffff;
+        wbound[3] = -1;
+    }
+    __syncthreads();
+    if (tid < 2 * NS) {
+        int lo, hi;
+        float wl, wh;
+        const bool isy = tid < NS;
+        const int s = isy ? tid : tid - NS;
+        if (isy) {
+            axis_sample(y1, bin_h, G, s, H, pad, &lo, &hi, &wl, &wh);
+            y_lo[s] = lo;
+            y_hi[s] = hi;
+            wy_lo[s] = wl;
+            wy_hi[s] = wh;
+        } else {
+            axis_sample(x1, bin_w, G, s, W, pad, &lo, &hi, &wl, &wh);
+            x_lo[s] = lo;
+            x_hi[s] = hi;
+            wx_lo[s] = wl;
+            wx_hi[s] = wh;
+        }
+        const int b = isy ? 0 : 2;
+        if (wl != 0.0f) {
+            atomicMin(&wbound[b], lo);
+            atomicMax(&wbound[b + 1], lo);
+        }
+        if (wh != 0.0f) {
+            atomicMin(&wbound[b], hi);
+            atomicMax(&wbound[b + 1], hi);
+        }
+    }
+    __syncthreads();
+    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
+    const int plane0 = n * C + c0 + 2 * wave;            // first of this wave's two planes
+    const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);   // planes this wave really owns
+    if (ymax < ymin || xmax < xmin) {
+        // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
+        if (nvalid > 0) {
+            for (int e = lane; e < nvalid * HO * HO; e += 64) resp[(size_t)plane0 * HO * HO + e] = 0.0f;
+            if (x_debug != nullptr)
+                for (int e = lane; e < nvalid * RX * RX; e += 64) x_debug[(size_t)plane0 * RX * RX + e] = 0.0f;
+        }
+        return;
+    }
+    const int ww = xmax - xmin + 1;
+    const bool fast = (ww <= 64);                        // workgroup-uniform
+    // re-base: zero-weight entries point at a safe cell; x entries become window-relative lane ids
+    if (tid < 2 * NS) {
+        if (tid < NS) {
+            if (wy_lo[tid] == 0.0f) y_lo[tid] = ymin;
+            if (wy_hi[tid] == 0.0f) y_hi[tid] = ymin;
+        } else {
+            const int s = tid - NS;
+            x_lo[s] = (wx_lo[s] != 0.0f) ? x_lo[s] - xmin : 0;
+            x_hi[s] = (wx_hi[s] != 0.0f) ? x_hi[s] - xmin : 0;
+        }
+    }
+    __syncthreads();
+    if (nvalid <= 0) return;
+
+    // ---- templates of this wave's planes -> LDS (dword loads, 225 floats per plane) ----------
+    {
+        constexpr int NZ = (2 * RZ * RZ + 63) / 64;
+        const float* __restrict__ zg = z + (size_t)plane0 * (RZ * RZ);
+        const int zcount = nvalid * RZ * RZ;
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 2 * RZ * RZ) {
+                const float v = zg[min(e, zcount - 1)];
+                const int pl = e / (RZ * RZ);
+                const int el = e - pl * (RZ * RZ);
+                const int u = el / RZ;
+                zs[pl * ZP + u * ZS + (el - u * RZ)] = v;
+            }
+        }
+    }
+
+    // ---- pooling --------------------------------------------------------------------------
+    const float* __restrict__ fbase = P.feat[lvl];
+    if (fast) {
+        const bool col_ok = lane < ww;
+        const int gcol = xmin + (col_ok ? lane : 0);
+        // lane pw's horizontal taps (pw < RX)
+        const int pw = lane < RX ? lane : 0;
+        int sxl[G], sxh[G];
+        float hxw[G], lxw[G];
+#pragma unroll
+        for (int ix = 0; ix < G; ++ix) {
+            sxl[ix] = x_lo[pw * G + ix] << 2;            // ds_bpermute takes byte addresses (lane*4)
+            sxh[ix] = x_hi[pw * G + ix] << 2;
+            hxw[ix] = wx_lo[pw * G + ix];
+            lxw[ix] = wx_hi[pw * G + ix];
+        }
+        for (int pl = 0; pl < nvalid; ++pl) {
+            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W + gcol;
+            float* xplane = xs + pl * XP;
+            constexpr int PHB = 5;                       // pooled rows per batch: 20 loads in flight per lane
+            for (int ph0 = 0; ph0 < RX; ph0 += PHB) {
+                float v[PHB][G][2];
+#pragma unroll
+                for (int b = 0; b < PHB; ++b)
+#pragma unroll
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int s = (ph0 + b) * G + iy;
+                        v[b][iy][0] = col_ok ? fc[y_lo[s] * W] : 0.0f;
+                        v[b][iy][1] = col_ok ? fc[y_hi[s] * W] : 0.0f;
+                    }
+#pragma unroll
+                for (int b = 0; b < PHB; ++b) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int s = (ph0 + b) * G + iy;
+                        const float col = wy_lo[s] * v[b][iy][0] + wy_hi[s] * v[b][iy][1];
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col)));
+                            const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col)));
+                            acc += hxw[ix] * a + lxw[ix] * c;
+                        }
+                    }
+                    if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc / (float)(G * G);
+                }
+            }
+        }
+    } else {
+        // slow path: per-bin gathers from the map (reference term order), lanes stride over the bins
+        for (int pl = 0; pl < nvalid; ++pl) {
+            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W;
+            float* xplane = xs + pl * XP;
+            for (int t = lane; t < RX * RX; t += 64) {
+                const int ph = t / RX, pwb = t - ph * RX;
+                float acc = 0.0f;
+#pragma unroll
+                for (int iy = 0; iy < G; ++iy)
+#pragma unroll
+                    for (int ix = 0; ix < G; ++ix) {
+                        const int sy = ph * G + iy, sx = pwb * G + ix;
+                        const int xl = x_lo[sx] + xmin, xh = x_hi[sx] + xmin;
+                        const float v1 = fc[y_lo[sy] * W + xl], v2 = fc[y_lo[sy] * W + xh];
+                        const float v3 = fc[y_hi[sy] * W + xl], v4 = fc[y_hi[sy] * W + xh];
+                        const float w1 = wy_lo[sy] * wx_lo[sx], w2 = wy_lo[sy] * wx_hi[sx];
+                        const float w3 = wy_hi[sy] * wx_lo[sx], w4 = wy_hi[sy] * wx_hi[sx];
+                        acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
+                    }
+                xplane[ph * XS + pwb] = acc / (float)(G * G);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (x_debug != nullptr) {
+        for (int e = lane; e < nvalid * RX * RX; e += 64) {
+            const int pl = e / (RX * RX);
+            const int el = e - pl * (RX * RX);
+            const int r = el / RX;
+            x_debug[(size_t)plane0 * RX * RX + e] = xs[pl * XP + r * XS + (el - r * RX)];
+        }
+    }
+    // a wave that owns a single plane (odd channel tails) computes garbage for the second half-wave
+    // and the tail guard below drops it
+    xcorr_patch2_compute<RX, RZ, 0>(xs, zs, lane, resp, plane0, plane0 + nvalid);
+}
+
+}  // namespace smot
+
+extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
+                                       const int* pad_cells, const float* scales, int num_levels, int C,
+                                       const float* boxes, const float* sr, const float* templates, int N, int rx,
+                                       int rz, int sampling_ratio, float* resp, float* x_debug,
+                                       smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && C > 0, "sr_xcorr_fused: bad sizes N=%d C=%d", N, C);
+    if (!(rx == 30 && rz == 15 && sampling_ratio == 2)) {
+        set_error("sr_xcorr_fused: only Rx=30, Rz=15, sampling_ratio=2 is fused (got %d, %d, %d); use "
+                  "smot_roi_align_levels_fwd + smot_xcorr_dw_fwd", rx, rz, sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_fused: null pointer");
+    LevelParams P;
+    const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
+    if (rc) return rc;
+    dim3 grid(N, (C + FX_CH - 1) / FX_CH);
+    hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr, boxes,
+                       templates, resp, x_debug);
+    return check_launch("sr_xcorr_fused");
+}

@@ -20,6 +20,7 @@
 //     oracle/emm_oracle.py:xcorr_depthwise uses the same order).
 // No workgroup barrier is needed: each wave only touches its own LDS slab.
 #include "smot_common.h"
+#include "xcorr_patch2.h"
 #include <stdlib.h>
 
 namespace smot {
@@ -486,12 +487,8 @@ xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
                        float* __restrict__ out, int planes) {
     constexpr int HO = RX - RZ + 1;
     static_assert(HO == 16, "patch kernel tiles a 16x16 response");
-    constexpr int XS = 36;                  // row stride: 4*XS mod 64 == 16 -> the four q land on disjoint banks
-    constexpr int XP = 1088;
-    constexpr int ZS = 16;
-    constexpr int ZP = RZ * ZS;
-    constexpr int WIN = RZ + 1;             // 16 floats of a window row feed a 2-wide patch
-    static_assert(RX * XS <= XP && 2 * 7 + WIN <= XS && RZ <= ZS, "LDS image too small");
+    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
+    static_assert(RX * XS <= XP && 2 * 7 + RZ + 1 <= XS && RZ <= ZS, "LDS image too small");
     __shared__ __attribute__((aligned(16))) float sm[2 * XP + 2 * ZP];
     float* xs = sm;
     float* zs = sm + 2 * XP;
@@ -547,75 +544,7 @@ xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
     }
     __builtin_amdgcn_wave_barrier();
 
-    const int p = lane >> 5, q = (lane >> 3) & 3, g = lane & 7;
-    const float* xrow = xs + p * XP + (4 * q) * XS + 2 * g;
-    const float* zrow = zs + p * ZP;
-    float acc[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = 0.0f;
-    float zr[RZ][RZ];
-    float wa[WIN], wb[WIN];
-#define SMOT_LOAD_X(T, DST)                                                                 \
-    {                                                                                       \
-        _Pragma("unroll") for (int m = 0; m < WIN / 2; ++m) {                               \
-            const float2 v2 = *reinterpret_cast<const float2*>(xrow + (T) * XS + 2 * m);    \
-            DST[2 * m + 0] = v2.x;                                                          \
-            DST[2 * m + 1] = v2.y;                                                          \
-        }                                                                                   \
-    }
-#define SMOT_LOAD_Z(T)                                                                      \
-    {                                                                                       \
-        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                     \
-            const float4 v4 = *reinterpret_cast<const float4*>(zrow + (T) * ZS + 4 * m);    \
-            zr[T][4 * m + 0] = v4.x;                                                        \
-            zr[T][4 * m + 1] = v4.y;                                                        \
-            zr[T][4 * m + 2] = v4.z;                                                        \
-            zr[T][4 * m + 3] = v4.w;                                                        \
-        }                                                                                   \
-        zr[T][12] = zrow[(T) * ZS + 12];                                                    \
-        zr[T][13] = zrow[(T) * ZS + 13];                                                    \
-        zr[T][14] = zrow[(T) * ZS + 14];                                                    \
-    }
-#define SMOT_PIN_ACC()                                                                      \
-    asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]),   \
-                      "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), "+v"(acc[3][1]));
-#define SMOT_STEP(T, CUR, NXT)                                                              \
-    {                                                                                       \
-        if ((T) + 1 < RZ + 3) SMOT_LOAD_X((T) + 1, NXT)                                     \
-        if ((T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                              \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                     \
-            const int u = (T) - k;                                                          \
-            if (MODE == 1) {                                                                \
-                if (u >= 0 && u < RZ) acc[k][0] += CUR[k] + zr[u][k];                       \
-            } else if (u >= 0 && u < RZ) {                                                  \
-                _Pragma("unroll") for (int v = 0; v < RZ; ++v) {                            \
-                    acc[k][0] = fmaf(CUR[v], zr[u][v], acc[k][0]);                          \
-                    acc[k][1] = fmaf(CUR[v + 1], zr[u][v], acc[k][1]);                      \
-                }                                                                           \
-            }                                                                               \
-        }                                                                                   \
-        SMOT_PIN_ACC()                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                  \
-    }
-    SMOT_LOAD_X(0, wa)
-    SMOT_LOAD_Z(0)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t2 = 0; t2 < RZ + 3; t2 += 2) {
-        SMOT_STEP(t2, wa, wb)
-        if (t2 + 1 < RZ + 3) SMOT_STEP(t2 + 1, wb, wa)
-    }
-#undef SMOT_STEP
-#undef SMOT_PIN_ACC
-#undef SMOT_LOAD_Z
-#undef SMOT_LOAD_X
-
-    const int plane = plane0 + p;
-    if (plane < planes) {
-        float* o = out + (size_t)plane * (HO * HO) + (4 * q) * HO + 2 * g;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) *reinterpret_cast<float2*>(o + k * HO) = make_float2(acc[k][0], acc[k][1]);
-    }
+    xcorr_patch2_compute<RX, RZ, MODE>(xs, zs, lane, out, plane0, planes);
 }
 
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.

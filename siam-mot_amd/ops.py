@@ -38,6 +38,8 @@ _SIGNATURES = {
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
                                            _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
+    "smot_sr_xcorr_fused_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
+                                               _vp, _vp, _vp]),
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
@@ -319,3 +321,25 @@ def xcorr_timer_end():
     _check(load_library().smot_xcorr_timer_end(ctypes.cast(ctypes.byref(tot), ctypes.c_void_p),
                                                ctypes.cast(ctypes.byref(n), ctypes.c_void_p)), "xcorr_timer_end")
     return tot.value, n.value
+
+
+def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_ratio, pad_pixels, return_pooled=False):
+    """Search-region pooling + depthwise cross-correlation in one kernel → response ``[N,C,Ho,Ho]``
+    (and the pooled ``[N,C,rx,rx]`` planes when asked — test hook)."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    sr = _dev_f32(sr, "sr")
+    templates = _dev_f32(templates, "template_features")
+    N = boxes.shape[0]
+    feats, fp, hs, ws_, sc = _level_arrays(features, scales)
+    C = feats[0].shape[1]
+    L = len(scales)
+    pc = (ctypes.c_int * L)(*[int(pad_pixels / ((2 ** i) * 4)) for i in range(L)])
+    ho = rx - rz + 1
+    resp = torch.empty((N, C, ho, ho), dtype=torch.float32, device=boxes.device)
+    pooled = torch.empty((N, C, rx, rx), dtype=torch.float32, device=boxes.device) if return_pooled else None
+    rc = lib.smot_sr_xcorr_fused_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
+                                     _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
+                                     _ptr(resp), _ptr(pooled), _stream())
+    _check(rc, "sr_xcorr_fused")
+    return (resp, pooled) if return_pooled else resp

@@ -469,3 +469,49 @@ def test_one_call_entry_points_equal_operator_composition(ops):
     bb0, conf0 = ops.emm_track(feats_b, e, e, torch.zeros((0, case["channels"], cfg.rz, cfg.rz), device=DEV), params,
                                cfg.rx, cfg.rz, cfg.scales, cfg.sampling_ratio, cfg.pad_pixels)
     assert tuple(bb0.shape) == (0, 4) and tuple(conf0.shape) == (0,)
+
+
+def test_fused_sr_pool_xcorr(ops, golden_dir):
+    """K1+K2 fused: pooled planes vs the oracle's physical-pad ROIAlign (separable factorisation: 1e-5),
+    responses bit-identical to the stand-alone xcorr kernel on those planes and within the xcorr
+    tolerance of the fp64 oracle; zero-window, odd channel tails and the wide-window slow path."""
+    case = gi.EMM_CASES["default"]
+    cfg = _cfg(case)
+    inp = gi.emm_case_inputs("default")
+    gold = np.load(os.path.join(golden_dir, "emm_default.npz"))
+    feats_b = [_t(f) for f in inp["features_b"]]
+    boxes = _t(inp["boxes"])
+    sr = _t(gold["sr"])
+    z = _t(gold["z"])
+    resp, pooled = ops.sr_xcorr_fused([f.to(DEV) for f in feats_b], boxes.to(DEV), sr.to(DEV), z.to(DEV), cfg.rx,
+                                      cfg.rz, cfg.scales, cfg.sampling_ratio, cfg.pad_pixels, return_pooled=True)
+    x_ref = O.sr_pool(O.pad_features(feats_b, cfg.pad_pixels), boxes, sr, cfg.rx, cfg.scales, cfg.sampling_ratio)
+    _assert_close(pooled, x_ref, 1e-5, 1e-5, "fused pooling vs oracle")
+    assert float(pooled[6].abs().max()) == 0.0          # track 7: search region entirely in the virtual border
+    assert torch.equal(resp, ops.xcorr_depthwise(pooled, z.to(DEV)))
+    _assert_close(resp, gold["response"], 1e-4, 3e-4, "fused response vs reference golden")
+    # channel counts that leave waves with one plane / none, and a track whose SR is all border
+    rs = np.random.RandomState(31)
+    for c in (2, 3, 9, 20):
+        f = [_t(rs.standard_normal((1, c, 96 // (2 ** l), 128 // (2 ** l))).astype(np.float32)) for l in range(4)]
+        b = torch.tensor([[30.0, 20.0, 95.5, 140.25], [200.0, 100.0, 420.0, 330.0], [-900.0, -900.0, -800.0, -820.0]])
+        s = O.search_region(b, 512, 1.0, 0)
+        zz = _t(rs.standard_normal((3, c, 15, 15)).astype(np.float32))
+        r, p = ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 30, 15, cfg.scales, 2, 512,
+                                  return_pooled=True)
+        pr = O.sr_pool(O.pad_features(f, 512), b, s, 30, cfg.scales, 2)
+        _assert_close(p, pr, 1e-5, 1e-5, "fused pooling C=%d" % c)
+        assert float(p[2].abs().max()) == 0.0 and float(r[2].abs().max()) == 0.0
+        assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
+    # a search region much wider than 64 cells at its level (tiny-area, extreme aspect box): slow path
+    f = [_t(rs.standard_normal((1, 4, 176 // (2 ** l), 320 // (2 ** l))).astype(np.float32)) for l in range(4)]
+    b = torch.tensor([[100.0, 300.0, 700.0, 312.0]])            # 600x12 px -> level 0, SR 1200 px = 300 cells wide
+    s = O.search_region(b, 512, 1.0, 0)
+    zz = _t(rs.standard_normal((1, 4, 15, 15)).astype(np.float32))
+    r, p = ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 30, 15, cfg.scales, 2, 512,
+                              return_pooled=True)
+    pr = O.sr_pool(O.pad_features(f, 512), b, s, 30, cfg.scales, 2)
+    _assert_close(p, pr, 1e-5, 1e-5, "fused pooling, wide window")
+    assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
+    with pytest.raises(RuntimeError, match="only Rx=30"):
+        ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 35, 7, cfg.scales, 2, 512)

@@ -86,6 +86,8 @@ def main():
                 rec("xcorr", var, t, {"algorithmic_GBps_at_min": round(xbytes / t[0] / 1e3, 1),
                                       "frac_of_8TBps": round(xbytes / t[0] / 1e3 / 8000.0, 4)})
             os.environ.pop("SMOT_XCORR_VARIANT", None)
+            t = timed(lambda: ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512), batch=50)
+            rec("sr_pool+xcorr fused", "default", t)
             rec("predictor", "default", timed(lambda: ops.emm_predictor(resp, params)))
             rec("decode", "default", timed(lambda: ops.emm_decode(logits, sr, boxes, 30, 15, 512)))
             rec("search_region", "default", timed(lambda: ops.search_region(boxes, 512, 1.0, 0)))
@@ -95,7 +97,10 @@ def main():
                 zz, ssr, dd = state
                 emm(feats, dd, ssr, template_features=zz)
                 state = emm.extract_cache(feats, det)
-            rec("frame_pair(EMM.forward+extract_cache)", "default", timed(frame_pair, batch=10))
+            rec("frame_pair(EMM.forward+extract_cache)", "fused", timed(frame_pair, batch=10))
+            os.environ["SMOT_NO_FUSE"] = "1"
+            rec("frame_pair(EMM.forward+extract_cache)", "unfused", timed(frame_pair, batch=10))
+            os.environ.pop("SMOT_NO_FUSE", None)
 
 
 if __name__ == "__main__":
