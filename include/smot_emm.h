@@ -166,8 +166,8 @@ int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes
 int smot_emm_decode_ws_floats(int Ho, int up);
 
 /*
- * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd launch —
- * direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
+ * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd and
+ * smot_sr_xcorr_fused_fwd launch — direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
  * stream (events are created in _begin, outside any timed region; at most max_launches pairs).
  * _end synchronises them and returns the summed kernel spans and the number of launches timed.
  * Not thread-safe; one timing session at a time.

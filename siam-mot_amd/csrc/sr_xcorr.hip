@@ -28,7 +28,7 @@ namespace smot {
 constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
 
 template <int RX, int RZ, int G>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)      // <= 168 VGPRs: three workgroups per CU (LDS allows three)
 sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                       const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug) {
     constexpr int HO = RX - RZ + 1;
@@ -52,6 +52,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     const float* roi = sr + (size_t)n * 4;
     int lvl = 0;
     if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
+    lvl = __builtin_amdgcn_readfirstlane(lvl);           // workgroup-uniform: keep level data in SGPRs
     const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
     const float scale = P.scale[lvl];
     const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
@@ -143,8 +144,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     // ---- pooling --------------------------------------------------------------------------
     const float* __restrict__ fbase = P.feat[lvl];
     if (fast) {
-        const bool col_ok = lane < ww;
-        const int gcol = xmin + (col_ok ? lane : 0);
+        // lanes beyond the window re-read its last column: their values are never gathered
+        const int gcol = xmin + min(lane, ww - 1);
         // lane pw's horizontal taps (pw < RX)
         const int pw = lane < RX ? lane : 0;
         int sxl[G], sxh[G];
@@ -157,9 +158,12 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
             lxw[ix] = wx_hi[pw * G + ix];
         }
         for (int pl = 0; pl < nvalid; ++pl) {
-            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W + gcol;
+            // wave-uniform channel base + 32-bit per-lane offsets (one address VGPR per load)
+            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W;
             float* xplane = xs + pl * XP;
-            constexpr int PHB = 5;                       // pooled rows per batch: 20 loads in flight per lane
+            // 60 row loads of a plane are in flight before the first use: the pooling is latency-bound
+            // (each batch is one ~2 us round trip), so two batches per plane within the register budget
+            constexpr int PHB = RX / 2;
             for (int ph0 = 0; ph0 < RX; ph0 += PHB) {
                 float v[PHB][G][2];
 #pragma unroll
@@ -167,8 +171,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
 #pragma unroll
                     for (int iy = 0; iy < G; ++iy) {
                         const int s = (ph0 + b) * G + iy;
-                        v[b][iy][0] = col_ok ? fc[y_lo[s] * W] : 0.0f;
-                        v[b][iy][1] = col_ok ? fc[y_hi[s] * W] : 0.0f;
+                        v[b][iy][0] = fc[(unsigned)(y_lo[s] * W + gcol)];
+                        v[b][iy][1] = fc[(unsigned)(y_hi[s] * W + gcol)];
                     }
 #pragma unroll
                 for (int b = 0; b < PHB; ++b) {
@@ -228,6 +232,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
 
 }  // namespace smot
 
+extern "C" void smot_xcorr_timer_mark(int end, void* stream);   // xcorr.hip (instrumentation)
+
 extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
                                        const int* pad_cells, const float* scales, int num_levels, int C,
                                        const float* boxes, const float* sr, const float* templates, int N, int rx,
@@ -246,7 +252,9 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
+    smot_xcorr_timer_mark(0, stream);
     hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr, boxes,
                        templates, resp, x_debug);
+    smot_xcorr_timer_mark(1, stream);
     return check_launch("sr_xcorr_fused");
 }

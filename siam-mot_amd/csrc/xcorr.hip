@@ -579,6 +579,18 @@ static int g_xc_capacity = 0;      // number of events (2 per launch)
 static int g_xc_used = 0;
 }  // namespace smot
 
+// used by sr_xcorr.hip: the fused kernel is bracketed by the same timer
+extern "C" void smot_xcorr_timer_mark(int end, void* stream) {
+    using namespace smot;
+    if (g_xc_events == nullptr) return;
+    if (!end) {
+        if (g_xc_used + 2 <= g_xc_capacity) (void)hipEventRecord(g_xc_events[g_xc_used], (hipStream_t)stream);
+    } else if (g_xc_used + 2 <= g_xc_capacity) {
+        (void)hipEventRecord(g_xc_events[g_xc_used + 1], (hipStream_t)stream);
+        g_xc_used += 2;
+    }
+}
+
 extern "C" int smot_xcorr_timer_begin(int max_launches) {
     using namespace smot;
     SMOT_REQUIRE(max_launches > 0 && g_xc_events == nullptr, "xcorr_timer_begin: bad count or already active");
