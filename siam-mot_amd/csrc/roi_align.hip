@@ -17,6 +17,7 @@
 // stores are fully coalesced.  Windows that exceed the LDS budget
 // (degenerate aspect ratios) fall back to direct gathers from the map, same arithmetic.
 #include "roi_common.h"
+#include <stdlib.h>
 
 namespace smot {
 
@@ -212,6 +213,11 @@ __global__ void search_region_kernel(const float* __restrict__ boxes, int N, flo
 
 }  // namespace smot
 
+namespace smot {
+int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
+                              int out_size, float* out, int32_t* levels_out, hipStream_t st);   // sr_xcorr.hip
+}
+
 extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* heights,
                                          const int* widths, const int* pad_cells,
                                          const float* scales, int num_levels, int C,
@@ -235,6 +241,11 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
         if (rc) return rc;
     }
 
+    // the two EMM pooler shapes (15x15 templates, 30x30 search regions, 2x2 samples) take the separable
+    // wave-per-two-planes kernel of sr_xcorr.hip; everything else the generic kernel below
+    if (out_h == out_w && (out_h == 15 || out_h == 30) && sampling_ratio == 2 && getenv("SMOT_ROI_GENERIC") == nullptr)
+        return launch_roi_pool_separable(P, C, rois, num_levels > 1 ? level_boxes : rois, R, out_h, out, levels_out,
+                                         (hipStream_t)stream);
     const int ch_per_block = RA_CH;
     dim3 grid(R, (C + ch_per_block - 1) / ch_per_block);
     const size_t smem = (size_t)(out_h + out_w) * sampling_ratio * 16 + (size_t)RA_CH * RA_WIN_FLOATS * sizeof(float);

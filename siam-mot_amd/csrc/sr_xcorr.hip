@@ -27,14 +27,20 @@ namespace smot {
 
 constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
 
-template <int RX, int RZ, int G>
+// XCORR = true : pooling + cross-correlation (resp = response [N,C,16,16]; x_debug optional pooled planes)
+// XCORR = false: pooling only — the separable pooler as a stand-alone ROIAlign for RX in {15, 30}
+//                (resp unused, x_debug = output [R,C,RX,RX], z unused); smot_roi_align_levels_fwd
+//                dispatches here for those shapes.
+template <int RX, int RZ, int G, bool XCORR>
 __global__ void __launch_bounds__(256, 3)      // <= 168 VGPRs: three workgroups per CU (LDS allows three)
 sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
-                      const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug) {
-    constexpr int HO = RX - RZ + 1;
+                      const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
+                      int32_t* __restrict__ levels_out) {
+    constexpr int HO = XCORR ? RX - RZ + 1 : 16;
     constexpr int NS = RX * G;                   // samples per axis (60)
     constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
-    static_assert(HO == 16 && RX <= 32 && G == 2, "fused kernel is specialised for the 30/15/16, g=2 geometry");
+    static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP,
+                  "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
     __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
     __shared__ int y_lo[NS], y_hi[NS], x_lo[NS], x_hi[NS];
     __shared__ float wy_lo[NS], wy_hi[NS], wx_lo[NS], wx_hi[NS];
@@ -53,6 +59,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     int lvl = 0;
     if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
     lvl = __builtin_amdgcn_readfirstlane(lvl);           // workgroup-uniform: keep level data in SGPRs
+    if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
     const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
     const float scale = P.scale[lvl];
     const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
@@ -101,7 +108,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     if (ymax < ymin || xmax < xmin) {
         // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
         if (nvalid > 0) {
-            for (int e = lane; e < nvalid * HO * HO; e += 64) resp[(size_t)plane0 * HO * HO + e] = 0.0f;
+            if (XCORR)
+                for (int e = lane; e < nvalid * HO * HO; e += 64) resp[(size_t)plane0 * HO * HO + e] = 0.0f;
             if (x_debug != nullptr)
                 for (int e = lane; e < nvalid * RX * RX; e += 64) x_debug[(size_t)plane0 * RX * RX + e] = 0.0f;
         }
@@ -124,7 +132,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     if (nvalid <= 0) return;
 
     // ---- templates of this wave's planes -> LDS (dword loads, 225 floats per plane) ----------
-    {
+    if (XCORR) {
         constexpr int NZ = (2 * RZ * RZ + 63) / 64;
         const float* __restrict__ zg = z + (size_t)plane0 * (RZ * RZ);
         const int zcount = nvalid * RZ * RZ;
@@ -163,7 +171,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
             float* xplane = xs + pl * XP;
             // 60 row loads of a plane are in flight before the first use: the pooling is latency-bound
             // (each batch is one ~2 us round trip), so two batches per plane within the register budget
-            constexpr int PHB = RX / 2;
+            constexpr int PHB = 15;
             for (int ph0 = 0; ph0 < RX; ph0 += PHB) {
                 float v[PHB][G][2];
 #pragma unroll
@@ -180,15 +188,18 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
 #pragma unroll
                     for (int iy = 0; iy < G; ++iy) {
                         const int s = (ph0 + b) * G + iy;
-                        const float col = wy_lo[s] * v[b][iy][0] + wy_hi[s] * v[b][iy][1];
+                        // explicit FMAs: the separable factorisation already differs from the reference's
+                        // rounding sequence at the 1e-7 level (tested to 1e-5); no reason to pay 2 ops per term
+                        const float col = fmaf(wy_hi[s], v[b][iy][1], wy_lo[s] * v[b][iy][0]);
 #pragma unroll
                         for (int ix = 0; ix < G; ++ix) {
                             const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col)));
                             const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col)));
-                            acc += hxw[ix] * a + lxw[ix] * c;
+                            acc = fmaf(hxw[ix], a, acc);
+                            acc = fmaf(lxw[ix], c, acc);
                         }
                     }
-                    if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc / (float)(G * G);
+                    if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc * (1.0f / (float)(G * G));   // exact: /4
                 }
             }
         }
@@ -227,12 +238,28 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     }
     // a wave that owns a single plane (odd channel tails) computes garbage for the second half-wave
     // and the tail guard below drops it
-    xcorr_patch2_compute<RX, RZ, 0>(xs, zs, lane, resp, plane0, plane0 + nvalid);
+    if constexpr (XCORR) xcorr_patch2_compute<RX, RZ, 0>(xs, zs, lane, resp, plane0, plane0 + nvalid);
 }
 
 }  // namespace smot
 
 extern "C" void smot_xcorr_timer_mark(int end, void* stream);   // xcorr.hip (instrumentation)
+
+// Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).
+namespace smot {
+int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
+                              int out_size, float* out, int32_t* levels_out, hipStream_t st) {
+    dim3 grid(R, (C + FX_CH - 1) / FX_CH);
+    if (out_size == 30) {
+        hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
+                           (const float*)nullptr, (float*)nullptr, out, levels_out);
+    } else {
+        hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
+                           (const float*)nullptr, (float*)nullptr, out, levels_out);
+    }
+    return check_launch("roi_pool_separable");
+}
+}  // namespace smot
 
 extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
                                        const int* pad_cells, const float* scales, int num_levels, int C,
@@ -253,8 +280,8 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     smot_xcorr_timer_mark(0, stream);
-    hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr, boxes,
-                       templates, resp, x_debug);
+    hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
+                       boxes, templates, resp, x_debug, (int32_t*)nullptr);
     smot_xcorr_timer_mark(1, stream);
     return check_launch("sr_xcorr_fused");
 }

@@ -455,15 +455,24 @@ def test_one_call_entry_points_equal_operator_composition(ops):
     bb, conf, idx = ops.emm_track(feats_b, boxes, sr, z, params, cfg.rx, cfg.rz, cfg.scales, cfg.sampling_ratio,
                                   cfg.pad_pixels, sigma=cfg.sigma, use_centerness=cfg.use_centerness,
                                   clip_wh=case["image_wh"], return_index=True)
-    pad_cells = [O.pad_cells(cfg.pad_pixels, i) for i in range(len(cfg.scales))]
-    x = ops.roi_align_levels(feats_b, sr, boxes, cfg.rx, cfg.scales, cfg.sampling_ratio, pad_cells)
-    logits = ops.emm_predictor(ops.xcorr_depthwise(x, z), params)
+    # the one-call path pools and correlates in the fused kernel
+    logits = ops.emm_predictor(ops.sr_xcorr_fused(feats_b, boxes, sr, z, cfg.rx, cfg.rz, cfg.scales,
+                                                  cfg.sampling_ratio, cfg.pad_pixels), params)
     total_ms, launches = ops.xcorr_timer_end()
-    assert launches == 2 and 0.0 < total_ms < 50.0       # the fused pool+xcorr launch and the stand-alone xcorr
+    assert launches == 2 and 0.0 < total_ms < 50.0       # both fused launches were bracketed
     bb2, conf2, idx2 = ops.emm_decode(logits, sr, boxes, cfg.rx, cfg.rz, cfg.pad_pixels, sigma=cfg.sigma,
                                       use_centerness=cfg.use_centerness, return_index=True,
                                       clip_wh=case["image_wh"])
     assert torch.equal(bb, bb2) and torch.equal(conf, conf2) and torch.equal(idx, idx2)
+    # ... and agrees with the unfused operators to fp32 rounding
+    pad_cells = [O.pad_cells(cfg.pad_pixels, i) for i in range(len(cfg.scales))]
+    x = ops.roi_align_levels(feats_b, sr, boxes, cfg.rx, cfg.scales, cfg.sampling_ratio, pad_cells)
+    bb3, conf3, idx3 = ops.emm_decode(ops.emm_predictor(ops.xcorr_depthwise(x, z), params), sr, boxes, cfg.rx, cfg.rz,
+                                      cfg.pad_pixels, sigma=cfg.sigma, use_centerness=cfg.use_centerness,
+                                      return_index=True, clip_wh=case["image_wh"])
+    assert torch.equal(idx, idx3)
+    _assert_close(bb, bb3, 0, 1e-3, "fused vs unfused boxes")
+    _assert_close(conf, conf3, 0, 1e-5, "fused vs unfused conf")
     # zero tracks: nothing is launched, shapes are preserved
     e = torch.zeros((0, 4), device=DEV)
     bb0, conf0 = ops.emm_track(feats_b, e, e, torch.zeros((0, case["channels"], cfg.rz, cfg.rz), device=DEV), params,
@@ -515,3 +524,22 @@ def test_fused_sr_pool_xcorr(ops, golden_dir):
     assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
     with pytest.raises(RuntimeError, match="only Rx=30"):
         ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 35, 7, cfg.scales, 2, 512)
+
+
+def test_generic_roi_kernel_still_matches(ops, golden_dir, monkeypatch):
+    """The 15/30 pooler shapes normally take the separable kernel; SMOT_ROI_GENERIC=1 forces the generic
+    LDS-window kernel on the same inputs — both must match the oracle (they differ from each other only by
+    fp32 rounding)."""
+    case = gi.EMM_CASES["default"]
+    cfg = _cfg(case)
+    inp = gi.emm_case_inputs("default")
+    feats = [_d(f) for f in inp["features_a"]]
+    boxes = _d(inp["boxes"])
+    z_sep = ops.roi_align_levels(feats, boxes, boxes, cfg.rz, cfg.scales, cfg.sampling_ratio)
+    monkeypatch.setenv("SMOT_ROI_GENERIC", "1")
+    z_gen = ops.roi_align_levels(feats, boxes, boxes, cfg.rz, cfg.scales, cfg.sampling_ratio)
+    monkeypatch.delenv("SMOT_ROI_GENERIC")
+    z_ref, _ = O.extract_cache(cfg, [_t(f) for f in inp["features_a"]], _t(inp["boxes"]))
+    _assert_close(z_gen, z_ref, 1e-5, 1e-5, "generic ROIAlign vs oracle")
+    _assert_close(z_sep, z_ref, 1e-5, 1e-5, "separable ROIAlign vs oracle")
+    _assert_close(z_sep, z_gen, 1e-5, 1e-5, "separable vs generic")
