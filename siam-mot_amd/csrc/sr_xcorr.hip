@@ -27,6 +27,20 @@ namespace smot {
 
 constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
 
+// base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
+// addressing form (one address VGPR per load instead of a 64-bit pair — 120 loads are in flight).
+typedef const __attribute__((address_space(1))) char* gptr_t;
+__device__ __forceinline__ float ld_off(gptr_t base, unsigned byte_off) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + byte_off);
+}
+// Launder a wave-uniform global pointer through an SGPR pair: stops loop-strength-reduction from turning
+// "base(pl) + offset(s)" into one 64-bit per-lane pointer induction variable per load (60 of them spill).
+__device__ __forceinline__ gptr_t uniform_base(const float* p) {
+    unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    asm volatile("" : "+s"(a));
+    return reinterpret_cast<gptr_t>(a);
+}
+
 // XCORR = true : pooling + cross-correlation (resp = response [N,C,16,16]; x_debug optional pooled planes)
 // XCORR = false: pooling only — the separable pooler as a stand-alone ROIAlign for RX in {15, 30}
 //                (resp unused, x_debug = output [R,C,RX,RX], z unused); smot_roi_align_levels_fwd
@@ -165,9 +179,10 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
             hxw[ix] = wx_lo[pw * G + ix];
             lxw[ix] = wx_hi[pw * G + ix];
         }
+#pragma unroll 1
         for (int pl = 0; pl < nvalid; ++pl) {
             // wave-uniform channel base + 32-bit per-lane offsets (one address VGPR per load)
-            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W;
+            const gptr_t fc = uniform_base(fbase + (size_t)(c0 + 2 * wave + pl) * H * W);
             float* xplane = xs + pl * XP;
             // 60 row loads of a plane are in flight before the first use: the pooling is latency-bound
             // (each batch is one ~2 us round trip), so two batches per plane within the register budget
@@ -179,8 +194,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
 #pragma unroll
                     for (int iy = 0; iy < G; ++iy) {
                         const int s = (ph0 + b) * G + iy;
-                        v[b][iy][0] = fc[(unsigned)(y_lo[s] * W + gcol)];
-                        v[b][iy][1] = fc[(unsigned)(y_hi[s] * W + gcol)];
+                        v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u);
+                        v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u);
                     }
 #pragma unroll
                 for (int b = 0; b < PHB; ++b) {
