@@ -179,44 +179,56 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
             hxw[ix] = wx_lo[pw * G + ix];
             lxw[ix] = wx_hi[pw * G + ix];
         }
-#pragma unroll 1
-        for (int pl = 0; pl < nvalid; ++pl) {
-            // wave-uniform channel base + 32-bit per-lane offsets (one address VGPR per load)
+        // Batches of 15 pooled rows (60 row loads per lane).  The pooling is latency-bound — every batch
+        // is one ~1.5 us memory round trip — so the loads of batch k+1 are issued before batch k is
+        // consumed (two named register sets), and only the first round trip is exposed.
+        constexpr int PHB = 15;
+        constexpr int BPP = RX / PHB;                    // batches per plane
+        static_assert(RX % PHB == 0, "pooled size must be a multiple of the batch");
+        const int nb = nvalid * BPP;
+        float va[PHB][G][2], vb[PHB][G][2];
+        auto issue = [&](int k, float (&v)[PHB][G][2]) {
+            const int pl = k / BPP, ph0 = (k - pl * BPP) * PHB;
             const gptr_t fc = uniform_base(fbase + (size_t)(c0 + 2 * wave + pl) * H * W);
-            float* xplane = xs + pl * XP;
-            // 60 row loads of a plane are in flight before the first use: the pooling is latency-bound
-            // (each batch is one ~2 us round trip), so two batches per plane within the register budget
-            constexpr int PHB = 15;
-            for (int ph0 = 0; ph0 < RX; ph0 += PHB) {
-                float v[PHB][G][2];
 #pragma unroll
-                for (int b = 0; b < PHB; ++b)
+            for (int b = 0; b < PHB; ++b)
 #pragma unroll
-                    for (int iy = 0; iy < G; ++iy) {
-                        const int s = (ph0 + b) * G + iy;
-                        v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u);
-                        v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u);
-                    }
-#pragma unroll
-                for (int b = 0; b < PHB; ++b) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int iy = 0; iy < G; ++iy) {
-                        const int s = (ph0 + b) * G + iy;
-                        // explicit FMAs: the separable factorisation already differs from the reference's
-                        // rounding sequence at the 1e-7 level (tested to 1e-5); no reason to pay 2 ops per term
-                        const float col = fmaf(wy_hi[s], v[b][iy][1], wy_lo[s] * v[b][iy][0]);
-#pragma unroll
-                        for (int ix = 0; ix < G; ++ix) {
-                            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col)));
-                            const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col)));
-                            acc = fmaf(hxw[ix], a, acc);
-                            acc = fmaf(lxw[ix], c, acc);
-                        }
-                    }
-                    if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc * (1.0f / (float)(G * G));   // exact: /4
+                for (int iy = 0; iy < G; ++iy) {
+                    const int s = (ph0 + b) * G + iy;
+                    v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u);
+                    v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u);
                 }
+        };
+        auto consume = [&](int k, float (&v)[PHB][G][2]) {
+            const int pl = k / BPP, ph0 = (k - pl * BPP) * PHB;
+            float* xplane = xs + pl * XP;
+#pragma unroll
+            for (int b = 0; b < PHB; ++b) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int iy = 0; iy < G; ++iy) {
+                    const int s = (ph0 + b) * G + iy;
+                    // explicit FMAs: the separable factorisation already differs from the reference's
+                    // rounding sequence at the 1e-7 level (tested to 1e-5); no reason to pay 2 ops per term
+                    const float col = fmaf(wy_hi[s], v[b][iy][1], wy_lo[s] * v[b][iy][0]);
+#pragma unroll
+                    for (int ix = 0; ix < G; ++ix) {
+                        const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col)));
+                        const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col)));
+                        acc = fmaf(hxw[ix], a, acc);
+                        acc = fmaf(lxw[ix], c, acc);
+                    }
+                }
+                if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc * (1.0f / (float)(G * G));   // exact: /4
             }
+        };
+        issue(0, va);
+#pragma unroll 1
+        for (int k = 0; k < nb; k += 2) {
+            if (k + 1 < nb) issue(k + 1, vb);
+            consume(k, va);
+            if (k + 2 < nb) issue(k + 2, va);
+            if (k + 1 < nb) consume(k + 1, vb);
         }
     } else {
         // slow path: per-bin gathers from the map (reference term order), lanes stride over the bins
