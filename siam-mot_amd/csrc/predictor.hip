@@ -147,26 +147,43 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         if (c + 1 < nchunks) load_chunk((c + 1) * T_IC);
         const float* A = buf + lane;
         const float* B = buf + A_FLOATS + kq * T_PLANE + (4 * wave) * 18 + xl;
+        // k-step S = tap*4 + icq.  Operands of step S+1 are read from LDS before the MFMAs of step S are
+        // issued (two named register sets); the accumulator pin + sched_barrier per step keep hipcc from
+        // re-clustering the reads next to their use (measured before: 51 % MFMA-pipe utilisation with
+        // two waves per SIMD, waves stalling on lgkmcnt right in front of every MFMA group).
+        float a_e[MT], b_e[4], a_o[MT], b_o[4];
+#define SMOT_LD(S, A_, B_)                                                                   \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) A_[m] = A[((S) * MT + m) * 64];        \
+        const float* Bp = B + (4 * ((S) & 3)) * T_PLANE + (((S) >> 2) / 3) * 18 + (((S) >> 2) % 3); \
+        B_[0] = Bp[0 * 18];                                                                  \
+        B_[1] = Bp[1 * 18];                                                                  \
+        B_[2] = Bp[2 * 18];                                                                  \
+        B_[3] = Bp[3 * 18];                                                                  \
+    }
+#define SMOT_MM(A_, B_)                                                                      \
+    {                                                                                        \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                      \
+            acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m], B_[0], acc[m][0], 0, 0, 0); \
+            acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m], B_[1], acc[m][1], 0, 0, 0); \
+            acc[m][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m], B_[2], acc[m][2], 0, 0, 0); \
+            acc[m][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[m], B_[3], acc[m][3], 0, 0, 0); \
+        }                                                                                    \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                        \
+            asm volatile("" : "+a"(acc[m][0]), "+a"(acc[m][1]), "+a"(acc[m][2]), "+a"(acc[m][3])); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    }
+        SMOT_LD(0, a_e, b_e)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - dy * 3;
-#pragma unroll
-            for (int icq = 0; icq < T_IC / 4; ++icq) {
-                const int s = tap * (T_IC / 4) + icq;
-                float a[MT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) a[m] = A[(s * MT + m) * 64];
-                const float* Bp = B + (4 * icq) * T_PLANE + dy * 18 + dx;
-                const float b0 = Bp[0 * 18], b1 = Bp[1 * 18], b2 = Bp[2 * 18], b3 = Bp[3 * 18];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b0, acc[m][0], 0, 0, 0);
-                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b1, acc[m][1], 0, 0, 0);
-                    acc[m][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b2, acc[m][2], 0, 0, 0);
-                    acc[m][3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b3, acc[m][3], 0, 0, 0);
-                }
-            }
+        for (int s2 = 0; s2 < T_STEPS; s2 += 2) {
+            SMOT_LD(s2 + 1, a_o, b_o)
+            SMOT_MM(a_e, b_e)
+            if (s2 + 2 < T_STEPS) SMOT_LD(s2 + 2, a_e, b_e)
+            SMOT_MM(a_o, b_o)
         }
+#undef SMOT_MM
+#undef SMOT_LD
         if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
         __syncthreads();
     }
