@@ -20,6 +20,7 @@
 // as wave-uniform scalar loads.
 // A generic (any Ho / channel count) tower kernel covers shapes the MFMA tiling does not.
 #include "smot_common.h"
+#include <stdlib.h>
 
 namespace smot {
 
@@ -53,7 +54,10 @@ __device__ __forceinline__ float group16_sum(float v) {
 // MT = number of 16-channel M tiles per workgroup (output-channel tile T_OC = 16*MT).
 // MT = 2 halves the B-operand traffic per MFMA; MT = 1 doubles the number of workgroups, which is
 // what fills the chip (and puts two waves on every SIMD) at small track counts.
-template <int MT>
+// ABL: 0 = the kernel; 1 = per-chunk staging removed (every chunk recomputes buffer 0: wrong results,
+// timing only); 2 = fused partial heads removed.  Ablation builds for profiles/, selected with
+// SMOT_TOWER_ABL=1|2.
+template <int MT, int ABL>
 __global__ void __launch_bounds__(256)
 tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
                   float* __restrict__ part) {
@@ -143,8 +147,8 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
     const int nchunks = C / T_IC;
     const int kq = lane >> 4, xl = lane & 15;
     for (int c = 0; c < nchunks; ++c) {
-        float* buf = sm + (c & 1) * BUF_FLOATS;
-        if (c + 1 < nchunks) load_chunk((c + 1) * T_IC);
+        float* buf = sm + ((ABL == 1) ? 0 : (c & 1)) * BUF_FLOATS;
+        if (ABL != 1 && c + 1 < nchunks) load_chunk((c + 1) * T_IC);
         const float* A = buf + lane;
         const float* B = buf + A_FLOATS + kq * T_PLANE + (4 * wave) * 18 + xl;
         // k-step S = tap*4 + icq.  Operands of step S+1 are read from LDS before the MFMAs of step S are
@@ -184,9 +188,12 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         }
 #undef SMOT_MM
 #undef SMOT_LD
-        if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
-        __syncthreads();
+        if (ABL != 1) {
+            if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
+            __syncthreads();
+        }
     }
+    if (ABL == 1) __syncthreads();
 
     // ---- fused GroupNorm (two-pass, fp32) + affine + ReLU -----------------------------------
     // acc[m][t][r] = conv[oc = m*16 + kq*4 + r][pos = (4*wave + t)*16 + xl]
@@ -276,7 +283,7 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         const int y = tid >> 4, x = tid & 15;
         float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < (ABL == 2 ? 0 : MT); ++m) {
             const float* pl0 = sm + m * BUF_FLOATS + A_FLOATS + y * 18 + x;
 #pragma unroll 4
             for (int cl = 0; cl < 16; ++cl) {
@@ -533,23 +540,37 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
         const int mt = narrow ? 1 : 2;
         const int tiles_per_tower = C / (16 * mt);
         const size_t smem = (size_t)2 * (T_STEPS * mt * 64 + T_B_FLOATS) * sizeof(float);
-        static bool attr_set[3] = {false, false, false};
-        const void* fn = narrow ? (const void*)tower_mfma_kernel<1> : (const void*)tower_mfma_kernel<2>;
-        if (!attr_set[mt]) {
+        const char* abl_s = getenv("SMOT_TOWER_ABL");
+        const int abl = abl_s ? atoi(abl_s) : 0;
+        const void* fn = narrow ? (abl == 1 ? (const void*)tower_mfma_kernel<1, 1>
+                                             : abl == 2 ? (const void*)tower_mfma_kernel<1, 2>
+                                                        : (const void*)tower_mfma_kernel<1, 0>)
+                                : (const void*)tower_mfma_kernel<2, 0>;
+        static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};   // one opt-in per kernel
+        bool seen = false;
+        for (const void* d : attr_done) seen = seen || (d == fn);
+        if (!seen) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) {
                 set_error("predictor: hipFuncSetAttribute: %s", hipGetErrorString(e));
                 return (int)e;
             }
-            attr_set[mt] = true;
+            for (const void*& d : attr_done)
+                if (d == nullptr) {
+                    d = fn;
+                    break;
+                }
         }
         // tower_ws holds the per-tile partial head sums [N][2*tiles_per_tower][4][256] (<= N*2C*256 floats)
-        if (narrow) {
-            hipLaunchKernelGGL(tower_mfma_kernel<1>, dim3(N * 2 * tiles_per_tower), dim3(256), smem, st, resp, T, C,
-                               cpg, gn_eps, tower_ws);
+        const dim3 tg(N * 2 * tiles_per_tower);
+        if (!narrow) {
+            hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+        } else if (abl == 1) {
+            hipLaunchKernelGGL((tower_mfma_kernel<1, 1>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+        } else if (abl == 2) {
+            hipLaunchKernelGGL((tower_mfma_kernel<1, 2>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         } else {
-            hipLaunchKernelGGL(tower_mfma_kernel<2>, dim3(N * 2 * tiles_per_tower), dim3(256), smem, st, resp, T, C,
-                               cpg, gn_eps, tower_ws);
+            hipLaunchKernelGGL((tower_mfma_kernel<1, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         }
         int rc = check_launch("predictor towers");
         if (rc) return rc;

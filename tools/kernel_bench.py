@@ -89,6 +89,10 @@ def main():
             t = timed(lambda: ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512), batch=50)
             rec("sr_pool+xcorr fused", "default", t)
             rec("predictor", "default", timed(lambda: ops.emm_predictor(resp, params)))
+            for abl in ("1", "2"):
+                os.environ["SMOT_TOWER_ABL"] = abl
+                rec("predictor", "ablation %s" % abl, timed(lambda: ops.emm_predictor(resp, params)))
+            os.environ.pop("SMOT_TOWER_ABL", None)
             rec("decode", "default", timed(lambda: ops.emm_decode(logits, sr, boxes, 30, 15, 512)))
             rec("search_region", "default", timed(lambda: ops.search_region(boxes, 512, 1.0, 0)))
 
