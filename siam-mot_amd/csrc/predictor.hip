@@ -181,6 +181,9 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s2 = 0; s2 < T_STEPS; s2 += 2) {
+            // the next chunk's operands (global loads issued at the top of this chunk) go to the OTHER LDS
+            // buffer half-way through this chunk's MFMAs, so the end of the chunk is only the barrier
+            if (ABL != 1 && s2 == T_STEPS / 2 && c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
             SMOT_LD(s2 + 1, a_o, b_o)
             SMOT_MM(a_e, b_e)
             if (s2 + 2 < T_STEPS) SMOT_LD(s2 + 2, a_e, b_e)
@@ -188,10 +191,7 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         }
 #undef SMOT_MM
 #undef SMOT_LD
-        if (ABL != 1) {
-            if (c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
-            __syncthreads();
-        }
+        if (ABL != 1) __syncthreads();
     }
     if (ABL == 1) __syncthreads();
 
@@ -536,7 +536,8 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
         const int blocks32 = N * 2 * (C / 32);
-        const bool narrow = blocks32 < 2 * 256;
+        // measured (profiles/r01_m): 16-channel tiles 1.79 us/track @N=30; 32-channel tiles 2.06 us/track @N=100
+        const bool narrow = blocks32 < 2 * 256 || getenv("SMOT_TOWER_WIDE") == nullptr;
         const int mt = narrow ? 1 : 2;
         const int tiles_per_tower = C / (16 * mt);
         const size_t smem = (size_t)2 * (T_STEPS * mt * 64 + T_B_FLOATS) * sizeof(float);
