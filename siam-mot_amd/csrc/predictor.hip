@@ -155,7 +155,7 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
         // issued (two named register sets); the accumulator pin + sched_barrier per step keep hipcc from
         // re-clustering the reads next to their use (measured before: 51 % MFMA-pipe utilisation with
         // two waves per SIMD, waves stalling on lgkmcnt right in front of every MFMA group).
-        float a_e[MT], b_e[4], a_o[MT], b_o[4];
+        float a_0[MT], b_0[4], a_1[MT], b_1[4], a_2[MT], b_2[4];
 #define SMOT_LD(S, A_, B_)                                                                   \
     {                                                                                        \
         _Pragma("unroll") for (int m = 0; m < MT; ++m) A_[m] = A[((S) * MT + m) * 64];        \
@@ -177,17 +177,23 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
             asm volatile("" : "+a"(acc[m][0]), "+a"(acc[m][1]), "+a"(acc[m][2]), "+a"(acc[m][3])); \
         __builtin_amdgcn_sched_barrier(0);                                                   \
     }
-        SMOT_LD(0, a_e, b_e)
+        // operands are fetched TWO k-steps ahead (three rotating register sets): one step (~136 cycles of
+        // MFMA issue) does not cover the LDS latency with 8 waves per CU reading
+        SMOT_LD(0, a_0, b_0)
+        SMOT_LD(1, a_1, b_1)
         __builtin_amdgcn_sched_barrier(0);
+        static_assert(T_STEPS % 3 == 0, "rotation period");
 #pragma unroll
-        for (int s2 = 0; s2 < T_STEPS; s2 += 2) {
+        for (int s3 = 0; s3 < T_STEPS; s3 += 3) {
             // the next chunk's operands (global loads issued at the top of this chunk) go to the OTHER LDS
             // buffer half-way through this chunk's MFMAs, so the end of the chunk is only the barrier
-            if (ABL != 1 && s2 == T_STEPS / 2 && c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
-            SMOT_LD(s2 + 1, a_o, b_o)
-            SMOT_MM(a_e, b_e)
-            if (s2 + 2 < T_STEPS) SMOT_LD(s2 + 2, a_e, b_e)
-            SMOT_MM(a_o, b_o)
+            if (ABL != 1 && s3 == T_STEPS / 2 && c + 1 < nchunks) store_chunk(sm + ((c + 1) & 1) * BUF_FLOATS);
+            SMOT_LD(s3 + 2, a_2, b_2)
+            SMOT_MM(a_0, b_0)
+            if (s3 + 3 < T_STEPS) SMOT_LD(s3 + 3, a_0, b_0)
+            SMOT_MM(a_1, b_1)
+            if (s3 + 4 < T_STEPS) SMOT_LD(s3 + 4, a_1, b_1)
+            SMOT_MM(a_2, b_2)
         }
 #undef SMOT_MM
 #undef SMOT_LD
