@@ -99,6 +99,31 @@ __device__ __forceinline__ float cell_score(const float* v, float box_w, float b
     return add_rn(mul_rn(mul_rn(conf, pen), D.one_minus_sigma), mul_rn(D.sigma, win));
 }
 
+// Search-pass variant: same formula with FMA interpolation, hardware reciprocals and exp2-based
+// exponentials (relative error a few 1e-7).  It only RANKS cells inside a band; pass 2 re-scores the 17
+// band winners with the exact sequence above and every reported number comes from that exact path.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__device__ __forceinline__ float cell_score_fast(const float* v, float inv_bw, float inv_bh, float win,
+                                                 const DecodeParams& D) {
+    const float m = fmaxf(v[0], v[1]);
+    const float e0 = fast_exp(v[0] - m);
+    const float e1 = fast_exp(v[1] - m);
+    float conf = e1 * fast_rcp(e0 + e1);
+    if (D.use_centerness) conf *= fast_rcp(1.0f + fast_exp(-v[2]));
+    float s_w = (v[5] + v[3]) * inv_bw;
+    float s_h = (v[6] + v[4]) * inv_bh;
+    s_w = max_nan(s_w, fast_rcp(s_w));
+    s_h = max_nan(s_h, fast_rcp(s_h));
+    const float pen = fast_exp(fmaf(-s_w, s_h, 1.0f) * 0.1f);
+    return fmaf(conf * pen, D.one_minus_sigma, D.sigma * win);
+}
+
+__device__ __forceinline__ float interp4_fma(float a, float b, float c, float d, const float* w) {
+    return fmaf(d, w[3], fmaf(c, w[2], fmaf(b, w[1], a * w[0])));
+}
+
 constexpr int DEC_MAX_COLS = 4;   // output columns per lane: G <= 1024
 
 __global__ void __launch_bounds__(256)
@@ -107,17 +132,29 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
                    unsigned long long* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
     __shared__ unsigned long long wbest[4];
+    __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
     const int n = blockIdx.x;
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
     const int Ho = D.Ho, up = D.up, G = D.G;
     const float* __restrict__ src = logits + (size_t)n * 7 * Ho * Ho;
     for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) lg[e] = src[e];
+    const int y_begin = max(0, up * f + up / 2);
+    const int y_end = min(G, up * f + up / 2 + up);
+    if ((int)threadIdx.x < y_end - y_begin) {      // row coefficients are lane-independent: once per band
+        int by;
+        float ty, w4[4];
+        cubic_src(y_begin + threadIdx.x, D.inv_up, &by, &ty);
+        cubic_coeffs(ty, w4);
+        wy_tab[threadIdx.x][0] = w4[0];
+        wy_tab[threadIdx.x][1] = w4[1];
+        wy_tab[threadIdx.x][2] = w4[2];
+        wy_tab[threadIdx.x][3] = w4[3];
+    }
     __syncthreads();
 
     const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
     const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
-    const int y_begin = max(0, up * f + up / 2);
-    const int y_end = min(G, up * f + up / 2 + up);
+    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
     int rows[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
@@ -142,19 +179,17 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float* rowp = lg + (ch * Ho + rows[k]) * Ho;
-                h[ch][k] = interp4(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
+                h[ch][k] = interp4_fma(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
             }
         const float hx = hann[X];
         for (int Y = y_begin; Y < y_end; ++Y) {
-            int by;
-            float ty, wy[4];
-            cubic_src(Y, D.inv_up, &by, &ty);
-            cubic_coeffs(ty, wy);
+            const float4 w4 = *reinterpret_cast<const float4*>(wy_tab[Y - y_begin]);
+            const float wy[4] = {w4.x, w4.y, w4.z, w4.w};
             float v[7];
 #pragma unroll
-            for (int ch = 0; ch < 7; ++ch) v[ch] = interp4(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
-            const float win = mul_rn(hann[Y], hx);
-            const float s = cell_score(v, box_w, box_h, win, D);
+            for (int ch = 0; ch < 7; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
+            const float win = hann[Y] * hx;
+            const float s = cell_score_fast(v, inv_bw, inv_bh, win, D);
             const unsigned long long key = make_key(s, (unsigned)(Y * G + X));
             if (!have || key > best) {
                 best = key;
@@ -181,23 +216,21 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
 
 __global__ void __launch_bounds__(64)
 decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict__ sr,
-                       const float* __restrict__ boxes, DecodeParams D, int rx, int rz, float pad,
-                       const unsigned long long* __restrict__ cand, int nband, float clip_w, float clip_h,
+                       const float* __restrict__ boxes, const float* __restrict__ hann, DecodeParams D, int rx,
+                       int rz, float pad, const unsigned long long* __restrict__ cand, int nband, float clip_w,
+                       float clip_h,
                        float* __restrict__ bb, float* __restrict__ conf, long long* __restrict__ idx_out) {
     const int n = blockIdx.x;
     const int lane = threadIdx.x;
-    unsigned long long best = 0ull;
+    // lane b re-scores band b's candidate with the exact (reference-sequence) arithmetic; bands beyond 64
+    // (up-sampled grids taller than 63*up rows) are folded onto the lanes by their search-pass keys
+    unsigned long long cand_key = 0ull;
     for (int b = lane; b < nband; b += 64) {
         const unsigned long long k = cand[(size_t)n * nband + b];
-        best = (k > best) ? k : best;
+        cand_key = (k > cand_key) ? k : cand_key;
     }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(best, m);
-        best = (o > best) ? o : best;
-    }
-    if (lane != 0) return;
-    const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+    const bool have = cand_key != 0ull;
+    const unsigned idx = have ? 0xFFFFFFFFu - (unsigned)(cand_key & 0xFFFFFFFFull) : 0u;
     const int Ho = D.Ho, G = D.G;
     const int Y = (int)(idx / (unsigned)G), X = (int)(idx - (unsigned)Y * (unsigned)G);
     int bx, by;
@@ -232,6 +265,18 @@ decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict
     const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
     const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), pad);
     const float cy = sub_rn(add_rn(sy1, mul_rn((float)(st + Y), stride_h)), pad);
+    // exact score of this lane's candidate -> exact arg-max over the band winners
+    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
+    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
+    const float score = cell_score(v, box_w, box_h, mul_rn(hann[Y], hann[X]), D);
+    const unsigned long long my_key = have ? make_key(score, idx) : 0ull;
+    unsigned long long best = my_key;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long o = shfl_xor_u64(best, m);
+        best = (o > best) ? o : best;
+    }
+    if (!have || my_key != best) return;      // keys are unique per cell index: exactly one lane continues
     float bx1 = sub_rn(cx, v[3]), by1 = sub_rn(cy, v[4]);
     float bx2 = add_rn(cx, v[5]), by2 = add_rn(cy, v[6]);
     if (clip_w > 0.0f) {
@@ -290,7 +335,8 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, logits, boxes, hann, D, cand);
     int rc = check_launch("decode bands");
     if (rc) return rc;
-    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, logits, sr, boxes, D, rx, rz, pad_pixels,
+    SMOT_REQUIRE(up <= 32, "decode: up=%d > 32", up);
+    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, logits, sr, boxes, hann, D, rx, rz, pad_pixels,
                        (const unsigned long long*)cand, Ho + 1, clip_w, clip_h, bb, conf, (long long*)idx);
     return check_launch("decode finalize");
 }
