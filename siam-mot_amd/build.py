@@ -40,6 +40,7 @@ def _stale():
         os.path.join(CSRC, "smot_common.h"),
         os.path.join(CSRC, "roi_common.h"),
         os.path.join(CSRC, "xcorr_patch2.h"),
+        os.path.join(CSRC, "logit_src.h"),
         os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"),
         os.path.abspath(__file__),
     ]

@@ -19,6 +19,7 @@
 // Arithmetic follows the reference op by op in fp32 (separately rounded mul/add where torch runs
 // separate kernels); NaN scores win and ties go to the lowest flat index, as torch.argmax on CPU.
 #include "smot_common.h"
+#include "logit_src.h"
 
 namespace smot {
 
@@ -127,7 +128,7 @@ __device__ __forceinline__ float interp4_fma(float a, float b, float c, float d,
 constexpr int DEC_MAX_COLS = 4;   // output columns per lane: G <= 1024
 
 __global__ void __launch_bounds__(256)
-decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
                    const float* __restrict__ hann, DecodeParams D,
                    unsigned long long* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
@@ -136,8 +137,10 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
     const int n = blockIdx.x;
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
     const int Ho = D.Ho, up = D.up, G = D.G;
-    const float* __restrict__ src = logits + (size_t)n * 7 * Ho * Ho;
-    for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) lg[e] = src[e];
+    for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
+        const int ch = e / (Ho * Ho);
+        lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
+    }
     const int y_begin = max(0, up * f + up / 2);
     const int y_end = min(G, up * f + up / 2 + up);
     if ((int)threadIdx.x < y_end - y_begin) {      // row coefficients are lane-independent: once per band
@@ -215,7 +218,7 @@ decode_band_kernel(const float* __restrict__ logits, const float* __restrict__ b
 }
 
 __global__ void __launch_bounds__(64)
-decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict__ sr,
+decode_finalize_kernel(LogitSrc L, const float* __restrict__ sr,
                        const float* __restrict__ boxes, const float* __restrict__ hann, DecodeParams D, int rx,
                        int rz, float pad, const unsigned long long* __restrict__ cand, int nband, float clip_w,
                        float clip_h,
@@ -245,15 +248,15 @@ decode_finalize_kernel(const float* __restrict__ logits, const float* __restrict
         cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
         rows[k] = clampi(by - 1 + k, 0, Ho - 1);
     }
-    const float* __restrict__ src = logits + (size_t)n * 7 * Ho * Ho;
     float v[7];
 #pragma unroll
     for (int ch = 0; ch < 7; ++ch) {
         float h[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float* rowp = src + (ch * Ho + rows[k]) * Ho;
-            h[k] = interp4(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
+            const int rb = rows[k] * Ho;
+            h[k] = interp4(L.get(n, ch, rb + cols[0], Ho * Ho), L.get(n, ch, rb + cols[1], Ho * Ho),
+                           L.get(n, ch, rb + cols[2], Ho * Ho), L.get(n, ch, rb + cols[3], Ho * Ho), wx);
         }
         v[ch] = interp4(h[0], h[1], h[2], h[3], wy);
     }
@@ -303,16 +306,16 @@ extern "C" int smot_emm_decode_ws_floats(int Ho, int up) {
     return 2 * (Ho + 1);
 }
 
-extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
-                                   int N, int Ho, int up, int rx, int rz, float pad_pixels, float one_minus_sigma,
-                                   float sigma, int use_centerness, float clip_w, float clip_h, float* cand_ws,
-                                   float* bb, float* conf, int64_t* idx, smot_stream_t stream) {
-    using namespace smot;
+namespace smot {
+// shared by smot_emm_decode_fwd (logits) and the one-call path of emm_fused.hip (tower partials)
+int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
+                int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
+                float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, hipStream_t st) {
     SMOT_REQUIRE(N >= 0 && Ho > 0 && up > 0, "decode: bad sizes N=%d Ho=%d up=%d", N, Ho, up);
     SMOT_REQUIRE(rx - rz + 1 == Ho && (rz & 1) == 1, "decode: need Ho == rx-rz+1 and odd rz (Ho=%d rx=%d rz=%d)", Ho,
                  rx, rz);
-    if ((up & (up - 1)) != 0 || up < 2) {
-        set_error("decode: up=%d unsupported (power of two >= 2 required; the reference uses 16)", up);
+    if ((up & (up - 1)) != 0 || up < 2 || up > 32) {
+        set_error("decode: up=%d unsupported (power of two in [2,32] required; the reference uses 16)", up);
         return SMOT_ERR_UNSUPPORTED;
     }
     const long long G = (long long)Ho * up;
@@ -320,7 +323,7 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     const size_t smem = (size_t)7 * Ho * Ho * sizeof(float);
     SMOT_REQUIRE(smem <= 64 * 1024, "decode: Ho=%d too large for LDS", Ho);
     if (N == 0) return SMOT_OK;
-    SMOT_REQUIRE(logits && sr && boxes && hann && cand_ws && bb && conf, "decode: null pointer");
+    SMOT_REQUIRE((L.logits || L.part) && sr && boxes && hann && cand_ws && bb && conf, "decode: null pointer");
     SMOT_REQUIRE(((uintptr_t)cand_ws & 7) == 0, "decode: cand_ws must be 8-byte aligned");
     DecodeParams D;
     D.Ho = Ho;
@@ -330,13 +333,25 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     D.one_minus_sigma = one_minus_sigma;
     D.sigma = sigma;
     D.use_centerness = use_centerness;
-    hipStream_t st = (hipStream_t)stream;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(cand_ws);
-    hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, logits, boxes, hann, D, cand);
+    hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand);
     int rc = check_launch("decode bands");
     if (rc) return rc;
-    SMOT_REQUIRE(up <= 32, "decode: up=%d > 32", up);
-    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, logits, sr, boxes, hann, D, rx, rz, pad_pixels,
+    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, L, sr, boxes, hann, D, rx, rz, pad_pixels,
                        (const unsigned long long*)cand, Ho + 1, clip_w, clip_h, bb, conf, (long long*)idx);
     return check_launch("decode finalize");
+}
+}  // namespace smot
+
+extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes, const float* hann,
+                                   int N, int Ho, int up, int rx, int rz, float pad_pixels, float one_minus_sigma,
+                                   float sigma, int use_centerness, float clip_w, float clip_h, float* cand_ws,
+                                   float* bb, float* conf, int64_t* idx, smot_stream_t stream) {
+    smot::LogitSrc L;
+    L.logits = logits;
+    L.part = nullptr;
+    L.tpt = 0;
+    L.cls_b = L.center_b = L.reg_b = nullptr;
+    return smot::decode_impl(L, sr, boxes, hann, N, Ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma,
+                             use_centerness, clip_w, clip_h, cand_ws, bb, conf, idx, (hipStream_t)stream);
 }

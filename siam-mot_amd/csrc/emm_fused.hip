@@ -5,7 +5,22 @@
 //   smot_emm_track_fwd         == the inference branch of EMM.forward          (reference EMM/track_core.py:28-79)
 //   smot_emm_extract_cache_fwd == EMM.extract_cache                             (reference EMM/track_core.py:81-98)
 #include "smot_common.h"
+#include "logit_src.h"
 #include <stdlib.h>
+
+namespace smot {
+int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tower_w, const float* cls_gn_w,
+                   const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
+                   const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
+                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps, float* tower_ws,
+                   float* logits, smot_stream_t stream, int* tiles_out);
+int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
+                int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
+                float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, hipStream_t st);
+int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
+                         int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
+                         float two_e, float min_wh, float* templates, float* sr, hipStream_t st);
+}  // namespace smot
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
     if (N < 0 || C <= 0 || rz <= 0 || rx < rz) return -1;
@@ -50,11 +65,21 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
         if (rc) return rc;
     }
     const float* const* p = predictor_params;
-    rc = smot_emm_predictor_fwd(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10],
-                                p[11], gn_groups, gn_eps, tower, logits, stream);
+    // towers only: when the matrix-core path applies the per-tile partial head sums stay in `tower` and the
+    // decode kernels sum them while loading (no combine launch, no logits round trip)
+    int tiles = 0;
+    rc = predictor_impl(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11],
+                        gn_groups, gn_eps, tower, logits, stream, &tiles);
     if (rc) return rc;
-    return smot_emm_decode_fwd(logits, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma,
-                               use_centerness, clip_w, clip_h, cand, bb, conf, idx, stream);
+    LogitSrc L;
+    L.logits = tiles > 0 ? nullptr : logits;
+    L.part = tower;
+    L.tpt = tiles;
+    L.cls_b = p[7];
+    L.center_b = p[9];
+    L.reg_b = p[11];
+    return decode_impl(L, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma, use_centerness,
+                       clip_w, clip_h, cand, bb, conf, idx, (hipStream_t)stream);
 }
 
 extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,
@@ -64,6 +89,13 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache: bad sizes");
     if (N == 0) return SMOT_OK;
+    if (rz == 15 && sampling_ratio == 2 && getenv("SMOT_ROI_GENERIC") == nullptr) {
+        // one launch: separable template pooling, with the search regions written by the same kernel
+        const float half_e = (float)((double)search_expansion / 2.0);
+        const float two_e = (float)((double)search_expansion * 2.0);
+        return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, N, rz, pad_pixels, half_e,
+                                    two_e, min_search_wh, templates, sr, (hipStream_t)stream);
+    }
     int zero_pad[SMOT_MAX_LEVELS] = {0};
     int rc = smot_roi_align_levels_fwd(feats, heights, widths, zero_pad, scales, num_levels, C, boxes, boxes, N, rz, rz,
                                        sampling_ratio, templates, nullptr, stream);

@@ -509,13 +509,16 @@ heads_kernel(const float* __restrict__ tower_ws, HeadsParams H, int C, int Ho, f
 
 }  // namespace smot
 
-extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, const float* cls_tower_w,
-                                      const float* cls_gn_w, const float* cls_gn_b, const float* reg_tower_w,
-                                      const float* reg_gn_w, const float* reg_gn_b, const float* cls_w,
-                                      const float* cls_b, const float* center_w, const float* center_b,
-                                      const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
-                                      float* tower_ws, float* logits, smot_stream_t stream) {
-    using namespace smot;
+namespace smot {
+// tiles_out != nullptr: "towers only" — when the MFMA path applies, stop after the tower kernel, leave
+// the per-tile partial head sums in tower_ws and return the tile count (the caller's decode sums them);
+// *tiles_out = 0 means the generic path ran and `logits` is complete.
+int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tower_w, const float* cls_gn_w,
+                   const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
+                   const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
+                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps, float* tower_ws,
+                   float* logits, smot_stream_t stream, int* tiles_out) {
+    if (tiles_out) *tiles_out = 0;
     SMOT_REQUIRE(N >= 0 && C > 0 && Ho > 0 && gn_groups > 0, "predictor: bad sizes N=%d C=%d Ho=%d groups=%d", N, C,
                  Ho, gn_groups);
     SMOT_REQUIRE(C % gn_groups == 0, "predictor: C=%d not divisible by gn_groups=%d", C, gn_groups);
@@ -581,6 +584,10 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
         }
         int rc = check_launch("predictor towers");
         if (rc) return rc;
+        if (tiles_out) {
+            *tiles_out = tiles_per_tower;
+            return SMOT_OK;
+        }
 #define SMOT_COMBINE(TPT)                                                                                \
     hipLaunchKernelGGL(heads_combine_kernel<TPT>, dim3(N, 7), dim3(256), 0, st, (const float*)tower_ws, cls_b, \
                        center_b, reg_b, logits)
@@ -625,3 +632,16 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
     }
     return check_launch("predictor heads");
 }
+}  // namespace smot
+
+extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, const float* cls_tower_w,
+                                      const float* cls_gn_w, const float* cls_gn_b, const float* reg_tower_w,
+                                      const float* reg_gn_w, const float* reg_gn_b, const float* cls_w,
+                                      const float* cls_b, const float* center_w, const float* center_b,
+                                      const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
+                                      float* tower_ws, float* logits, smot_stream_t stream) {
+    return smot::predictor_impl(resp, N, C, Ho, cls_tower_w, cls_gn_w, cls_gn_b, reg_tower_w, reg_gn_w, reg_gn_b, cls_w,
+                                cls_b, center_w, center_b, reg_w, reg_b, gn_groups, gn_eps, tower_ws, logits, stream,
+                                nullptr);
+}
+

@@ -27,6 +27,14 @@ namespace smot {
 
 constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
 
+// EMM.extract_cache in one launch: the pool-only kernel also writes the next frame's search regions
+// (update_boxes_in_pad_images + extend_bbox, reference track_utils.py:62-85,109-135; same arithmetic as
+// search_region_kernel in roi_align.hip) from its (roi, channel-group 0) workgroup.
+struct SrOut {
+    float* sr;            // [R,4] or nullptr
+    float pad, half_e, two_e, min_wh;
+};
+
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
 // addressing form (one address VGPR per load instead of a 64-bit pair — 120 loads are in flight).
 typedef const __attribute__((address_space(1))) char* gptr_t;
@@ -49,7 +57,7 @@ template <int RX, int RZ, int G, bool XCORR>
 __global__ void __launch_bounds__(256, 3)      // <= 168 VGPRs: three workgroups per CU (LDS allows three)
 sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                       const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
-                      int32_t* __restrict__ levels_out) {
+                      int32_t* __restrict__ levels_out, SrOut S) {
     constexpr int HO = XCORR ? RX - RZ + 1 : 16;
     constexpr int NS = RX * G;                   // samples per axis (60)
     constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
@@ -74,6 +82,17 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
     lvl = __builtin_amdgcn_readfirstlane(lvl);           // workgroup-uniform: keep level data in SGPRs
     if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
+    if (!XCORR && S.sr != nullptr && blockIdx.y == 0 && tid == 0) {
+        const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
+        const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
+        const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
+        const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
+        const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
+        S.sr[n * 4 + 0] = sub_rn(bx1, w_ext);
+        S.sr[n * 4 + 1] = sub_rn(by1, h_ext);
+        S.sr[n * 4 + 2] = add_rn(bx2, w_ext);
+        S.sr[n * 4 + 3] = add_rn(by2, h_ext);
+    }
     const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
     const float scale = P.scale[lvl];
     const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
@@ -277,14 +296,30 @@ namespace smot {
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f};
     if (out_size == 30) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out);
+                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
     } else {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out);
+                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
     }
     return check_launch("roi_pool_separable");
+}
+
+int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
+                         int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
+                         float two_e, float min_wh, float* templates, float* sr, hipStream_t st) {
+    (void)rz;
+    LevelParams P;
+    const int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "emm_extract_cache");
+    if (rc) return rc;
+    SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
+    dim3 grid(N, (C + FX_CH - 1) / FX_CH);
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh};
+    hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, boxes, boxes,
+                       (const float*)nullptr, (float*)nullptr, templates, (int32_t*)nullptr, S);
+    return check_launch("emm_extract_cache");
 }
 }  // namespace smot
 
@@ -307,8 +342,9 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     smot_xcorr_timer_mark(0, stream);
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
-                       boxes, templates, resp, x_debug, (int32_t*)nullptr);
+                       boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
     smot_xcorr_timer_mark(1, stream);
     return check_launch("sr_xcorr_fused");
 }
