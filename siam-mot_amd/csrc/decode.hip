@@ -137,9 +137,21 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     const int n = blockIdx.x;
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
     const int Ho = D.Ho, up = D.up, G = D.G;
-    for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
-        const int ch = e / (Ho * Ho);
-        lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
+    if (L.logits != nullptr) {
+        for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
+            const int ch = e / (Ho * Ho);
+            lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
+        }
+    } else {
+        // Ho == 16: thread = position; the 7 channels' tile loads are independent (56 in flight at C = 128)
+        float c7[7];
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch) c7[ch] = L.combine(n, ch, threadIdx.x);
+#pragma unroll
+        for (int ch = 0; ch < 7; ++ch) {
+            lg[ch * 256 + threadIdx.x] = c7[ch];
+            if (blockIdx.y == 0) L.logits_out[((size_t)n * 7 + ch) * 256 + threadIdx.x] = c7[ch];
+        }
     }
     const int y_begin = max(0, up * f + up / 2);
     const int y_end = min(G, up * f + up / 2 + up);
@@ -337,7 +349,12 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand);
     int rc = check_launch("decode bands");
     if (rc) return rc;
-    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, L, sr, boxes, hann, D, rx, rz, pad_pixels,
+    LogitSrc L2 = L;
+    if (L.logits == nullptr) {
+        SMOT_REQUIRE(Ho == 16 && L.logits_out != nullptr, "decode: partial-sum source needs Ho == 16 and a logits buffer");
+        L2.logits = L.logits_out;       // written by the band-0 workgroups of the launch above
+    }
+    hipLaunchKernelGGL(decode_finalize_kernel, dim3(N), dim3(64), 0, st, L2, sr, boxes, hann, D, rx, rz, pad_pixels,
                        (const unsigned long long*)cand, Ho + 1, clip_w, clip_h, bb, conf, (long long*)idx);
     return check_launch("decode finalize");
 }
@@ -352,6 +369,7 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     L.part = nullptr;
     L.tpt = 0;
     L.cls_b = L.center_b = L.reg_b = nullptr;
+    L.logits_out = nullptr;
     return smot::decode_impl(L, sr, boxes, hann, N, Ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma,
                              use_centerness, clip_w, clip_h, cand_ws, bb, conf, idx, (hipStream_t)stream);
 }

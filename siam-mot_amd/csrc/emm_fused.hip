@@ -78,6 +78,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     L.cls_b = p[7];
     L.center_b = p[9];
     L.reg_b = p[11];
+    L.logits_out = logits;
     return decode_impl(L, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma, use_centerness,
                        clip_w, clip_h, cand, bb, conf, idx, (hipStream_t)stream);
 }
