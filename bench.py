@@ -67,6 +67,30 @@ def synthetic_features(seed, device):
     return tuple(torch.randn((1, CHANNELS, H // s, W // s), generator=g).to(device) for s in (4, 8, 16, 32, 64))
 
 
+def fused_algorithmic_bytes(boxes, image_wh, channels, rz=15, rx=30, pad_pixels=512, search_expansion=1.0):
+    """Compulsory HBM bytes of the fused search-region-pool + xcorr kernel for these tracks (SURVEY.md §8d
+    formula B restricted to that kernel): every feature cell of a track's search window read once
+    (virtual zero border excluded), its template read once, its response written once.
+        fp(sr, l) = (ceil(x2 s) - floor(x1 s) + 1) * (ceil(y2 s) - floor(y1 s) + 1), clipped to the real map."""
+    import math
+    W, H = image_wh
+    total_cells = 0
+    for x1, y1, x2, y2 in boxes.tolist():
+        s = math.sqrt((x2 - x1 + 1) * (y2 - y1 + 1))
+        lvl = int(min(max(math.floor(4 + math.log2(s / 224 + 1e-6)), 2), 5)) - 2
+        scale = 1.0 / (4 * 2 ** lvl)
+        w, h = x2 - x1 + 1, y2 - y1 + 1
+        wx, hy = w * search_expansion / 2.0, h * search_expansion / 2.0
+        sx1, sy1, sx2, sy2 = x1 - wx, y1 - hy, x2 + wx, y2 + hy            # un-padded image coordinates
+        mw, mh = W // (4 * 2 ** lvl), H // (4 * 2 ** lvl)
+        cx1, cx2 = max(math.floor(sx1 * scale), 0), min(math.ceil(sx2 * scale), mw - 1)
+        cy1, cy2 = max(math.floor(sy1 * scale), 0), min(math.ceil(sy2 * scale), mh - 1)
+        total_cells += max(cx2 - cx1 + 1, 0) * max(cy2 - cy1 + 1, 0)
+    ho = rx - rz + 1
+    n = boxes.shape[0]
+    return 4.0 * channels * total_cells + 4.0 * n * channels * (rz * rz + ho * ho)
+
+
 def init_predictor(pred, boxes):
     """Random-init weights of the reference architecture (there are no checkpoints offline), with
     biases that keep the decode non-degenerate (SURVEY.md §7 'Degenerate synthetic weights')."""
@@ -216,6 +240,7 @@ def main():
             state, _ = step(k, state)
         if not args.no_kernel_timer:
             ops.xcorr_timer_begin(args.steps)      # events are created here, outside the timed region
+            ops.kernel_timer_begin(ops.TIMER_TOWER, args.steps)
         parallel.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -225,6 +250,7 @@ def main():
         parallel.barrier()
         elapsed = time.perf_counter() - t0
         xcorr_total_ms, xcorr_launches = (0.0, 0) if args.no_kernel_timer else ops.xcorr_timer_end()
+        tower_total_ms, tower_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_TOWER)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
@@ -232,8 +258,31 @@ def main():
         return
     rx, rz = emm.rx, emm.rz
     ho = rx - rz + 1
+    # the kernel that runs in the pipeline: search-region pooling fused with the cross-correlation
+    fused_bytes = fused_algorithmic_bytes(boxes_cpu, image_wh, CHANNELS, rz, rx)
+    achieved = fused_bytes / xcorr_avg_s / 1e9 if xcorr_avg_s > 0 else 0.0
+    # the stand-alone xcorr operator (SURVEY.md §8d figure A) on the same search regions, timed the same way
     xcorr_bytes = 4.0 * n * CHANNELS * (rx * rx + rz * rz + ho * ho)
-    achieved = xcorr_bytes / xcorr_avg_s / 1e9 if xcorr_avg_s > 0 else 0.0
+    xop = None
+    if not args.no_kernel_timer:
+        with torch.no_grad():
+            z, sr, d = state
+            x = ops.roi_align_levels(feats[0], sr[0].bbox, d[0].bbox, rx, emm.feature_extractor.pooler_x.scales, 2,
+                                     [int(emm.pad_pixels / ((2 ** i) * 4)) for i in range(4)])
+            for _ in range(20):
+                ops.xcorr_depthwise(x, z)
+            reps = 200
+            ops.xcorr_timer_begin(reps)
+            for _ in range(reps):
+                ops.xcorr_depthwise(x, z)
+            torch.cuda.synchronize()
+            ms, cnt = ops.xcorr_timer_end()
+        t = ms * 1e-3 / max(cnt, 1)
+        xop = {"kernel": "xcorr_dw_patch2_kernel<30,15,0>", "algorithmic_bytes_per_launch": xcorr_bytes,
+               "avg_launch_us": t * 1e6, "achieved": xcorr_bytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": xcorr_bytes / t / 1e9 / HBM_PEAK_GBS, "launches_timed": cnt,
+               "note": "stand-alone operator, input resident in L2/MALL (not part of the frame-pair pipeline, which "
+                       "runs the fused kernel)"}
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "xcorr_traffic.json")
     if os.path.exists(tpath):
@@ -262,11 +311,22 @@ def main():
             "parallelism": "streams x%d (weights broadcast once: %d B)" % (world, bcast_bytes),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "xcorr_dw_patch2_kernel<30,15,0>",
+            "bound": "hbm", "kernel": "sr_xcorr_fused_kernel<30,15,2,true> (search-region ROIAlign + depthwise xcorr)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "algorithmic_bytes_per_launch": xcorr_bytes,
+            "algorithmic_bytes_per_launch": fused_bytes,
             "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches,
+            "xcorr_op": xop,
+        },
+        # the kernel with the largest share of GPU time (fp32-input MFMA implicit GEMM of the two towers)
+        "roofline_tower": None if tower_launches == 0 else {
+            "bound": "mfma", "kernel": "tower_mfma_kernel<1,0>",
+            "flops_per_launch": 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS,
+            "avg_launch_us": tower_total_ms * 1e3 / tower_launches,
+            "achieved": 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS / (tower_total_ms * 1e-3 / tower_launches) / 1e12,
+            "peak": 157.3, "unit": "TFLOP/s",
+            "frac": 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS / (tower_total_ms * 1e-3 / tower_launches) / 1e12 / 157.3,
+            "launches_timed": tower_launches,
         },
     }
     if world == 1 and not args.no_cpu_baseline:

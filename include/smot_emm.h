@@ -174,6 +174,10 @@ int smot_emm_decode_ws_floats(int Ho, int up);
  */
 int smot_xcorr_timer_begin(int max_launches);
 int smot_xcorr_timer_end(double* total_ms, int* launches);
+/* Same mechanism per slot: 0 = the cross-correlation kernels (what the two calls above use),
+ * 1 = the tower MFMA kernel of smot_emm_predictor_fwd / smot_emm_track_fwd. */
+int smot_kernel_timer_begin(int slot, int max_launches);
+int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
 
 /*
  * One-call halves of a frame pair (same kernels, one FFI crossing each).

@@ -17,3 +17,73 @@ void set_error(const char* fmt, ...) {
 extern "C" int smot_abi_version(void) { return SMOT_ABI_VERSION; }
 
 extern "C" const char* smot_last_error(void) { return smot::g_err; }
+
+// ---- instrumentation: HIP events recorded on the launch stream around selected kernels --------------
+// slot 0: cross-correlation (stand-alone or fused with the search-region pooling); slot 1: tower MFMA.
+namespace smot {
+struct EventTimer {
+    hipEvent_t* ev = nullptr;
+    int capacity = 0;
+    int used = 0;
+};
+static EventTimer g_timers[2];
+
+void timer_mark(int slot, int end, hipStream_t st) {
+    EventTimer& t = g_timers[slot];
+    if (t.ev == nullptr || t.used + 2 > t.capacity) return;
+    if (!end) {
+        (void)hipEventRecord(t.ev[t.used], st);
+    } else {
+        (void)hipEventRecord(t.ev[t.used + 1], st);
+        t.used += 2;
+    }
+}
+}  // namespace smot
+
+extern "C" int smot_kernel_timer_begin(int slot, int max_launches) {
+    using namespace smot;
+    SMOT_REQUIRE(slot >= 0 && slot < 2 && max_launches > 0, "kernel_timer_begin: bad slot/count");
+    EventTimer& t = g_timers[slot];
+    SMOT_REQUIRE(t.ev == nullptr, "kernel_timer_begin: slot %d already active", slot);
+    t.ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipError_t e = hipEventCreate(&t.ev[i]);
+        if (e != hipSuccess) {
+            set_error("kernel_timer_begin: hipEventCreate: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    t.capacity = 2 * max_launches;
+    t.used = 0;
+    return SMOT_OK;
+}
+
+extern "C" int smot_kernel_timer_end(int slot, double* total_ms, int* launches) {
+    using namespace smot;
+    SMOT_REQUIRE(slot >= 0 && slot < 2 && total_ms && launches, "kernel_timer_end: bad arguments");
+    EventTimer& t = g_timers[slot];
+    SMOT_REQUIRE(t.ev != nullptr, "kernel_timer_end: slot %d not active", slot);
+    double tot = 0.0;
+    for (int i = 0; i + 1 < t.used; i += 2) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(t.ev[i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]);
+        if (e != hipSuccess) {
+            set_error("kernel_timer_end: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = t.used / 2;
+    for (int i = 0; i < t.capacity; ++i) (void)hipEventDestroy(t.ev[i]);
+    delete[] t.ev;
+    t.ev = nullptr;
+    t.capacity = t.used = 0;
+    return SMOT_OK;
+}
+
+extern "C" int smot_xcorr_timer_begin(int max_launches) { return smot_kernel_timer_begin(0, max_launches); }
+extern "C" int smot_xcorr_timer_end(double* total_ms, int* launches) {
+    return smot_kernel_timer_end(0, total_ms, launches);
+}

@@ -573,6 +573,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         }
         // tower_ws holds the per-tile partial head sums [N][2*tiles_per_tower][4][256] (<= N*2C*256 floats)
         const dim3 tg(N * 2 * tiles_per_tower);
+        timer_mark(1, 0, st);
         if (!narrow) {
             hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         } else if (abl == 1) {
@@ -582,6 +583,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         } else {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         }
+        timer_mark(1, 1, st);
         int rc = check_launch("predictor towers");
         if (rc) return rc;
         if (tiles_out) {

@@ -289,7 +289,6 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
 
 }  // namespace smot
 
-extern "C" void smot_xcorr_timer_mark(int end, void* stream);   // xcorr.hip (instrumentation)
 
 // Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).
 namespace smot {
@@ -341,10 +340,10 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    smot_xcorr_timer_mark(0, stream);
+    timer_mark(0, 0, (hipStream_t)stream);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f};
     hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
                        boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
-    smot_xcorr_timer_mark(1, stream);
+    timer_mark(0, 1, (hipStream_t)stream);
     return check_launch("sr_xcorr_fused");
 }

@@ -572,64 +572,6 @@ xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z
 
 }  // namespace smot
 
-// ---- instrumentation: HIP events recorded on the launch stream around every xcorr launch ----------
-namespace smot {
-static hipEvent_t* g_xc_events = nullptr;
-static int g_xc_capacity = 0;      // number of events (2 per launch)
-static int g_xc_used = 0;
-}  // namespace smot
-
-// used by sr_xcorr.hip: the fused kernel is bracketed by the same timer
-extern "C" void smot_xcorr_timer_mark(int end, void* stream) {
-    using namespace smot;
-    if (g_xc_events == nullptr) return;
-    if (!end) {
-        if (g_xc_used + 2 <= g_xc_capacity) (void)hipEventRecord(g_xc_events[g_xc_used], (hipStream_t)stream);
-    } else if (g_xc_used + 2 <= g_xc_capacity) {
-        (void)hipEventRecord(g_xc_events[g_xc_used + 1], (hipStream_t)stream);
-        g_xc_used += 2;
-    }
-}
-
-extern "C" int smot_xcorr_timer_begin(int max_launches) {
-    using namespace smot;
-    SMOT_REQUIRE(max_launches > 0 && g_xc_events == nullptr, "xcorr_timer_begin: bad count or already active");
-    g_xc_events = new hipEvent_t[2 * (size_t)max_launches];
-    for (int i = 0; i < 2 * max_launches; ++i) {
-        hipError_t e = hipEventCreate(&g_xc_events[i]);
-        if (e != hipSuccess) {
-            set_error("xcorr_timer_begin: hipEventCreate: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-    }
-    g_xc_capacity = 2 * max_launches;
-    g_xc_used = 0;
-    return SMOT_OK;
-}
-
-extern "C" int smot_xcorr_timer_end(double* total_ms, int* launches) {
-    using namespace smot;
-    SMOT_REQUIRE(g_xc_events != nullptr && total_ms && launches, "xcorr_timer_end: not active");
-    double tot = 0.0;
-    for (int i = 0; i + 1 < g_xc_used; i += 2) {
-        float ms = 0.f;
-        hipError_t e = hipEventSynchronize(g_xc_events[i + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_xc_events[i], g_xc_events[i + 1]);
-        if (e != hipSuccess) {
-            set_error("xcorr_timer_end: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-        tot += ms;
-    }
-    *total_ms = tot;
-    *launches = g_xc_used / 2;
-    for (int i = 0; i < g_xc_capacity; ++i) (void)hipEventDestroy(g_xc_events[i]);
-    delete[] g_xc_events;
-    g_xc_events = nullptr;
-    g_xc_capacity = g_xc_used = 0;
-    return SMOT_OK;
-}
-
 extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, int Rx, int Rz,
                                  smot_stream_t stream) {
     using namespace smot;
@@ -639,8 +581,7 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
     SMOT_REQUIRE((long long)N * C < (1ll << 31), "xcorr: N*C too large");
     const int planes = N * C;
     hipStream_t st = (hipStream_t)stream;
-    const bool timed = (g_xc_events != nullptr) && (g_xc_used + 2 <= g_xc_capacity);
-    if (timed) (void)hipEventRecord(g_xc_events[g_xc_used], st);
+    timer_mark(0, 0, st);
     if (Rx == 30 && Rz == 15) {
         // SMOT_XCORR_VARIANT = wave | patch | pk (older kernels, A/B) | fill | compute (phase ablations of
         // the default two-planes-per-wave kernel): measurements only
@@ -665,9 +606,6 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
         SMOT_REQUIRE(smem <= 160 * 1024, "xcorr: plane too large for LDS (Rx=%d Rz=%d)", Rx, Rz);
         hipLaunchKernelGGL(xcorr_dw_generic_kernel, dim3(planes), dim3(256), smem, st, x, z, out, Rx, Rz);
     }
-    if (timed) {
-        (void)hipEventRecord(g_xc_events[g_xc_used + 1], st);
-        g_xc_used += 2;
-    }
+    timer_mark(0, 1, st);
     return check_launch("xcorr_dw");
 }

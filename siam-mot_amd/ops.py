@@ -42,6 +42,8 @@ _SIGNATURES = {
                                                _vp, _vp, _vp]),
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
+    "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i]),
+    "smot_kernel_timer_end": (ctypes.c_int, [_i, _vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                           _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
@@ -309,18 +311,29 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
     return templates, sr
 
 
+TIMER_XCORR, TIMER_TOWER = 0, 1
+
+
+def kernel_timer_begin(slot, max_launches):
+    """Start bracketing the kernels of ``slot`` with HIP events on their launch stream (bench.py)."""
+    _check(load_library().smot_kernel_timer_begin(int(slot), int(max_launches)), "kernel_timer_begin")
+
+
+def kernel_timer_end(slot):
+    """→ (total milliseconds inside the slot's kernels, launches timed)."""
+    tot = ctypes.c_double(0.0)
+    n = ctypes.c_int(0)
+    _check(load_library().smot_kernel_timer_end(int(slot), ctypes.cast(ctypes.byref(tot), ctypes.c_void_p),
+                                                ctypes.cast(ctypes.byref(n), ctypes.c_void_p)), "kernel_timer_end")
+    return tot.value, n.value
+
+
 def xcorr_timer_begin(max_launches):
-    """Start bracketing every xcorr launch with HIP events on its launch stream (bench.py)."""
-    _check(load_library().smot_xcorr_timer_begin(int(max_launches)), "xcorr_timer_begin")
+    kernel_timer_begin(TIMER_XCORR, max_launches)
 
 
 def xcorr_timer_end():
-    """→ (total milliseconds inside xcorr kernels, launches timed)."""
-    tot = ctypes.c_double(0.0)
-    n = ctypes.c_int(0)
-    _check(load_library().smot_xcorr_timer_end(ctypes.cast(ctypes.byref(tot), ctypes.c_void_p),
-                                               ctypes.cast(ctypes.byref(n), ctypes.c_void_p)), "xcorr_timer_end")
-    return tot.value, n.value
+    return kernel_timer_end(TIMER_XCORR)
 
 
 def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_ratio, pad_pixels, return_pooled=False):
