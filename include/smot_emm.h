@@ -166,6 +166,21 @@ int smot_emm_decode_fwd(const float* logits, const float* sr, const float* boxes
 int smot_emm_decode_ws_floats(int Ho, int up);
 
 /*
+ * Greedy IoU non-maximum suppression.
+ *
+ * Replaces [UPSTREAM] _C.nms(dets, scores, thresh) as reached through boxlist_nms from the solver
+ *   (track_head/track_solver.py:22), the RPN post-processor (operator_patch/rpn_patch.py:53) and the box
+ *   post-processor (box_head/inference.py:174).
+ *   boxes_sorted [n,4] xyxy, ALREADY sorted by descending score (the host layer sorts, as upstream's wrapper
+ *   does); IoU with the upstream +1 convention; box j is dropped when a kept earlier box i has
+ *   IoU(i,j) > thresh.  keep [n] bytes (1 = kept), in the sorted order.  mask_ws: smot_nms_ws_bytes(n)
+ *   bytes, 8-byte aligned.  n <= 8192.
+ */
+long long smot_nms_ws_bytes(int n);
+int smot_nms_fwd(const float* boxes_sorted, int n, float thresh, void* mask_ws, unsigned char* keep,
+                 smot_stream_t stream);
+
+/*
  * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd and
  * smot_sr_xcorr_fused_fwd launch — direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
  * stream (events are created in _begin, outside any timed region; at most max_launches pairs).

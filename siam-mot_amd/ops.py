@@ -40,6 +40,8 @@ _SIGNATURES = {
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
     "smot_sr_xcorr_fused_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                                _vp, _vp, _vp]),
+    "smot_nms_ws_bytes": (ctypes.c_longlong, [_i]),
+    "smot_nms_fwd": (ctypes.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
     "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i]),
@@ -356,3 +358,22 @@ def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_rati
                                      _ptr(resp), _ptr(pooled), _stream())
     _check(rc, "sr_xcorr_fused")
     return (resp, pooled) if return_pooled else resp
+
+
+def nms(boxes, scores, thresh):
+    """[UPSTREAM] ``_C.nms(dets, scores, thresh)`` semantics: indices of the kept boxes, ascending (original
+    order), after greedy suppression in descending-score order with the +1 IoU convention.  One host sync
+    (the number of kept boxes), as in the reference."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    scores = _dev_f32(scores, "scores")
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    sorted_boxes = boxes[order].contiguous()
+    ws = torch.empty((max(lib.smot_nms_ws_bytes(n) // 8, 1),), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
+    rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), _stream())
+    _check(rc, "nms")
+    return order[keep.bool()].sort()[0]

@@ -153,3 +153,16 @@ def cat_boxlist(bboxes):
     for f in fields:
         out.add_field(f, cat([b.get_field(f) for b in bboxes], dim=0))
     return out
+
+
+def boxlist_nms(boxlist, nms_thresh, max_proposals=-1, score_field="scores"):
+    """[UPSTREAM] ``structures.boxlist_ops.boxlist_nms`` on the HIP NMS kernel (device BoxLists only)."""
+    if nms_thresh <= 0:
+        return boxlist
+    from . import ops
+    mode = boxlist.mode
+    boxlist = boxlist.convert("xyxy")
+    keep = ops.nms(boxlist.bbox, boxlist.get_field(score_field), nms_thresh)
+    if max_proposals > 0:
+        keep = keep[:max_proposals]
+    return boxlist[keep].convert(mode)

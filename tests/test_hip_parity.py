@@ -543,3 +543,70 @@ def test_generic_roi_kernel_still_matches(ops, golden_dir, monkeypatch):
     _assert_close(z_gen, z_ref, 1e-5, 1e-5, "generic ROIAlign vs oracle")
     _assert_close(z_sep, z_ref, 1e-5, 1e-5, "separable ROIAlign vs oracle")
     _assert_close(z_sep, z_gen, 1e-5, 1e-5, "separable vs generic")
+
+
+def test_box_head_pooler_7x7(ops):
+    """the box head's Pooler (7x7, 4 FPN levels, level from the roi itself) on the
+    ROIAlign kernel — 300 proposals on 720p-shaped maps (C=16 to keep the oracle quick) plus the track
+    boxes of _refine_tracks."""
+    from siammot_amd.poolers import Pooler
+    from siammot_amd.structures import BoxList
+    rs = np.random.RandomState(41)
+    shapes = [(176, 320), (88, 160), (44, 80), (22, 40)]
+    feats = [_t(rs.standard_normal((1, 16, h, w)).astype(np.float32)) for h, w in shapes]
+    wh = np.exp(rs.uniform(np.log(8), np.log(600), (300, 2)))
+    xy = rs.uniform(-40, 1200, (300, 2)) * np.array([1.0, 0.55])
+    props = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    pooler = Pooler(7, (0.25, 0.125, 0.0625, 0.03125), 2)
+    out = pooler([f.to(DEV) for f in feats], [BoxList(_d(props), (1280, 704))])
+    ref = O.sr_pool(feats, _t(props), None, 7, (0.25, 0.125, 0.0625, 0.03125), 2)
+    assert tuple(out.shape) == (300, 16, 7, 7)
+    _assert_close(out, ref, 1e-5, 1e-5, "box-head Pooler 7x7")
+    lv = O.level_mapper(_t(props))
+    assert len(set(lv.tolist())) == 4           # all four levels exercised
+
+
+def _nms_reference(boxes, scores, thresh):
+    """[UPSTREAM] nms_cpu.cpp / nms.cu restated on numpy: greedy in descending-score order, +1 areas,
+    suppress when IoU > thresh (CUDA convention), kept indices ascending."""
+    order = np.argsort(-scores, kind="stable")
+    b = boxes[order].astype(np.float32)
+    area = (b[:, 2] - b[:, 0] + np.float32(1)) * (b[:, 3] - b[:, 1] + np.float32(1))
+    n = len(b)
+    sup = np.zeros(n, bool)
+    for i in range(n):
+        if sup[i]:
+            continue
+        w = np.maximum(np.minimum(b[i, 2], b[i + 1:, 2]) - np.maximum(b[i, 0], b[i + 1:, 0]) + np.float32(1), 0)
+        h = np.maximum(np.minimum(b[i, 3], b[i + 1:, 3]) - np.maximum(b[i, 1], b[i + 1:, 1]) + np.float32(1), 0)
+        inter = (w * h).astype(np.float32)
+        iou_ = inter / (area[i] + area[i + 1:] - inter)
+        sup[i + 1:] |= iou_ > np.float32(thresh)
+    return np.sort(order[~sup])
+
+
+@pytest.mark.parametrize("n,thresh", [(1, 0.5), (63, 0.5), (64, 0.5), (65, 0.3), (300, 0.5), (1000, 0.7), (2500, 0.5)])
+def test_nms_vs_reference(ops, n, thresh):
+    rs = np.random.RandomState(n)
+    centers = rs.uniform(0, 600, (max(n // 6, 1), 2))                       # clustered: plenty of overlaps
+    c = centers[rs.randint(0, len(centers), n)] + rs.normal(0, 12, (n, 2))
+    wh = rs.uniform(20, 120, (n, 2))
+    boxes = np.concatenate((c - wh / 2, c + wh / 2), 1).astype(np.float32)
+    scores = rs.permutation(n).astype(np.float32) / n + 0.001                # distinct scores: no sort ties
+    keep = ops.nms(_d(boxes), _d(scores), thresh).cpu().numpy()
+    ref = _nms_reference(boxes, scores, thresh)
+    assert keep.tolist() == ref.tolist(), "n=%d: %d kept vs %d" % (n, len(keep), len(ref))
+    assert 0 < len(keep) <= n
+
+
+def test_nms_boxlist_and_edges(ops):
+    from siammot_amd.structures import BoxList, boxlist_nms
+    e = ops.nms(torch.zeros((0, 4), device=DEV), torch.zeros((0,), device=DEV), 0.5)
+    assert e.numel() == 0
+    b = BoxList(_d(np.array([[0, 0, 10, 10], [1, 1, 11, 11], [50, 50, 60, 60], [0, 0, 10, 10]], np.float32)), (100, 100))
+    b.add_field("scores", _d(np.array([0.9, 0.8, 0.7, 0.95], np.float32)))
+    b.add_field("ids", torch.arange(4, device=DEV))
+    out = boxlist_nms(b, 0.5)
+    assert out.get_field("ids").cpu().tolist() == [2, 3]         # box 3 (highest) suppresses its duplicate 0 and box 1
+    assert len(boxlist_nms(b, 0.5, max_proposals=1)) == 1
+    assert boxlist_nms(b, -1.0) is b
