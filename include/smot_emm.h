@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 1
+#define SMOT_ABI_VERSION 2
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -125,14 +125,25 @@ int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const
  *   tower_ws  [N, 2C, Ho, Ho] caller-owned workspace (cls tower in channels [0,C), reg in [C,2C))
  *   logits    [N, 7, Ho, Ho]  channel order: cls0, cls1, center, reg_l, reg_t, reg_r, reg_b
  * Requires C % gn_groups == 0.
+ *
+ *   tower_packed: optional (may be NULL) output of smot_emm_tower_pack for the SAME tower weights: the
+ *   Winograd F(2x2,3x3)-transformed tower filters in the order the matrix-core kernel consumes them.
+ *   With it (and Ho == 16) the towers run as a Winograd convolution on the fp32 matrix cores — all-fp32
+ *   arithmetic, 2.25x fewer multiplies, results equal to the direct convolution up to fp32 rounding
+ *   order; without it the direct fp32 kernel runs.  It is a pure function of the two tower weight
+ *   tensors: recompute it whenever they change (the Python layer keys it on the tensors' versions).
  */
+long long smot_emm_tower_pack_floats(int C);      /* 2*C*C*16 for C % 16 == 0, else 0 (no packed path) */
+int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
+                        smot_stream_t stream);
+
 int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho,
                            const float* cls_tower_w, const float* cls_gn_w, const float* cls_gn_b,
                            const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
                            const float* cls_w, const float* cls_b,
                            const float* center_w, const float* center_b,
                            const float* reg_w, const float* reg_b,
-                           int gn_groups, float gn_eps,
+                           int gn_groups, float gn_eps, const float* tower_packed,
                            float* tower_ws, float* logits, smot_stream_t stream);
 
 /*
@@ -201,10 +212,11 @@ int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
  *   pad_feature (virtual) + SRPooler on the search regions -> xcorr_depthwise -> EMMPredictor ->
  *   bicubic x`up` + get_locations + decode_response -> clip of wrap_results_to_boxlist.
  *   boxes     [N,4] template boxes (pick the FPN level, scale penalty), sr [N,4] search regions
- *   templates [N,C,rz,rz] (track memory), predictor_params: HOST array of the 12 device pointers in
+ *   templates [N,C,rz,rz] (track memory), predictor_params: HOST array of 13 device pointers: the 12 parameters in
  *   the order cls_tower.0.weight, cls_tower.1.weight, cls_tower.1.bias, reg_tower.0.weight,
  *   reg_tower.1.weight, reg_tower.1.bias, cls.weight, cls.bias, center.weight, center.bias,
- *   reg.weight, reg.bias.   ws: smot_emm_track_ws_floats(N,C,rx,rz) floats, 16-byte aligned.
+ *   reg.weight, reg.bias, followed by a 13th entry: the smot_emm_tower_pack image of the tower weights
+ *   or NULL (see smot_emm_predictor_fwd).   ws: smot_emm_track_ws_floats(N,C,rx,rz) floats, 16-byte aligned.
  *   Remaining arguments as in the per-operator calls above.
  *
  * smot_emm_extract_cache_fwd replaces EMM.extract_cache (EMM/track_core.py:81-98): template pooling

@@ -12,8 +12,8 @@ namespace smot {
 int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tower_w, const float* cls_gn_w,
                    const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
-                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps, float* tower_ws,
-                   float* logits, smot_stream_t stream, int* tiles_out);
+                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
+                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out);
 int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
                 int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
                 float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, hipStream_t st);
@@ -69,7 +69,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     // decode kernels sum them while loading (no combine launch, no logits round trip)
     int tiles = 0;
     rc = predictor_impl(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11],
-                        gn_groups, gn_eps, tower, logits, stream, &tiles);
+                        gn_groups, gn_eps, p[12], tower, logits, stream, &tiles);
     if (rc) return rc;
     LogitSrc L;
     L.logits = tiles > 0 ? nullptr : logits;

@@ -19,37 +19,15 @@
 // Heads: 7 output channels, 4 MFLOP/track — plain VALU from LDS-staged tower planes, head weights
 // as wave-uniform scalar loads.
 // A generic (any Ho / channel count) tower kernel covers shapes the MFMA tiling does not.
-#include "smot_common.h"
+#include "tower_common.h"
 #include <stdlib.h>
 
 namespace smot {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int T_IC = 16;                          // input channels per K chunk
 constexpr int T_STEPS = 9 * (T_IC / 4);           // MFMA k-steps per chunk (36)
-constexpr int T_PLANE = 336;                      // 18*18 = 324 padded to 336
 constexpr int T_B_FLOATS = T_IC * T_PLANE;        // 5376
 constexpr int T_B_PER_THREAD = T_IC;              // one position of each plane per thread
-
-struct TowerParams {
-    const float* w[2];      // [C, C, 3, 3] cls_tower.0.weight / reg_tower.0.weight
-    const float* gamma[2];  // [C]
-    const float* beta[2];   // [C]
-    // head filters (fused partial heads): cls [2,C,3,3], center [1,C,3,3], reg [4,C,3,3]
-    const float* cls_w;
-    const float* center_w;
-    const float* reg_w;
-};
-
-__device__ __forceinline__ float group16_sum(float v) {
-    // sum over the 16 lanes that share lane>>4
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    return v;
-}
 
 // MT = number of 16-channel M tiles per workgroup (output-channel tile T_OC = 16*MT).
 // MT = 2 halves the B-operand traffic per MFMA; MT = 1 doubles the number of workgroups, which is
@@ -516,8 +494,8 @@ namespace smot {
 int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tower_w, const float* cls_gn_w,
                    const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
-                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps, float* tower_ws,
-                   float* logits, smot_stream_t stream, int* tiles_out) {
+                   const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
+                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out) {
     if (tiles_out) *tiles_out = 0;
     SMOT_REQUIRE(N >= 0 && C > 0 && Ho > 0 && gn_groups > 0, "predictor: bad sizes N=%d C=%d Ho=%d groups=%d", N, C,
                  Ho, gn_groups);
@@ -541,12 +519,13 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
     T.reg_w = reg_w;
     const bool pow2 = (C & (C - 1)) == 0;      // tile counts 1,2,4,...: what heads_combine is built for
     const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && pow2 && (C <= 512) && (cpg <= 16) && (16 % cpg == 0);
+    const bool wino = mfma_ok && tower_packed != nullptr && getenv("SMOT_TOWER_DIRECT") == nullptr;
     if (mfma_ok) {
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
         const int blocks32 = N * 2 * (C / 32);
         // measured (profiles/r01_m): 16-channel tiles 1.79 us/track @N=30; 32-channel tiles 2.06 us/track @N=100
-        const bool narrow = blocks32 < 2 * 256 || getenv("SMOT_TOWER_WIDE") == nullptr;
+        const bool narrow = wino || blocks32 < 2 * 256 || getenv("SMOT_TOWER_WIDE") == nullptr;
         const int mt = narrow ? 1 : 2;
         const int tiles_per_tower = C / (16 * mt);
         const size_t smem = (size_t)2 * (T_STEPS * mt * 64 + T_B_FLOATS) * sizeof(float);
@@ -559,7 +538,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};   // one opt-in per kernel
         bool seen = false;
         for (const void* d : attr_done) seen = seen || (d == fn);
-        if (!seen) {
+        if (!seen && !wino) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) {
                 set_error("predictor: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -574,7 +553,11 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         // tower_ws holds the per-tile partial head sums [N][2*tiles_per_tower][4][256] (<= N*2C*256 floats)
         const dim3 tg(N * 2 * tiles_per_tower);
         timer_mark(1, 0, st);
-        if (!narrow) {
+        if (wino) {
+            SMOT_REQUIRE(((uintptr_t)tower_packed & 15) == 0, "predictor: tower_packed must be 16-byte aligned");
+            int rcw = launch_tower_wino(resp, tower_packed, T, N, C, cpg, gn_eps, tower_ws, st);
+            if (rcw) return rcw;
+        } else if (!narrow) {
             hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         } else if (abl == 1) {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 1>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
@@ -641,9 +624,10 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
                                       const float* reg_gn_w, const float* reg_gn_b, const float* cls_w,
                                       const float* cls_b, const float* center_w, const float* center_b,
                                       const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
-                                      float* tower_ws, float* logits, smot_stream_t stream) {
+                                      const float* tower_packed, float* tower_ws, float* logits,
+                                      smot_stream_t stream) {
     return smot::predictor_impl(resp, N, C, Ho, cls_tower_w, cls_gn_w, cls_gn_b, reg_tower_w, reg_gn_w, reg_gn_b, cls_w,
-                                cls_b, center_w, center_b, reg_w, reg_b, gn_groups, gn_eps, tower_ws, logits, stream,
-                                nullptr);
+                                cls_b, center_w, center_b, reg_w, reg_b, gn_groups, gn_eps, tower_packed, tower_ws,
+                                logits, stream, nullptr);
 }
 

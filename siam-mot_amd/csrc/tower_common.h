@@ -1,0 +1,34 @@
+// Shared by the tower kernels (predictor.hip, tower_wino.hip).
+#pragma once
+#include "smot_common.h"
+
+namespace smot {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct TowerParams {
+    const float* w[2];      // [C, C, 3, 3] cls_tower.0.weight / reg_tower.0.weight
+    const float* gamma[2];  // [C]
+    const float* beta[2];   // [C]
+    // head filters (fused partial heads): cls [2,C,3,3], center [1,C,3,3], reg [4,C,3,3]
+    const float* cls_w;
+    const float* center_w;
+    const float* reg_w;
+};
+
+__device__ __forceinline__ float group16_sum(float v) {
+    // sum over the 16 lanes that share lane>>4
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+constexpr int T_PLANE = 336;                      // 18*18 = 324 padded to 336
+
+// tower_wino.hip
+int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
+                      float* part, hipStream_t st);
+
+}  // namespace smot

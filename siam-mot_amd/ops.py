@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -34,7 +34,9 @@ _SIGNATURES = {
                                                  _vp, _vp, _vp]),
     "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
     "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp]),
+    "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp, _vp]),
+    "smot_emm_tower_pack_floats": (ctypes.c_longlong, [_i]),
+    "smot_emm_tower_pack": (ctypes.c_int, [_vp, _vp, _i, _vp, _vp]),
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
                                            _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
@@ -172,9 +174,37 @@ PREDICTOR_KEYS = (
 )
 
 
-def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5):
+_pack_cache = {}
+
+
+def tower_packed(params):
+    """Winograd-transformed tower filters (``smot_emm_tower_pack``) for the matrix-core tower kernel, cached per
+    pair of weight tensors and recomputed when either is modified in place (``load_state_dict``) or replaced
+    (``.to()``).  ``None`` when the channel count has no packed path."""
+    lib = load_library()
+    wc = _dev_f32(params["cls_tower.0.weight"], "cls_tower.0.weight")
+    wr = _dev_f32(params["reg_tower.0.weight"], "reg_tower.0.weight")
+    C = wc.shape[0]
+    nfl = lib.smot_emm_tower_pack_floats(C)
+    if nfl == 0 or tuple(wc.shape) != (C, C, 3, 3) or tuple(wr.shape) != (C, C, 3, 3):
+        return None
+    key = (wc.data_ptr(), wr.data_ptr())
+    ver = (wc._version, wr._version)
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    packed = torch.empty((nfl,), dtype=torch.float32, device=wc.device)
+    _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), _stream()), "tower_pack")
+    if len(_pack_cache) > 16:
+        _pack_cache.clear()
+    _pack_cache[key] = (ver, packed)
+    return packed
+
+
+def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5, winograd=True):
     """``resp [N,C,Ho,Ho]`` + reference-keyed ``params`` → logits ``[N,7,Ho,Ho]``
-    (cls0, cls1, center, reg l/t/r/b; reg already ReLU'd)."""
+    (cls0, cls1, center, reg l/t/r/b; reg already ReLU'd).  ``winograd=False`` forces the direct fp32
+    tower kernel (same result up to fp32 rounding order)."""
     lib = load_library()
     resp = _dev_f32(resp, "resp")
     N, C, Ho, _ = resp.shape
@@ -186,8 +216,9 @@ def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5):
                                % (PREDICTOR_KEYS[i], tuple(w[i].shape), shp))
     tower_ws = torch.empty((N, 2 * C, Ho, Ho), dtype=torch.float32, device=resp.device)
     logits = torch.empty((N, 7, Ho, Ho), dtype=torch.float32, device=resp.device)
+    packed = tower_packed(params) if (winograd and Ho == 16) else None
     rc = lib.smot_emm_predictor_fwd(_ptr(resp), N, C, Ho, *[_ptr(t) for t in w], int(gn_groups), float(gn_eps),
-                                    _ptr(tower_ws), _ptr(logits), _stream())
+                                    _ptr(packed), _ptr(tower_ws), _ptr(logits), _stream())
     _check(rc, "emm_predictor")
     return logits
 
@@ -263,7 +294,8 @@ def _workspace(device, n_floats):
 
 
 def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_ratio, pad_pixels,
-              sigma=0.4, use_centerness=True, clip_wh=None, gn_groups=32, gn_eps=1e-5, return_index=False):
+              sigma=0.4, use_centerness=True, clip_wh=None, gn_groups=32, gn_eps=1e-5, return_index=False,
+              winograd=True):
     """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``)."""
     lib = load_library()
     boxes = _dev_f32(boxes, "boxes")
@@ -279,8 +311,9 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     L = len(scales)
     pc = (ctypes.c_int * L)(*[int(pad_pixels / ((2 ** i) * 4)) for i in range(L)])
     w = [_dev_f32(params[k], k) for k in PREDICTOR_KEYS]
-    pp = (ctypes.c_void_p * 12)(*[t.data_ptr() for t in w])
     ho = rx - rz + 1
+    packed = tower_packed(params) if (winograd and ho == 16) else None
+    pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in w] + [packed.data_ptr() if packed is not None else None]))
     work = _workspace(dev, lib.smot_emm_track_ws_floats(N, C, rx, rz))
     bb = torch.empty((N, 4), dtype=torch.float32, device=dev)
     conf = torch.empty((N,), dtype=torch.float32, device=dev)

@@ -235,14 +235,16 @@ def test_xcorr_rejects_bad_inputs(ops):
 # ------------------------------------------------------------------------------------------------
 # K3: predictor
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,c,ho", [(3, 64, 16), (2, 128, 16), (1, 256, 16), (2, 32, 29), (2, 96, 16)])
-def test_predictor_vs_oracle(ops, n, c, ho):
-    """MFMA tiling (Ho=16, C in {64,128,256}) and the generic kernel (Ho=29; C=96 -> 3 ch/group)."""
+@pytest.mark.parametrize("winograd", [True, False])
+@pytest.mark.parametrize("n,c,ho", [(3, 64, 16), (2, 128, 16), (1, 256, 16), (2, 32, 29), (2, 96, 16), (9, 128, 16)])
+def test_predictor_vs_oracle(ops, n, c, ho, winograd):
+    """Matrix-core towers (Ho=16, C in {64,128,256}: Winograd F(2x2,3x3) with the packed filters, or the direct
+    kernel) and the generic kernel (Ho=29; C=96 -> 3 ch/group).  Same tolerance for both tower kernels."""
     rs = np.random.RandomState(100 + c + ho)
     boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
     params = gi.predictor_params(rs, c, boxes)
     resp = (rs.standard_normal((n, c, ho, ho)) * 15.0).astype(np.float32)
-    logits = ops.emm_predictor(_d(resp), {k: _d(v) for k, v in params.items()}).cpu()
+    logits = ops.emm_predictor(_d(resp), {k: _d(v) for k, v in params.items()}, winograd=winograd).cpu()
     p64 = {k: _t(v, torch.float64) for k, v in params.items()}
     cls, center, reg = O.predictor(_t(resp, torch.float64), p64)
     ref = torch.cat((cls, center, reg), 1)
@@ -253,6 +255,26 @@ def test_predictor_vs_oracle(ops, n, c, ho):
     c32, ce32, r32 = O.predictor(_t(resp), {k: _t(v) for k, v in params.items()})
     ref32 = torch.cat((c32, ce32, r32), 1)
     assert float(((logits - ref32).abs() / scale.float()).max()) < 2e-4
+
+
+def test_tower_pack_cache_follows_the_weights(ops):
+    """The packed (Winograd-transformed) filters are a cache keyed on the weight tensors: an in-place update
+    (load_state_dict) or a replacement must be picked up, otherwise stale filters would be used silently."""
+    rs = np.random.RandomState(5)
+    boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+    pa = {k: _d(v) for k, v in gi.predictor_params(rs, 64, boxes).items()}
+    pb = {k: _d(v) for k, v in gi.predictor_params(rs, 64, boxes).items()}
+    resp = _d((rs.standard_normal((2, 64, 16, 16)) * 15.0).astype(np.float32))
+    la = ops.emm_predictor(resp, pa)
+    lb = ops.emm_predictor(resp, pb)
+    assert not torch.equal(la, lb)
+    assert ops.tower_packed(pa) is ops.tower_packed(pa)                  # cached
+    for k in pa:
+        pa[k].copy_(pb[k])                                                # in place: same pointers, new version
+    assert torch.equal(ops.emm_predictor(resp, pa), lb)
+    direct = ops.emm_predictor(resp, pb, winograd=False)
+    scale = direct.abs().amax(dim=(0, 2, 3), keepdim=True)
+    assert float(((lb - direct).abs() / scale).max()) < 2e-5             # the two tower kernels agree
 
 
 def test_predictor_module_views_and_state_dict(ops):
@@ -428,6 +450,57 @@ def test_emm_full_size_against_oracle(ops):
                                 sr_ref, z_ref, case["image_wh"])
     assert (iou(result[0].bbox.cpu().numpy(), bb.numpy()) >= 1 - 1e-3).all()
     _assert_close(result[0].get_field("scores"), conf, 0, 1e-4, "scores vs oracle")
+
+
+@pytest.mark.parametrize("label,channels,image_wh,n", [("config3", 128, (1280, 704), 100), ("config5", 256, (1920, 1056), 50)])
+def test_emm_configs_3_and_5(ops, label, channels, image_wh, n):
+    """BASELINE.json configs[2] (720p, 100 tracks) and configs[4] (R-50-FPN: C=256, 1080p net input, 50 tracks).
+    Tracks are independent, so the oracle checks a 6-track sample (one per box size + the level-3 size) and the
+    full set is checked through order-equivariance: permuting the tracks permutes the results bit for bit."""
+    from siammot_amd.structures import BoxList
+    case = dict(gi.EMM_CASES["default"], channels=channels, image_wh=image_wh)
+    rs = np.random.RandomState(n)
+    shapes = gi.feature_shapes(image_wh, channels)
+    feats_a = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    feats_b = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    sizes = [(32, 64), (64, 128), (100, 200), (160, 320), (320, 640)]
+    boxes = []
+    for i in range(n):
+        w, h = sizes[i % 5] if i < 10 else sizes[i % 4]
+        x1 = rs.uniform(0, image_wh[0] - w - 1)
+        y1 = rs.uniform(0, image_wh[1] - h - 1)
+        boxes.append([x1, y1, x1 + w, y1 + h])
+    boxes = np.array(boxes, dtype=np.float32)
+    params = gi.predictor_params(rs, channels, boxes)
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in params.items()})
+    fa, fb = tuple(_d(f) for f in feats_a), tuple(_d(f) for f in feats_b)
+
+    def run(order):
+        det = BoxList(_d(boxes[order]), image_wh, mode="xyxy")
+        det.add_field("ids", torch.as_tensor(order, device=DEV))
+        det.add_field("labels", torch.ones(len(order), dtype=torch.int64, device=DEV))
+        with torch.no_grad():
+            z, sr, det_out = emm.extract_cache(fa, det)
+            _, result, _ = emm(fb, det_out, sr, template_features=z)
+        return z, sr[0].bbox, result[0]
+
+    ident = np.arange(n)
+    z0, sr0, res0 = run(ident)
+    perm = rs.permutation(n)
+    z1, sr1, res1 = run(perm)
+    assert torch.equal(z1, z0[perm]) and torch.equal(sr1, sr0[perm])
+    assert torch.equal(res1.bbox, res0.bbox[perm]) and torch.equal(res1.get_field("scores"), res0.get_field("scores")[perm])
+    assert res1.get_field("ids").cpu().tolist() == perm.tolist()
+
+    sample = np.array([0, 1, 2, 3, 4, n - 1])
+    cfg = _cfg(case)
+    z_ref, sr_ref = O.extract_cache(cfg, [_t(f) for f in feats_a], _t(boxes[sample]))
+    _assert_close(z0[sample], z_ref, 1e-5, 1e-5, label + " templates vs oracle")
+    bb, conf, _ = O.emm_forward(cfg, {k: _t(v) for k, v in params.items()}, [_t(f) for f in feats_b],
+                                _t(boxes[sample]), sr_ref, z_ref, image_wh)
+    assert (iou(res0.bbox.cpu().numpy()[sample], bb.numpy()) >= 1 - 1e-3).all()
+    _assert_close(res0.get_field("scores")[sample], conf, 0, 1e-4, label + " scores vs oracle")
 
 
 def test_emm_training_mode_is_refused(ops):

@@ -49,8 +49,10 @@ def test_argument_errors_are_reported_without_a_device():
     rc = lib.smot_emm_decode_fwd(null, null, null, null, 1, 16, 16, 30, 14, 512.0, 0.6, 0.4, 1, 0.0, 0.0,
                                  null, null, null, null, null)                  # even rz / Ho mismatch
     assert rc == -1
-    rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null)
+    rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null, null)
     assert rc == -1 and b"divisible" in lib.smot_last_error()
+    assert lib.smot_emm_tower_pack_floats(128) == 2 * 128 * 128 * 16 and lib.smot_emm_tower_pack_floats(100) == 0
+    assert lib.smot_emm_tower_pack(null, null, 100, null, null) == -1
     assert lib.smot_emm_decode_ws_floats(16, 16) == 34
 
 

@@ -88,10 +88,12 @@ def main():
             os.environ.pop("SMOT_XCORR_VARIANT", None)
             t = timed(lambda: ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512), batch=50)
             rec("sr_pool+xcorr fused", "default", t)
-            rec("predictor", "default", timed(lambda: ops.emm_predictor(resp, params)))
+            rec("predictor", "winograd", timed(lambda: ops.emm_predictor(resp, params)))
+            rec("predictor", "direct", timed(lambda: ops.emm_predictor(resp, params, winograd=False)))
             for abl in ("1", "2"):
                 os.environ["SMOT_TOWER_ABL"] = abl
-                rec("predictor", "ablation %s" % abl, timed(lambda: ops.emm_predictor(resp, params)))
+                rec("predictor", "direct ablation %s" % abl,
+                    timed(lambda: ops.emm_predictor(resp, params, winograd=False)))
             os.environ.pop("SMOT_TOWER_ABL", None)
             rec("decode", "default", timed(lambda: ops.emm_decode(logits, sr, boxes, 30, 15, 512)))
             rec("search_region", "default", timed(lambda: ops.search_region(boxes, 512, 1.0, 0)))
