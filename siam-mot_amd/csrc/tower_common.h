@@ -5,6 +5,7 @@
 namespace smot {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct TowerParams {
     const float* w[2];      // [C, C, 3, 3] cls_tower.0.weight / reg_tower.0.weight

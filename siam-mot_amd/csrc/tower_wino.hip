@@ -17,28 +17,31 @@
 //   wave w    = xi row i = w (4 xi) x 4 N-tiles of 16 tiles  -> 16 accumulator tiles (64 AGPRs).
 //   A operand = U, transformed ONCE per parameter set by tower_pack_kernel into the exact per-lane order the
 //               waves consume (one coalesced 16-byte load per lane and 4-channel k-step, straight to VGPRs).
-//   B operand = V, built in registers: lane (ic = lane/16, tile = 16t + lane%16) reads two rows of its 4x4
-//               input patch from LDS (only the two rows the wave's xi-row needs: 8 ds_read_b64 per k-step),
-//               5 adds per operand.  The transformed input never exists in memory.
-//   LDS       = raw response planes only (16 channels per stage, zero-haloed 18 x 24 rows, plane stride 480
-//               = 32 mod 64 banks: conflict-free 64-bit patch reads), double-buffered, one barrier per 16
-//               input channels; the stage after next is in flight in registers.
+//   B operand = V, built in registers: a lane owns one input channel of the k-step and two horizontally
+//               adjacent tiles per pair of N-tiles; it reads only the two patch rows the wave's xi-row
+//               combines (one ds_read_b128 + one ds_read_b64 per row and tile pair) and spends 14 adds per
+//               8 operands.  The transformed input never exists in memory.
+//   LDS       = raw response planes only (8 channels per stage, zero-haloed 18 x 24 rows, plane stride 448),
+//               ring of four stages, one barrier per stage; two further stages are in flight in registers.
 //   epilogue  = output transform (column half in registers, row half across the waves through LDS), two-pass
 //               GroupNorm + affine + ReLU, fused partial heads exactly as in predictor.hip.
 #include "tower_common.h"
+#include <stdlib.h>
 
 namespace smot {
 
 constexpr int W_ROW = 24;                 // floats per LDS row (18 used)
-constexpr int W_PLANE = 480;              // 18 rows * 24 = 432, padded: plane stride = 32 (mod 64) banks
-constexpr int W_STAGE_IC = 16;            // input channels per LDS stage
-constexpr int W_BUF = W_STAGE_IC * W_PLANE;      // 7680 floats
+constexpr int W_PLANE = 448;              // 18 rows * 24 = 432, padded: plane stride = 0 (mod 64) banks, see W_READ
+constexpr int W_STAGE_IC = 8;             // input channels per LDS stage (2 k-steps)
+constexpr int W_RING = 4;                 // stage buffers
+constexpr int W_BUF = W_STAGE_IC * W_PLANE;      // 3840 floats
 constexpr int W_XOC = 68;                 // oc stride of the exchange image (4*68 = 16 mod 64 banks)
 constexpr int W_X_FLOATS = 4 * 2 * 16 * W_XOC;   // 8704
 constexpr int W_PL_OFF = W_X_FLOATS;             // head planes [16][336]
 constexpr int W_HW_OFF = W_PL_OFF + 16 * T_PLANE;   // head taps [16*9][4]
 constexpr int W_ST_OFF = W_HW_OFF + 16 * 36;        // channel sums [16], [16]
-static_assert(W_ST_OFF + 32 <= 2 * W_BUF, "epilogue overlays the stage buffers");
+constexpr int W_SMEM_FLOATS = (W_ST_OFF + 32 > W_RING * W_BUF) ? W_ST_OFF + 32 : W_RING * W_BUF;   // epilogue overlays the ring
+static_assert(W_SMEM_FLOATS * 4 <= 64 * 1024, "two workgroups per CU, no opt-in needed");
 
 // packed[tile][k = ic/4][wave][lane][q] = (G g G^T)[i = wave][j = q] of g = W[oc = 16*tile + lane%16][ic = 4k + lane/16]
 // (oc counts cls_tower channels first, then reg_tower).  One thread per (oc, ic).
@@ -70,11 +73,18 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
     }
 }
 
-__global__ void __launch_bounds__(256)
+// ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
+// loads inside the loop, 3 = no LDS reads / operand transform, 4 = no MFMAs, 5 = MFMAs + barriers only,
+// 6 = MFMAs only.  SMOT_WINO_ABL=n selects.
+template <int ABL>
+__global__ void __launch_bounds__(256, 2)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
-                  int cpg, float eps, float* __restrict__ part) {
+                  int cpg, float eps, float* __restrict__ part, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
+#define W_TRACE(SLOT) \
+    if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    W_TRACE(0)
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_per_tower = C >> 4;
@@ -90,9 +100,9 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int nk = C >> 2;
     const int nstages = C / W_STAGE_IC;
 
-    {   // zero both stage buffers once: the halos stay zero for the whole main loop
+    {   // zero the stage buffers once: the halos stay zero for the whole main loop
         float4* z = reinterpret_cast<float4*>(sm);
-        for (int e = tid; e < 2 * W_BUF / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < W_RING * W_BUF / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // head taps of this tile's channels, fetched now, used in the epilogue: hw[(ocl*9+tap)*4 + o]
     float hwreg[3];
@@ -115,17 +125,18 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         hwreg[j] = v;
     }
 
-    float4 pr[4];
-    auto load_raw = [&](int g) {
+    // ---- staging: ring of four 8-channel stages of raw response planes --------------------------------
+    float4 prs[2][2];                         // two stages in flight in registers
+    auto load_raw = [&](int st, float4* pr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int f = tid + 256 * j;
-            pr[j] = *reinterpret_cast<const float4*>(in + (size_t)(W_STAGE_IC * g + (f >> 6)) * 256 + (f & 63) * 4);
+            pr[j] = *reinterpret_cast<const float4*>(in + (size_t)(W_STAGE_IC * st + (f >> 6)) * 256 + (f & 63) * 4);
         }
     };
-    auto store_raw = [&](float* buf) {
+    auto store_raw = [&](float* buf, const float4* pr) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 2; ++j) {
             const int f = tid + 256 * j;
             const int f4 = f & 63;
             float* d = buf + (f >> 6) * W_PLANE + ((f4 >> 2) + 1) * W_ROW + 1 + (f4 & 3) * 4;
@@ -136,10 +147,10 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         }
     };
     const float* __restrict__ ua = packed + (((size_t)tile * nk) * 4 + wave) * 256 + lane * 4;   // + k*1024
-    f32x4 ac[4], an[4];
-    auto load_a = [&](int g, f32x4* dst) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(ua + (size_t)(4 * g + q) * 1024);
+    f32x4 aset[2][2];                         // A operands: the stage in use and the next one
+    auto load_a = [&](int st, f32x4* dst) {
+        dst[0] = *reinterpret_cast<const f32x4*>(ua + (size_t)(2 * st) * 1024);
+        dst[1] = *reinterpret_cast<const f32x4*>(ua + (size_t)(2 * st + 1) * 1024);
     };
 
     f32x4 acc[4][4];
@@ -148,58 +159,140 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_raw(0);
-    load_a(0, ac);
+    load_raw(0, prs[0]);
+    load_raw(1, prs[1]);
+    load_a(0, aset[0]);
+    if (ABL == 2 || ABL >= 5) {
+        aset[1][0] = aset[0][0]; aset[1][1] = aset[0][1];
+    }
     __syncthreads();                       // zero fill complete before interior writes
-    store_raw(sm);
-    if (nstages > 1) load_raw(1);
+    store_raw(sm, prs[0]);
+    store_raw(sm + W_BUF, prs[1]);
+    load_raw(min(2, nstages - 1), prs[0]);
+    load_raw(min(3, nstages - 1), prs[1]);
     __syncthreads();
 
     // rows of the 4x4 patch this wave's xi-row combines:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
     const int row_a = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
     const int row_b = (wave == 2) ? 1 : ((wave == 3) ? 3 : 2);
-    const float sgn = (wave == 1) ? 1.0f : -1.0f;
     const int kq = lane >> 4, xl = lane & 15;
-    // tile (ty, tx) = (2t + xl/8, xl%8): patch origin (haloed coordinates) row 2*ty, column 2*tx
-    const int patch0 = kq * W_PLANE + (2 * (xl >> 3)) * W_ROW + 2 * (xl & 7);
-    const int off_a = patch0 + row_a * W_ROW, off_b = patch0 + row_b * W_ROW;
+    // Lane (kq, xl) supplies input channel kq of the k-step and, for N-tile t, the 2x2-output tile
+    //     ty = xl/4 + 4*(t/2),  tx = 2*(xl%4) + (t%2):
+    // t = 2p and 2p+1 are horizontal neighbours, so one 6-float row segment (one ds_read_b128 + one
+    // ds_read_b64, both naturally aligned: haloed column 4*(xl%4)) serves both.  Banks: row stride 24 and
+    // plane stride 448 put the four (plane, tile-row) classes of every 16-lane b128 group on disjoint
+    // 16-bank windows; the b64 halves of planes 0/1 collide 2-way (4 instead of 2 LDS cycles).
+    const int patch0 = kq * W_PLANE + (2 * (xl >> 2)) * W_ROW + 4 * (xl & 3);
+    const int ia = patch0 + row_a * W_ROW, ib = patch0 + row_b * W_ROW;
 
-    for (int g = 0; g < nstages; ++g) {
-        const float* buf = sm + (g & 1) * W_BUF;
-        if (g + 1 < nstages) {
-            store_raw(sm + ((g + 1) & 1) * W_BUF);      // last read in stage g-1, barrier passed
-            load_a(g + 1, an);
+    // Main loop.  Stage = 8 input channels = 2 k-steps; ring of four stage buffers; one barrier per stage.
+    // At the start of stage s: store the raw planes of stage s+2 (fetched two stages ago), fetch stage s+4 and
+    // the A operands of stage s+1.  A k-step is: issue the LDS reads of the NEXT k-step (they may already touch
+    // stage s+1, visible since this stage's barrier), the 16 MFMAs of this k-step (which cover the LDS latency),
+    // then the operand transform of the next k-step.  MFMA and VALU work are serialised on purpose: fp32 MFMAs
+    // and fp32 VALU ops do not overlap on gfx950 (measured with the ablations: loop time = MFMA time + VALU time;
+    // the fp32 matrix rate equals the packed-fp32 vector rate), and one operand/read set instead of two keeps
+    // the kernel inside the 256-register budget of two workgroups per CU.
+    // Everything is branch-free (prefetch indices are clamped; the tail re-fetches the last stage): with guards
+    // the waitcnt pass drains vmcnt at the top of every stage; the fences keep hipcc from sinking the prefetch
+    // loads to their first use.
+    float rd[2][6][2];
+    float bop[4][4];
+    if (ABL >= 3) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e) {
+            (&bop[0][0])[e & 15] = (float)(lane + e);
+            (&rd[0][0][0])[e] = (float)(lane - e);
         }
-        if (g + 2 < nstages) load_raw(g + 2);
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-            const float* R = buf + q4 * 4 * W_PLANE;
-            float bop[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float2 a01 = *reinterpret_cast<const float2*>(R + off_a + t * 4 * W_ROW);
-                const float2 a23 = *reinterpret_cast<const float2*>(R + off_a + t * 4 * W_ROW + 2);
-                const float2 b01 = *reinterpret_cast<const float2*>(R + off_b + t * 4 * W_ROW);
-                const float2 b23 = *reinterpret_cast<const float2*>(R + off_b + t * 4 * W_ROW + 2);
-                const float w0 = fmaf(sgn, b01.x, a01.x), w1 = fmaf(sgn, b01.y, a01.y);
-                const float w2 = fmaf(sgn, b23.x, a23.x), w3 = fmaf(sgn, b23.y, a23.y);
-                bop[0][t] = w0 - w2;
-                bop[1][t] = w1 + w2;
-                bop[2][t] = w2 - w1;
-                bop[3][t] = w1 - w3;
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q4][0], bop[0][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q4][1], bop[1][t], acc[1][t], 0, 0, 0);
-                acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q4][2], bop[2][t], acc[2][t], 0, 0, 0);
-                acc[3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q4][3], bop[3][t], acc[3][t], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = an[q];
-        __syncthreads();
     }
+#define W_READ(BUFI, Q, RD)                                                                      \
+    if (ABL != 3 && ABL < 5) {                                                                   \
+        /* one laundered base per k-step so the pair offsets fold into the ds_read immediates */ \
+        int oa = ia + (BUFI) * W_BUF + (Q) * 4 * W_PLANE;                                        \
+        int ob = ib + (BUFI) * W_BUF + (Q) * 4 * W_PLANE;                                        \
+        asm volatile("" : "+v"(oa), "+v"(ob));                                                   \
+        __builtin_assume((oa & 3) == 0);                                                         \
+        __builtin_assume((ob & 3) == 0);                                                         \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {          /* tile rows ty and ty + 4 */    \
+            const float4 a4 = *reinterpret_cast<const float4*>(sm + oa + p * 8 * W_ROW);         \
+            const float2 a2 = *reinterpret_cast<const float2*>(sm + oa + p * 8 * W_ROW + 4);     \
+            const float4 b4 = *reinterpret_cast<const float4*>(sm + ob + p * 8 * W_ROW);         \
+            const float2 b2 = *reinterpret_cast<const float2*>(sm + ob + p * 8 * W_ROW + 4);     \
+            RD[p][0][0] = a4.x; RD[p][0][1] = b4.x;                                              \
+            RD[p][1][0] = a4.y; RD[p][1][1] = b4.y;                                              \
+            RD[p][2][0] = a4.z; RD[p][2][1] = b4.z;                                              \
+            RD[p][3][0] = a4.w; RD[p][3][1] = b4.w;                                              \
+            RD[p][4][0] = a2.x; RD[p][4][1] = b2.x;                                              \
+            RD[p][5][0] = a2.y; RD[p][5][1] = b2.y;                                              \
+        }                                                                                        \
+    }
+#define W_XFORM(RD, BOP)                                                                         \
+    if (ABL != 3 && ABL < 5) _Pragma("unroll") for (int p = 0; p < 2; ++p) {                     \
+        /* six columns of the row combination d_a +- d_b, shared by the tile pair */             \
+        float w[6];                                                                              \
+        _Pragma("unroll") for (int c = 0; c < 6; ++c)                                            \
+            w[c] = PLUS ? RD[p][c][0] + RD[p][c][1] : RD[p][c][0] - RD[p][c][1];                 \
+        BOP[0][2 * p] = w[0] - w[2];                                                             \
+        BOP[1][2 * p] = w[1] + w[2];                                                             \
+        BOP[2][2 * p] = w[2] - w[1];                                                             \
+        BOP[3][2 * p] = w[1] - w[3];                                                             \
+        BOP[0][2 * p + 1] = w[2] - w[4];                                                         \
+        BOP[1][2 * p + 1] = w[3] + w[4];                                                         \
+        BOP[2][2 * p + 1] = w[4] - w[3];                                                         \
+        BOP[3][2 * p + 1] = w[3] - w[5];                                                         \
+    }
+#define W_MFMA(AV, BOP)                                                                          \
+    if (ABL != 4) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                \
+        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[0], BOP[0][t], acc[0][t], 0, 0, 0);   \
+        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[1], BOP[1][t], acc[1][t], 0, 0, 0);   \
+        acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[2], BOP[2][t], acc[2][t], 0, 0, 0);   \
+        acc[3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[3], BOP[3][t], acc[3][t], 0, 0, 0);   \
+    }
+#define W_FENCE __builtin_amdgcn_sched_barrier(0);
+#define W_STAGE(J)                                                                               \
+    {                                                                                            \
+        if (ABL != 6) __syncthreads();                                                           \
+        if (ABL != 1 && ABL < 5) store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);          \
+        if (ABL != 1 && ABL < 5) load_raw(min(s0 + (J) + 4, nstages - 1), prs[(J) & 1]);         \
+        if (ABL != 2 && ABL < 5) load_a(min(s0 + (J) + 1, nstages - 1), aset[((J) + 1) & 1]);    \
+        W_FENCE                                                                                  \
+        W_READ((J), 1, rd)                             /* k-step 2s+1 */                         \
+        W_MFMA(aset[(J) & 1][0], bop)                                                            \
+        W_FENCE                                                                                  \
+        W_XFORM(rd, bop)                                                                         \
+        W_FENCE                                                                                  \
+        W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
+        W_MFMA(aset[(J) & 1][1], bop)                                                            \
+        W_FENCE                                                                                  \
+        W_XFORM(rd, bop)                                                                         \
+        W_FENCE                                                                                  \
+    }
+#define W_LOOP                                                                                   \
+    W_READ(0, 0, rd)                                                                             \
+    W_XFORM(rd, bop)                                                                             \
+    W_FENCE                                                                                      \
+    for (int s0 = 0; s0 < nstages; s0 += 4) {       /* nstages is a multiple of 4 (C % 32 == 0) */ \
+        W_STAGE(0)                                                                               \
+        W_STAGE(1)                                                                               \
+        W_STAGE(2)                                                                               \
+        W_STAGE(3)                                                                               \
+    }
+    W_TRACE(1)
+    if (wave == 1) {             // the xi-row 1 combination adds its two patch rows, the others subtract
+        constexpr bool PLUS = true;
+        W_LOOP
+    } else {
+        constexpr bool PLUS = false;
+        W_LOOP
+    }
+    __syncthreads();
+#undef W_LOOP
+#undef W_FENCE
+#undef W_STAGE
+#undef W_MFMA
+#undef W_XFORM
+#undef W_READ
+    W_TRACE(2)
 
     // ---- output transform --------------------------------------------------------------------------
     // acc[q][t][r] = M_(i=wave, j=q)[oc = 4*kq + r][tile = 16t + xl].  Column half (j) in registers,
@@ -230,6 +323,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     }
     __syncthreads();
 
+    W_TRACE(3)
     // thread = (output channel ocl = tid/16, tiles 16t + x16): 4 tiles x 2x2 outputs
     const int ocl = tid >> 4, x16 = tid & 15;
     float y[4][2][2];
@@ -277,7 +371,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         float* pl = planes + ocl * T_PLANE;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ty = 2 * t + (x16 >> 3), tx = x16 & 7;
+            const int ty = (x16 >> 2) + 4 * (t >> 1), tx = 2 * (x16 & 3) + (t & 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -289,6 +383,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     }
     __syncthreads();
 
+    W_TRACE(4)
     // ---- fused partial heads: this tile's 16 channels x 9 taps -> 4 head outputs per position ---------
     {
         const int py = tid >> 4, px = tid & 15;
@@ -314,18 +409,38 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         dst[2 * 256] = h2;
         dst[3 * 256] = h3;
     }
+    W_TRACE(5)
+#undef W_TRACE
 }
+
+static long long* g_tower_trace = nullptr;
 
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
                       float* part, hipStream_t st) {
-    const size_t smem = (size_t)2 * W_BUF * sizeof(float);     // 61,440 B: two workgroups per CU
+    const size_t smem = (size_t)W_SMEM_FLOATS * sizeof(float);     // 58,752 B: two workgroups per CU
     const int tiles = 2 * (C / 16);
     const int grid = ((N + 7) / 8) * 8 * tiles;
-    hipLaunchKernelGGL(tower_wino_kernel, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part);
+    const char* abl_s = getenv("SMOT_WINO_ABL");
+    const int abl = abl_s ? atoi(abl_s) : 0;
+#define W_LAUNCH(A)                                                                                             \
+    hipLaunchKernelGGL(tower_wino_kernel<A>, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part, \
+                       g_tower_trace)
+    switch (abl) {
+        case 1: W_LAUNCH(1); break;
+        case 2: W_LAUNCH(2); break;
+        case 3: W_LAUNCH(3); break;
+        case 4: W_LAUNCH(4); break;
+        case 5: W_LAUNCH(5); break;
+        case 6: W_LAUNCH(6); break;
+        default: W_LAUNCH(0); break;
+    }
+#undef W_LAUNCH
     return check_launch("predictor towers (winograd)");
 }
 
 }  // namespace smot
+
+extern "C" void smot_debug_tower_trace(long long* buf) { smot::g_tower_trace = buf; }
 
 extern "C" long long smot_emm_tower_pack_floats(int C) {
     if (C <= 0 || C % 16 != 0) return 0;          // the packed path needs 16-channel tiles

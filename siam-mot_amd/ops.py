@@ -11,6 +11,7 @@ Operator ↔ reference map (reference paths relative to amazon-science/siam-mot)
     emm_decode         3x F.interpolate + get_locations + decode_response   EMM/track_core.py:69-77
 """
 import ctypes
+import weakref
 import os
 
 import torch
@@ -35,6 +36,7 @@ _SIGNATURES = {
     "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
     "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp, _vp]),
+    "smot_debug_tower_trace": (None, [_vp]),
     "smot_emm_tower_pack_floats": (ctypes.c_longlong, [_i]),
     "smot_emm_tower_pack": (ctypes.c_int, [_vp, _vp, _i, _vp, _vp]),
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
@@ -188,16 +190,18 @@ def tower_packed(params):
     nfl = lib.smot_emm_tower_pack_floats(C)
     if nfl == 0 or tuple(wc.shape) != (C, C, 3, 3) or tuple(wr.shape) != (C, C, 3, 3):
         return None
+    # Keyed on the tensor OBJECTS (weak references), not on addresses: the caching allocator hands the address
+    # of a freed weight tensor to the next model's weights, and version counters restart with every tensor.
     key = (wc.data_ptr(), wr.data_ptr())
     ver = (wc._version, wr._version)
     hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    if hit is not None and hit[0]() is wc and hit[1]() is wr and hit[2] == ver:
+        return hit[3]
     packed = torch.empty((nfl,), dtype=torch.float32, device=wc.device)
     _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), _stream()), "tower_pack")
-    if len(_pack_cache) > 16:
-        _pack_cache.clear()
-    _pack_cache[key] = (ver, packed)
+    for k in [k for k, v in _pack_cache.items() if v[0]() is None or v[1]() is None]:
+        del _pack_cache[k]
+    _pack_cache[key] = (weakref.ref(wc), weakref.ref(wr), ver, packed)
     return packed
 
 

@@ -275,6 +275,12 @@ def test_tower_pack_cache_follows_the_weights(ops):
     direct = ops.emm_predictor(resp, pb, winograd=False)
     scale = direct.abs().amax(dim=(0, 2, 3), keepdim=True)
     assert float(((lb - direct).abs() / scale).max()) < 2e-5             # the two tower kernels agree
+    del pa, pb
+    for _ in range(4):        # freed weights hand their addresses (and version numbers) to the next model
+        p = {k: _d(v) for k, v in gi.predictor_params(rs, 64, boxes).items()}
+        w, dd = ops.emm_predictor(resp, p), ops.emm_predictor(resp, p, winograd=False)
+        assert float(((w - dd).abs() / dd.abs().amax(dim=(0, 2, 3), keepdim=True)).max()) < 2e-5
+        del p, w, dd
 
 
 def test_predictor_module_views_and_state_dict(ops):

@@ -1,0 +1,43 @@
+"""Tower kernel timing: winograd vs direct, N in {30, 100}; prints JSON lines."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+import golden_inputs as gi
+import siammot_amd.ops as ops
+dev = "cuda:0"
+rs = np.random.RandomState(0)
+boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+P = {k: torch.from_numpy(v).to(dev) for k, v in gi.predictor_params(rs, 128, boxes).items()}
+ABLS = os.environ.get("ABLS", "0").split(",")
+for n in (30, 100):
+    resp = torch.randn(n, 128, 16, 16, device=dev) * 15
+    for abl in ABLS:
+        os.environ["SMOT_WINO_ABL"] = abl
+        f = lambda: ops.emm_predictor(resp, P, winograd=(abl != "direct"))
+        for _ in range(200): f()
+        torch.cuda.synchronize()
+        ts = []
+        for rep in range(5):
+            ops.kernel_timer_begin(ops.TIMER_TOWER, 300)
+            for _ in range(300): f()
+            ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
+            ts.append(ms / cnt * 1e3)
+        print(json.dumps({"tracks": n, "variant": abl, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
+os.environ["SMOT_WINO_ABL"] = "0"
+# phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
+lib = ops.load_library()
+for n in (30, 100):
+    resp = torch.randn(n, 128, 16, 16, device=dev) * 15
+    grid = (n + 7) // 8 * 8 * 16
+    tr = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
+    lib.smot_debug_tower_trace(ops._ptr(tr))
+    ops.emm_predictor(resp, P); torch.cuda.synchronize()
+    ops.emm_predictor(resp, P); torch.cuda.synchronize()
+    lib.smot_debug_tower_trace(ops._ptr(None))
+    t = tr.view(grid, 8).cpu().numpy()
+    t = t[t[:, 5] != 0]
+    t0 = t[:, 0].min()
+    d = np.diff(t[:, :6], axis=1)
+    print(json.dumps({"tracks": n, "blocks": len(t), "phase_ticks_mean": [round(float(x), 1) for x in d.mean(0)],
+                      "phase_ticks_max": [int(x) for x in d.max(0)], "block_total_mean": round(float((t[:, 5] - t[:, 0]).mean()), 1),
+                      "kernel_span_ticks": int(t[:, 5].max() - t0), "start_spread": int(t[:, 0].max() - t0)}), flush=True)
