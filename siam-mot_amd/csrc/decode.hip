@@ -108,16 +108,22 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 
 __device__ __forceinline__ float cell_score_fast(const float* v, float inv_bw, float inv_bh, float win,
                                                  const DecodeParams& D) {
-    const float m = fmaxf(v[0], v[1]);
-    const float e0 = fast_exp(v[0] - m);
-    const float e1 = fast_exp(v[1] - m);
-    float conf = e1 * fast_rcp(e0 + e1);
-    if (D.use_centerness) conf *= fast_rcp(1.0f + fast_exp(-v[2]));
-    float s_w = (v[5] + v[3]) * inv_bw;
-    float s_h = (v[6] + v[4]) * inv_bh;
-    s_w = max_nan(s_w, fast_rcp(s_w));
-    s_h = max_nan(s_h, fast_rcp(s_h));
-    const float pen = fast_exp(fmaf(-s_w, s_h, 1.0f) * 0.1f);
+    // softmax over two classes and the centerness sigmoid share one reciprocal:
+    //   p1 * sig = 1 / ((1 + exp(v0 - v1)) * (1 + exp(-v2)))
+    float den = 1.0f + fast_exp(v[0] - v[1]);
+    if (D.use_centerness) den *= 1.0f + fast_exp(-v[2]);
+    const float conf = fast_rcp(den);
+    // max(a, 1/a) * max(b, 1/b) with ONE reciprocal r = 1/(a*b) (1/a = b*r, 1/b = a*r).  max(a, 1/a) is a
+    // itself for a >= 1 and for -1 <= a < 0 (bicubic overshoot can make the sizes negative), else 1/a.
+    // NaN in a or b makes r NaN and every comparison false -> NaN (propagates, as max_nan does in the exact path).
+    const float a = (v[5] + v[3]) * inv_bw;
+    const float b = (v[6] + v[4]) * inv_bh;
+    const float ab = a * b;
+    const float r = fast_rcp(ab);
+    const bool pa = (a >= 1.0f) || (a < 0.0f && a >= -1.0f);
+    const bool pb = (b >= 1.0f) || (b < 0.0f && b >= -1.0f);
+    const float sws = pa ? (pb ? ab : a * a * r) : (pb ? b * b * r : r);
+    const float pen = fast_exp(fmaf(-sws, 0.1f, 0.1f));
     return fmaf(conf * pen, D.one_minus_sigma, D.sigma * win);
 }
 
@@ -142,15 +148,31 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
             const int ch = e / (Ho * Ho);
             lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
         }
-    } else {
-        // Ho == 16: thread = position; the 7 channels' tile loads are independent (56 in flight at C = 128)
+    } else if (blockIdx.y == 0) {
+        // Ho == 16, band-0 workgroup: all 7 x 256 combined logits (it also leaves them in HBM for pass 2);
+        // thread = position; the 7 channels' tile loads are independent (56 in flight at C = 128)
         float c7[7];
 #pragma unroll
         for (int ch = 0; ch < 7; ++ch) c7[ch] = L.combine(n, ch, threadIdx.x);
 #pragma unroll
         for (int ch = 0; ch < 7; ++ch) {
             lg[ch * 256 + threadIdx.x] = c7[ch];
-            if (blockIdx.y == 0) L.logits_out[((size_t)n * 7 + ch) * 256 + threadIdx.x] = c7[ch];
+            L.logits_out[((size_t)n * 7 + ch) * 256 + threadIdx.x] = c7[ch];
+        }
+    } else {
+        // other bands only touch their four source rows f-1..f+2 (clamped): 7 x 4 x 16 = 448 logits
+        float c2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = threadIdx.x + 256 * j;                  // (ch, k, col)
+            const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
+            c2[j] = (e < 448) ? L.combine(n, ch, row * 16 + (e & 15)) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
+            if (e < 448) lg[ch * 256 + row * 16 + (e & 15)] = c2[j];   // clamped duplicates write equal values
         }
     }
     const int y_begin = max(0, up * f + up / 2);
