@@ -202,10 +202,11 @@ int smot_xcorr_timer_begin(int max_launches);
 int smot_xcorr_timer_end(double* total_ms, int* launches);
 /* Same mechanism per slot: 0 = the cross-correlation kernels (what the two calls above use),
  * 1 = the tower MFMA kernel of smot_emm_predictor_fwd / smot_emm_track_fwd. */
-/* Phase trace of the Winograd tower kernel: while buf != NULL every workgroup writes six s_memtime stamps
- * (start, main loop begin/end, output exchange done, GroupNorm done, end) to buf[workgroup*8 + 0..5]
- * (device memory, 8 int64 per workgroup of the launch grid ((N+7)/8*8 * 2C/16)).  NULL switches it off. */
-void smot_debug_tower_trace(long long* buf);
+/* Phase trace: while buf != NULL every workgroup of the Winograd tower kernel and of the fused pooling /
+ * correlation kernel writes s_memtime stamps to buf[workgroup*8 + 0..7] (device memory, 8 int64 per workgroup of
+ * the launch grid; tower: start, main loop begin/end, output exchange done, GroupNorm done, end; fused: start,
+ * tables done, templates staged, pooling done, end).  NULL switches it off. */
+void smot_debug_trace(long long* buf);
 int smot_kernel_timer_begin(int slot, int max_launches);
 int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
 

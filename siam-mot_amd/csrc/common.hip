@@ -16,6 +16,11 @@ void set_error(const char* fmt, ...) {
 
 extern "C" int smot_abi_version(void) { return SMOT_ABI_VERSION; }
 
+namespace smot {
+long long* g_trace = nullptr;
+}
+extern "C" void smot_debug_trace(long long* buf) { smot::g_trace = buf; }
+
 extern "C" const char* smot_last_error(void) { return smot::g_err; }
 
 // ---- instrumentation: HIP events recorded on the launch stream around selected kernels --------------

@@ -10,6 +10,7 @@
 namespace smot {
 
 void set_error(const char* fmt, ...);
+extern long long* g_trace;                           // common.hip: phase-trace buffer (smot_debug_trace), or nullptr
 void timer_mark(int slot, int end, hipStream_t st);   // common.hip: event bracket for bench.py (no-op when idle)
 
 inline int check_launch(const char* what) {

@@ -22,6 +22,7 @@
 // aspect ratios) take a workgroup-uniform slow path: per-bin gathers, same arithmetic as roi_align.hip.
 #include "roi_common.h"
 #include "xcorr_patch2.h"
+#include <type_traits>
 
 namespace smot {
 
@@ -33,6 +34,7 @@ constexpr int FX_CH = 8;          // channels per workgroup (2 per wave)
 struct SrOut {
     float* sr;            // [R,4] or nullptr
     float pad, half_e, two_e, min_wh;
+    long long* trace;     // phase trace (smot_debug_trace) or nullptr
 };
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
@@ -73,6 +75,10 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = blockIdx.x;
     const int c0 = blockIdx.y * FX_CH;
+#define FX_TRACE(SLOT)                                                                      \
+    if (S.trace && tid == 0)                                                                \
+        S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    FX_TRACE(0)
     float* xs = sm + wave * (2 * XP + 2 * ZP);
     float* zs = xs + 2 * XP;
 
@@ -163,6 +169,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     }
     __syncthreads();
     if (nvalid <= 0) return;
+    FX_TRACE(1)
 
     // ---- templates of this wave's planes -> LDS (dword loads, 225 floats per plane) ----------
     if (XCORR) {
@@ -182,72 +189,92 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
         }
     }
 
+    FX_TRACE(2)
     // ---- pooling --------------------------------------------------------------------------
     const float* __restrict__ fbase = P.feat[lvl];
     if (fast) {
-        // lanes beyond the window re-read its last column: their values are never gathered
-        const int gcol = xmin + min(lane, ww - 1);
-        // lane pw's horizontal taps (pw < RX)
-        const int pw = lane < RX ? lane : 0;
-        int sxl[G], sxh[G];
-        float hxw[G], lxw[G];
+        // DUAL (window <= 32 columns, the common case: three of the four benchmark box sizes): the two planes
+        // of the wave are pooled side by side, plane = lane / 32 — half the load, bpermute and FMA instructions
+        // per plane.  Otherwise one plane per pass over all 64 lanes.
+        auto pool = [&](auto dual_tag) {
+            constexpr bool DUAL = decltype(dual_tag)::value;
+            const int half = DUAL ? (lane >> 5) : 0;                 // plane handled by this lane (DUAL)
+            const int col = DUAL ? (lane & 31) : lane;
+            // lanes beyond the window re-read its last column: their values are never gathered
+            const int gcol = xmin + min(col, ww - 1);
+            // a wave that owns a single plane (odd channel tails) lets its upper half shadow plane 0
+            const unsigned plane_off = (DUAL && half == 1 && nvalid > 1) ? (unsigned)(H * W) * 4u : 0u;
+            // lane pw's horizontal taps (pw < RX)
+            const int pw = col < RX ? col : 0;
+            int sxl[G], sxh[G];
+            float hxw[G], lxw[G];
 #pragma unroll
-        for (int ix = 0; ix < G; ++ix) {
-            sxl[ix] = x_lo[pw * G + ix] << 2;            // ds_bpermute takes byte addresses (lane*4)
-            sxh[ix] = x_hi[pw * G + ix] << 2;
-            hxw[ix] = wx_lo[pw * G + ix];
-            lxw[ix] = wx_hi[pw * G + ix];
-        }
-        // Batches of 15 pooled rows (60 row loads per lane).  The pooling is latency-bound — every batch
-        // is one ~1.5 us memory round trip — so the loads of batch k+1 are issued before batch k is
-        // consumed (two named register sets), and only the first round trip is exposed.
-        constexpr int PHB = 15;
-        constexpr int BPP = RX / PHB;                    // batches per plane
-        static_assert(RX % PHB == 0, "pooled size must be a multiple of the batch");
-        const int nb = nvalid * BPP;
-        float va[PHB][G][2], vb[PHB][G][2];
-        auto issue = [&](int k, float (&v)[PHB][G][2]) {
-            const int pl = k / BPP, ph0 = (k - pl * BPP) * PHB;
-            const gptr_t fc = uniform_base(fbase + (size_t)(c0 + 2 * wave + pl) * H * W);
+            for (int ix = 0; ix < G; ++ix) {
+                sxl[ix] = (x_lo[pw * G + ix] + 32 * half) << 2;      // ds_bpermute takes byte addresses (lane*4)
+                sxh[ix] = (x_hi[pw * G + ix] + 32 * half) << 2;
+                hxw[ix] = wx_lo[pw * G + ix];
+                lxw[ix] = wx_hi[pw * G + ix];
+            }
+            // Batches of 15 pooled rows (60 row loads per lane).  The pooling is latency-bound — every batch
+            // is one memory round trip — so the loads of batch k+1 are issued before batch k is consumed (two
+            // named register sets), and only the first round trip is exposed.
+            constexpr int PHB = 15;
+            constexpr int BPP = RX / PHB;                    // batches per plane
+            static_assert(RX % PHB == 0, "pooled size must be a multiple of the batch");
+            const int nb = DUAL ? BPP : nvalid * BPP;
+            float va[PHB][G][2], vb[PHB][G][2];
+            auto issue = [&](int k, float (&v)[PHB][G][2]) {
+                const int pl = DUAL ? 0 : k / BPP, ph0 = (k - pl * BPP) * PHB;
+                const gptr_t fc = uniform_base(fbase + (size_t)(c0 + 2 * wave + pl) * H * W);
 #pragma unroll
-            for (int b = 0; b < PHB; ++b)
+                for (int b = 0; b < PHB; ++b)
 #pragma unroll
-                for (int iy = 0; iy < G; ++iy) {
-                    const int s = (ph0 + b) * G + iy;
-                    v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u);
-                    v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u);
-                }
-        };
-        auto consume = [&](int k, float (&v)[PHB][G][2]) {
-            const int pl = k / BPP, ph0 = (k - pl * BPP) * PHB;
-            float* xplane = xs + pl * XP;
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int s = (ph0 + b) * G + iy;
+                        v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u + plane_off);
+                        v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u + plane_off);
+                    }
+            };
+            auto consume = [&](int k, float (&v)[PHB][G][2]) {
+                const int pl = DUAL ? 0 : k / BPP, ph0 = (k - pl * BPP) * PHB;
+                float* xplane = xs + (DUAL ? half : pl) * XP;
 #pragma unroll
-            for (int b = 0; b < PHB; ++b) {
-                float acc = 0.0f;
+                for (int b = 0; b < PHB; ++b) {
+                    // the horizontal weights do not depend on the y-sample: add the two y-samples' column values
+                    // first, gather once (4 bpermutes per pooled row instead of 8).  The factorisation already
+                    // differs from the reference's rounding sequence at the 1e-7 level (tested to 1e-5).
+                    float col_sum = 0.0f;
 #pragma unroll
-                for (int iy = 0; iy < G; ++iy) {
-                    const int s = (ph0 + b) * G + iy;
-                    // explicit FMAs: the separable factorisation already differs from the reference's
-                    // rounding sequence at the 1e-7 level (tested to 1e-5); no reason to pay 2 ops per term
-                    const float col = fmaf(wy_hi[s], v[b][iy][1], wy_lo[s] * v[b][iy][0]);
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int s = (ph0 + b) * G + iy;
+                        col_sum = fmaf(wy_lo[s], v[b][iy][0], col_sum);
+                        col_sum = fmaf(wy_hi[s], v[b][iy][1], col_sum);
+                    }
+                    float acc = 0.0f;
 #pragma unroll
                     for (int ix = 0; ix < G; ++ix) {
-                        const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col)));
-                        const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col)));
+                        const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col_sum)));
+                        const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col_sum)));
                         acc = fmaf(hxw[ix], a, acc);
                         acc = fmaf(lxw[ix], c, acc);
                     }
+                    if (col < RX && (!DUAL || half < nvalid))
+                        xplane[(ph0 + b) * XS + col] = acc * (1.0f / (float)(G * G));   // exact: /4
                 }
-                if (lane < RX) xplane[(ph0 + b) * XS + lane] = acc * (1.0f / (float)(G * G));   // exact: /4
+            };
+            issue(0, va);
+#pragma unroll 1
+            for (int k = 0; k < nb; k += 2) {
+                if (k + 1 < nb) issue(k + 1, vb);
+                consume(k, va);
+                if (k + 2 < nb) issue(k + 2, va);
+                if (k + 1 < nb) consume(k + 1, vb);
             }
         };
-        issue(0, va);
-#pragma unroll 1
-        for (int k = 0; k < nb; k += 2) {
-            if (k + 1 < nb) issue(k + 1, vb);
-            consume(k, va);
-            if (k + 2 < nb) issue(k + 2, va);
-            if (k + 1 < nb) consume(k + 1, vb);
+        if (ww <= 32) {
+            pool(std::true_type{});
+        } else {
+            pool(std::false_type{});
         }
     } else {
         // slow path: per-bin gathers from the map (reference term order), lanes stride over the bins
@@ -274,6 +301,7 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
         }
     }
     __builtin_amdgcn_wave_barrier();
+    FX_TRACE(3)
     if (x_debug != nullptr) {
         for (int e = lane; e < nvalid * RX * RX; e += 64) {
             const int pl = e / (RX * RX);
@@ -285,6 +313,8 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     // a wave that owns a single plane (odd channel tails) computes garbage for the second half-wave
     // and the tail guard below drops it
     if constexpr (XCORR) xcorr_patch2_compute<RX, RZ, 0>(xs, zs, lane, resp, plane0, plane0 + nvalid);
+    FX_TRACE(4)
+#undef FX_TRACE
 }
 
 }  // namespace smot
@@ -295,7 +325,7 @@ namespace smot {
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace};
     if (out_size == 30) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
                            (const float*)nullptr, (float*)nullptr, out, levels_out, none);
@@ -315,7 +345,7 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh};
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace};
     hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, boxes, boxes,
                        (const float*)nullptr, (float*)nullptr, templates, (int32_t*)nullptr, S);
     return check_launch("emm_extract_cache");
@@ -341,7 +371,7 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace};
     hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
                        boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
     timer_mark(0, 1, (hipStream_t)stream);

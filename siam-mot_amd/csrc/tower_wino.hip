@@ -413,8 +413,6 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #undef W_TRACE
 }
 
-static long long* g_tower_trace = nullptr;
-
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
                       float* part, hipStream_t st) {
     const size_t smem = (size_t)W_SMEM_FLOATS * sizeof(float);     // 58,752 B: two workgroups per CU
@@ -424,7 +422,7 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
     const int abl = abl_s ? atoi(abl_s) : 0;
 #define W_LAUNCH(A)                                                                                             \
     hipLaunchKernelGGL(tower_wino_kernel<A>, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part, \
-                       g_tower_trace)
+                       g_trace)
     switch (abl) {
         case 1: W_LAUNCH(1); break;
         case 2: W_LAUNCH(2); break;
@@ -439,8 +437,6 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 }
 
 }  // namespace smot
-
-extern "C" void smot_debug_tower_trace(long long* buf) { smot::g_tower_trace = buf; }
 
 extern "C" long long smot_emm_tower_pack_floats(int C) {
     if (C <= 0 || C % 16 != 0) return 0;          // the packed path needs 16-channel tiles

@@ -36,7 +36,7 @@ _SIGNATURES = {
     "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
     "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp, _vp]),
-    "smot_debug_tower_trace": (None, [_vp]),
+    "smot_debug_trace": (None, [_vp]),
     "smot_emm_tower_pack_floats": (ctypes.c_longlong, [_i]),
     "smot_emm_tower_pack": (ctypes.c_int, [_vp, _vp, _i, _vp, _vp]),
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,

@@ -1,0 +1,34 @@
+"""Phase trace (s_memtime ticks) of the fused pooling+xcorr kernel and the template pooler, bench workload."""
+import json, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import bench
+import siammot_amd.ops as ops
+dev = torch.device("cuda:0")
+lib = ops.load_library()
+scales = (0.25, 0.125, 0.0625, 0.03125)
+for n in [int(a) for a in sys.argv[1:]] or [30]:
+    boxes = bench.synthetic_boxes(n, (1280, 704)).to(dev)
+    feats = bench.synthetic_features(1, dev)
+    sr = ops.search_region(boxes, 512, 1.0, 0)
+    z = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)
+    lv = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2, return_levels=True)[1].cpu().numpy()
+    runs = {"fused<30,15,true>": lambda: ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512),
+            "pool<15>": lambda: ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2),
+            "pool<30>": lambda: ops.roi_align_levels(feats, sr, boxes, 30, scales, 2, [128, 64, 32, 16])}
+    for name, f in runs.items():
+        for _ in range(20): f()
+        torch.cuda.synchronize()
+        grid = n * 16
+        tr = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
+        lib.smot_debug_trace(ops._ptr(tr)); f(); torch.cuda.synchronize(); lib.smot_debug_trace(ops._ptr(None))
+        t = tr.view(n, 16, 8).cpu().numpy().astype(np.float64)
+        d = np.diff(t[:, :, :5], axis=2)
+        t0 = t[:, :, 0].min()
+        out = {"tracks": n, "kernel": name, "phase_ticks_mean(tables,z,pool,xcorr)": [round(float(x)) for x in d.reshape(-1, 4).mean(0)],
+               "phase_max": [int(x) for x in d.reshape(-1, 4).max(0)], "span": int(t[:, :, 4].max() - t0),
+               "start_spread": int(t[:, :, 0].max() - t0)}
+        for L in range(4):
+            m = lv == L
+            if m.any(): out["pool_ticks_level%d" % L] = round(float(d[m][:, :, 2].mean()))
+        print(json.dumps(out), flush=True)

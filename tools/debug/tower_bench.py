@@ -30,10 +30,10 @@ for n in (30, 100):
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     grid = (n + 7) // 8 * 8 * 16
     tr = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
-    lib.smot_debug_tower_trace(ops._ptr(tr))
+    lib.smot_debug_trace(ops._ptr(tr))
     ops.emm_predictor(resp, P); torch.cuda.synchronize()
     ops.emm_predictor(resp, P); torch.cuda.synchronize()
-    lib.smot_debug_tower_trace(ops._ptr(None))
+    lib.smot_debug_trace(ops._ptr(None))
     t = tr.view(grid, 8).cpu().numpy()
     t = t[t[:, 5] != 0]
     t0 = t[:, 0].min()
