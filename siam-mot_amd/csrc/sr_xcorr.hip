@@ -105,45 +105,64 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
     const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
     const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
-    if (tid == 0) {
-        wbound[0] = 0x7fffffff;
-        wbound[1] = -1;
-        wbound[2] = 0x7fffffff;
-        wbound[3] = -1;
+    // templates of this wave's planes: issue the loads now, park them in LDS after the tables (hides their latency)
+    const int plane0 = n * C + c0 + 2 * wave;            // first of this wave's two planes
+    const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);   // planes this wave really owns
+    constexpr int NZ = XCORR ? (2 * RZ * RZ + 63) / 64 : 1;
+    float zreg[NZ];
+    if (XCORR && nvalid > 0) {
+        const float* __restrict__ zg = z + (size_t)plane0 * (RZ * RZ);
+        const int zcount = nvalid * RZ * RZ;
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, zcount - 1)];
     }
-    __syncthreads();
-    if (tid < 2 * NS) {
-        int lo, hi;
-        float wl, wh;
-        const bool isy = tid < NS;
-        const int s = isy ? tid : tid - NS;
-        if (isy) {
-            axis_sample(y1, bin_h, G, s, H, pad, &lo, &hi, &wl, &wh);
-            y_lo[s] = lo;
-            y_hi[s] = hi;
-            wy_lo[s] = wl;
-            wy_hi[s] = wh;
-        } else {
-            axis_sample(x1, bin_w, G, s, W, pad, &lo, &hi, &wl, &wh);
-            x_lo[s] = lo;
-            x_hi[s] = hi;
-            wx_lo[s] = wl;
-            wx_hi[s] = wh;
+    // Sample tables: wave 0 = the y axis, wave 1 = the x axis, lane = sample.  The bounding window of the touched
+    // real cells is a wave-wide min/max (no LDS atomics), and the entries are re-based before they are stored
+    // (zero-weight entries point at a safe cell; x entries become window-relative lane ids): one barrier.
+    if (wave < 2) {
+        int lo = 0, hi = 0;
+        float wl = 0.0f, wh = 0.0f;
+        if (lane < NS) {
+            if (wave == 0) {
+                axis_sample(y1, bin_h, G, lane, H, pad, &lo, &hi, &wl, &wh);
+            } else {
+                axis_sample(x1, bin_w, G, lane, W, pad, &lo, &hi, &wl, &wh);
+            }
         }
-        const int b = isy ? 0 : 2;
+        int mn = 0x7fffffff, mx = -1;
         if (wl != 0.0f) {
-            atomicMin(&wbound[b], lo);
-            atomicMax(&wbound[b + 1], lo);
+            mn = lo;
+            mx = lo;
         }
         if (wh != 0.0f) {
-            atomicMin(&wbound[b], hi);
-            atomicMax(&wbound[b + 1], hi);
+            mn = min(mn, hi);
+            mx = max(mx, hi);
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            mn = min(mn, __shfl_xor(mn, m));
+            mx = max(mx, __shfl_xor(mx, m));
+        }
+        if (lane < NS) {
+            if (wave == 0) {
+                y_lo[lane] = (wl != 0.0f) ? lo : mn;
+                y_hi[lane] = (wh != 0.0f) ? hi : mn;
+                wy_lo[lane] = wl;
+                wy_hi[lane] = wh;
+            } else {
+                x_lo[lane] = (wl != 0.0f) ? lo - mn : 0;
+                x_hi[lane] = (wh != 0.0f) ? hi - mn : 0;
+                wx_lo[lane] = wl;
+                wx_hi[lane] = wh;
+            }
+        }
+        if (lane == 0) {
+            wbound[2 * wave] = mn;
+            wbound[2 * wave + 1] = mx;
         }
     }
     __syncthreads();
     const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
-    const int plane0 = n * C + c0 + 2 * wave;            // first of this wave's two planes
-    const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);   // planes this wave really owns
     if (ymax < ymin || xmax < xmin) {
         // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
         if (nvalid > 0) {
@@ -156,35 +175,19 @@ sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const 
     }
     const int ww = xmax - xmin + 1;
     const bool fast = (ww <= 64);                        // workgroup-uniform
-    // re-base: zero-weight entries point at a safe cell; x entries become window-relative lane ids
-    if (tid < 2 * NS) {
-        if (tid < NS) {
-            if (wy_lo[tid] == 0.0f) y_lo[tid] = ymin;
-            if (wy_hi[tid] == 0.0f) y_hi[tid] = ymin;
-        } else {
-            const int s = tid - NS;
-            x_lo[s] = (wx_lo[s] != 0.0f) ? x_lo[s] - xmin : 0;
-            x_hi[s] = (wx_hi[s] != 0.0f) ? x_hi[s] - xmin : 0;
-        }
-    }
-    __syncthreads();
     if (nvalid <= 0) return;
     FX_TRACE(1)
 
-    // ---- templates of this wave's planes -> LDS (dword loads, 225 floats per plane) ----------
+    // ---- templates of this wave's planes -> LDS (225 floats per plane, fetched before the tables) ----
     if (XCORR) {
-        constexpr int NZ = (2 * RZ * RZ + 63) / 64;
-        const float* __restrict__ zg = z + (size_t)plane0 * (RZ * RZ);
-        const int zcount = nvalid * RZ * RZ;
 #pragma unroll
         for (int t = 0; t < NZ; ++t) {
             const int e = lane + 64 * t;
             if (e < 2 * RZ * RZ) {
-                const float v = zg[min(e, zcount - 1)];
                 const int pl = e / (RZ * RZ);
                 const int el = e - pl * (RZ * RZ);
                 const int u = el / RZ;
-                zs[pl * ZP + u * ZS + (el - u * RZ)] = v;
+                zs[pl * ZP + u * ZS + (el - u * RZ)] = zreg[t];
             }
         }
     }
