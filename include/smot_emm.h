@@ -192,6 +192,24 @@ int smot_nms_fwd(const float* boxes_sorted, int n, float thresh, void* mask_ws, 
                  smot_stream_t stream);
 
 /*
+ * Frame pre-processing: uint8 RGB HWC frame -> fp32 CHW network input in one launch.
+ *
+ * Replaces the CPU chain of demos/demo_inference.py:74-82 and build_augmentation.py:52-66 / image_augmentation.py:21-50:
+ *   PIL.Image.resize((OW, OH), BILINEAR) -> ToTensor -> Normalize(mean, std, to_bgr255) [UPSTREAM transforms.py].
+ *   Bit-exact with Pillow's 8-bit resampler: the caller supplies Pillow's per-axis tables (device memory),
+ *   bounds [O,2] int32 = (first input index, tap count) and coeffs [O,k] int32 = weights quantised to 22
+ *   fractional bits (an axis that keeps its size: (i,1) and 1<<22).  max_tile_rows = the largest number of
+ *   input rows any 8 consecutive output rows touch.  mean3 / std3: HOST arrays, indexed by OUTPUT channel
+ *   (after the optional BGR swap, as upstream applies them).  out [3, OH, OW].
+ */
+int smot_preprocess_fwd(const unsigned char* frame, int H, int W,
+                        const int* xbounds, const int* xcoeffs, int kx,
+                        const int* ybounds, const int* ycoeffs, int ky,
+                        int OH, int OW, int max_tile_rows,
+                        const float* mean3, const float* std3, int to_bgr255,
+                        float* out, smot_stream_t stream);
+
+/*
  * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd and
  * smot_sr_xcorr_fused_fwd launch — direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
  * stream (events are created in _begin, outside any timed region; at most max_launches pairs).

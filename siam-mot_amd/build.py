@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
-SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip",
+SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "preprocess.hip",
            "emm_fused.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of

@@ -24,7 +24,10 @@ class CfgNode(dict):
 
 def get_default_cfg(conv_body="DLA-34-FPN", channels=128):
     cfg = CfgNode()
-    cfg.INPUT = CfgNode(AMODAL=False)
+    # INPUT.* / DATALOADER.*: the DLA_34_FPN_EMM.yaml values (reference configs/dla/DLA_34_FPN_EMM.yaml:4-8,38)
+    cfg.INPUT = CfgNode(AMODAL=False, MIN_SIZE_TEST=800, MAX_SIZE_TEST=1280, PIXEL_MEAN=[0.485, 0.456, 0.406],
+                        PIXEL_STD=[0.229, 0.224, 0.225], TO_BGR255=False)
+    cfg.DATALOADER = CfgNode(SIZE_DIVISIBILITY=32)
     cfg.MODEL = CfgNode()
     cfg.MODEL.BACKBONE = CfgNode(CONV_BODY=conv_body)
     cfg.MODEL.DLA = CfgNode(BACKBONE_OUT_CHANNELS=channels)

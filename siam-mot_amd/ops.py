@@ -44,6 +44,7 @@ _SIGNATURES = {
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
     "smot_sr_xcorr_fused_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                                _vp, _vp, _vp]),
+    "smot_preprocess_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "smot_nms_ws_bytes": (ctypes.c_longlong, [_i]),
     "smot_nms_fwd": (ctypes.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
@@ -414,3 +415,27 @@ def nms(boxes, scores, thresh):
     rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), _stream())
     _check(rc, "nms")
     return order[keep.bool()].sort()[0]
+
+
+def preprocess_frame(frame, tables, out_hw, mean, std, to_bgr255):
+    """uint8 RGB ``[H,W,3]`` device tensor -> fp32 ``[3,OH,OW]`` network input (resize + ToTensor + Normalize in
+    one launch).  ``tables`` = (xbounds, xcoeffs, ybounds, ycoeffs, max_tile_rows) from ``siammot_amd.preprocess``."""
+    lib = load_library()
+    if not isinstance(frame, torch.Tensor) or not frame.is_cuda or frame.dtype != torch.uint8:
+        raise RuntimeError("siammot_amd.preprocess_frame: frame must be a uint8 device (ROCm) tensor — no CPU path exists")
+    if frame.dim() != 3 or frame.shape[2] != 3:
+        raise RuntimeError("siammot_amd.preprocess_frame: frame must be [H, W, 3], got %s" % (tuple(frame.shape),))
+    frame = frame.contiguous()
+    H, W, _ = frame.shape
+    xb, xk, yb, yk, max_rows = tables
+    OH, OW = out_hw
+    if xb.shape[0] != OW or yb.shape[0] != OH:
+        raise RuntimeError("siammot_amd.preprocess_frame: tables are for %dx%d, asked for %dx%d"
+                           % (yb.shape[0], xb.shape[0], OH, OW))
+    out = torch.empty((3, OH, OW), dtype=torch.float32, device=frame.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in std])
+    rc = lib.smot_preprocess_fwd(_ptr(frame), H, W, _ptr(xb), _ptr(xk), xk.shape[1], _ptr(yb), _ptr(yk), yk.shape[1],
+                                 OH, OW, int(max_rows), _cast(m), _cast(s), int(bool(to_bgr255)), _ptr(out), _stream())
+    _check(rc, "preprocess_frame")
+    return out
