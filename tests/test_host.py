@@ -153,3 +153,28 @@ def test_bench_workload_definition():
     assert sorted(set(O.level_mapper(b).tolist())) == [0, 1, 2]
     # algorithmic bytes of the graded kernel: 707,072 B per track at C=128
     assert 4 * 128 * (30 * 30 + 15 * 15 + 16 * 16) == 707072
+
+
+def test_result_wire_format_matches_the_reference_contract():
+    """siammot/utils/boxlists_to_entities.py:6-37 restated with one host copy per frame."""
+    from siammot_amd.results import boxlists_to_entities, mot_challenge_rows, to_original_xywh
+    from siammot_amd.structures import BoxList
+    b = BoxList(torch.tensor([[10.0, 20.0, 29.0, 59.0], [0.5, 0.25, 100.5, 50.25]]), (1280, 704), mode="xyxy")
+    b.add_field("scores", torch.tensor([0.9, 0.123456]))
+    b.add_field("labels", torch.tensor([1, 2]))
+    b.add_field("ids", torch.tensor([7, -1]))
+    out = to_original_xywh(b, (1280, 720))
+    ents = boxlists_to_entities([out, out], 5, [0.2, 0.24], class_table=["person", "vehicle"])
+    assert len(ents) == 4
+    e = ents[0]
+    ref_box = out.bbox[0].tolist()
+    assert e.bbox == ref_box and e.id == 7 and e.frame_num == 5 and e.time == 0.2
+    assert e.confidence == out.get_field("scores")[0].item() and e.labels == {"person": e.confidence}
+    assert ents[1].id == -1 and list(ents[1].labels) == ["vehicle"] and ents[3].frame_num == 6
+    assert abs(e.bbox[2] - 20.0) < 1e-5 and abs(e.bbox[3] - 40.0 * 720 / 704) < 0.2     # xywh with the +1 convention
+    rows = mot_challenge_rows(ents)
+    assert len(rows) == 2 and rows[0].startswith("6,7,10.00,")
+    empty = BoxList(torch.zeros((0, 4)), (10, 10))
+    empty.add_field("scores", torch.zeros(0))
+    empty.add_field("labels", torch.zeros(0, dtype=torch.int64))
+    assert boxlists_to_entities(empty, 0, [0.0]) == []
