@@ -218,14 +218,16 @@ int smot_preprocess_fwd(const unsigned char* frame, int H, int W,
  */
 int smot_xcorr_timer_begin(int max_launches);
 int smot_xcorr_timer_end(double* total_ms, int* launches);
-/* Same mechanism per slot: 0 = the cross-correlation kernels (what the two calls above use),
+/* Same mechanism per slot, bracketing every `stride`-th launch only (an event pair costs ~3 us of stream time:
+ * at stride 1 the instrumentation itself slows a 80 us frame pair by 17 %): 0 = the cross-correlation kernels
+ * (what the two calls above use, stride 1),
  * 1 = the tower MFMA kernel of smot_emm_predictor_fwd / smot_emm_track_fwd. */
 /* Phase trace: while buf != NULL every workgroup of the Winograd tower kernel and of the fused pooling /
  * correlation kernel writes s_memtime stamps to buf[workgroup*8 + 0..7] (device memory, 8 int64 per workgroup of
  * the launch grid; tower: start, main loop begin/end, output exchange done, GroupNorm done, end; fused: start,
  * tables done, templates staged, pooling done, end).  NULL switches it off. */
 void smot_debug_trace(long long* buf);
-int smot_kernel_timer_begin(int slot, int max_launches);
+int smot_kernel_timer_begin(int slot, int max_launches, int stride);
 int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
 
 /*

@@ -30,24 +30,29 @@ struct EventTimer {
     hipEvent_t* ev = nullptr;
     int capacity = 0;
     int used = 0;
+    int stride = 1;       // bracket every stride-th launch only (an event pair costs ~3 us of stream time)
+    int seen = 0;         // launches seen since _begin
+    bool open = false;    // the current launch is being bracketed
 };
 static EventTimer g_timers[2];
 
 void timer_mark(int slot, int end, hipStream_t st) {
     EventTimer& t = g_timers[slot];
-    if (t.ev == nullptr || t.used + 2 > t.capacity) return;
+    if (t.ev == nullptr) return;
     if (!end) {
-        (void)hipEventRecord(t.ev[t.used], st);
-    } else {
+        t.open = (t.seen++ % t.stride == 0) && (t.used + 2 <= t.capacity);
+        if (t.open) (void)hipEventRecord(t.ev[t.used], st);
+    } else if (t.open) {
         (void)hipEventRecord(t.ev[t.used + 1], st);
         t.used += 2;
+        t.open = false;
     }
 }
 }  // namespace smot
 
-extern "C" int smot_kernel_timer_begin(int slot, int max_launches) {
+extern "C" int smot_kernel_timer_begin(int slot, int max_launches, int stride) {
     using namespace smot;
-    SMOT_REQUIRE(slot >= 0 && slot < 2 && max_launches > 0, "kernel_timer_begin: bad slot/count");
+    SMOT_REQUIRE(slot >= 0 && slot < 2 && max_launches > 0 && stride > 0, "kernel_timer_begin: bad slot/count/stride");
     EventTimer& t = g_timers[slot];
     SMOT_REQUIRE(t.ev == nullptr, "kernel_timer_begin: slot %d already active", slot);
     t.ev = new hipEvent_t[2 * (size_t)max_launches];
@@ -60,6 +65,9 @@ extern "C" int smot_kernel_timer_begin(int slot, int max_launches) {
     }
     t.capacity = 2 * max_launches;
     t.used = 0;
+    t.stride = stride;
+    t.seen = 0;
+    t.open = false;
     return SMOT_OK;
 }
 
@@ -88,7 +96,7 @@ extern "C" int smot_kernel_timer_end(int slot, double* total_ms, int* launches) 
     return SMOT_OK;
 }
 
-extern "C" int smot_xcorr_timer_begin(int max_launches) { return smot_kernel_timer_begin(0, max_launches); }
+extern "C" int smot_xcorr_timer_begin(int max_launches) { return smot_kernel_timer_begin(0, max_launches, 1); }
 extern "C" int smot_xcorr_timer_end(double* total_ms, int* launches) {
     return smot_kernel_timer_end(0, total_ms, launches);
 }

@@ -49,7 +49,7 @@ _SIGNATURES = {
     "smot_nms_fwd": (ctypes.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
-    "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i]),
+    "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i, _i]),
     "smot_kernel_timer_end": (ctypes.c_int, [_i, _vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
@@ -354,9 +354,9 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
 TIMER_XCORR, TIMER_TOWER = 0, 1
 
 
-def kernel_timer_begin(slot, max_launches):
+def kernel_timer_begin(slot, max_launches, stride=1):
     """Start bracketing the kernels of ``slot`` with HIP events on their launch stream (bench.py)."""
-    _check(load_library().smot_kernel_timer_begin(int(slot), int(max_launches)), "kernel_timer_begin")
+    _check(load_library().smot_kernel_timer_begin(int(slot), int(max_launches), int(stride)), "kernel_timer_begin")
 
 
 def kernel_timer_end(slot):
