@@ -36,7 +36,9 @@ def broadcast_module(module, src=0):
     """Broadcast every parameter and buffer of ``module`` from rank ``src`` as ONE flat fp32
     buffer (a single collective: xGMI rings are per-link bound, so one large message beats many
     small ones).  Returns the number of bytes broadcast (0 when not distributed)."""
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    # the tensors themselves, not ``.data`` aliases: an in-place copy through ``.data`` does not advance the
+    # tensor's version counter, and derived parameter caches (ops.tower_packed) key on it
+    tensors = list(module.parameters()) + list(module.buffers())
     tensors = [t for t in tensors if t.is_floating_point()]
     if not is_distributed() or not tensors:
         return 0
