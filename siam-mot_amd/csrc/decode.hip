@@ -106,18 +106,20 @@ __device__ __forceinline__ float cell_score(const float* v, float box_w, float b
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// v = {cls0 - cls1, center, l + r, t + b}: the four derived planes are interpolated instead of the seven logits
+// (bicubic interpolation is linear, so this differs from the seven-plane result by rounding only).
 __device__ __forceinline__ float cell_score_fast(const float* v, float inv_bw, float inv_bh, float win,
                                                  const DecodeParams& D) {
     // softmax over two classes and the centerness sigmoid share one reciprocal:
     //   p1 * sig = 1 / ((1 + exp(v0 - v1)) * (1 + exp(-v2)))
-    float den = 1.0f + fast_exp(v[0] - v[1]);
-    if (D.use_centerness) den *= 1.0f + fast_exp(-v[2]);
+    float den = 1.0f + fast_exp(v[0]);
+    if (D.use_centerness) den *= 1.0f + fast_exp(-v[1]);
     const float conf = fast_rcp(den);
     // max(a, 1/a) * max(b, 1/b) with ONE reciprocal r = 1/(a*b) (1/a = b*r, 1/b = a*r).  max(a, 1/a) is a
     // itself for a >= 1 and for -1 <= a < 0 (bicubic overshoot can make the sizes negative), else 1/a.
     // NaN in a or b makes r NaN and every comparison false -> NaN (propagates, as max_nan does in the exact path).
-    const float a = (v[5] + v[3]) * inv_bw;
-    const float b = (v[6] + v[4]) * inv_bh;
+    const float a = v[2] * inv_bw;
+    const float b = v[3] * inv_bh;
     const float ab = a * b;
     const float r = fast_rcp(ab);
     const bool pa = (a >= 1.0f) || (a < 0.0f && a >= -1.0f);
@@ -140,6 +142,7 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
     __shared__ unsigned long long wbest[4];
     __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
+    __shared__ float dv[4][4][64];     // ranking planes {cls0-cls1, center, l+r, t+b} of the band's 4 source rows
     const int n = blockIdx.x;
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
     const int Ho = D.Ho, up = D.up, G = D.G;
@@ -189,12 +192,22 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     }
     __syncthreads();
 
-    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
-    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
-    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
     int rows[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
+    for (int e = threadIdx.x; e < 4 * Ho; e += 256) {              // (k, col)
+        const int k = e / Ho, col = e - k * Ho;
+        const float* q = lg + rows[k] * Ho + col;
+        const int hw = Ho * Ho;
+        dv[0][k][col] = q[0] - q[hw];
+        dv[1][k][col] = q[2 * hw];
+        dv[2][k][col] = q[5 * hw] + q[3 * hw];
+        dv[3][k][col] = q[6 * hw] + q[4 * hw];
+    }
+    __syncthreads();
+    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
+    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
+    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
 
     unsigned long long best = 0ull;
     bool have = false;
@@ -210,21 +223,21 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
 #pragma unroll
         for (int k = 0; k < 4; ++k) cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
         // horizontal pass: h[ch][k] for the band's four source rows
-        float h[7][4];
+        float h[4][4];
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch)
+        for (int ch = 0; ch < 4; ++ch)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float* rowp = lg + (ch * Ho + rows[k]) * Ho;
+                const float* rowp = dv[ch][k];
                 h[ch][k] = interp4_fma(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
             }
         const float hx = hann[X];
         for (int Y = y_begin; Y < y_end; ++Y) {
             const float4 w4 = *reinterpret_cast<const float4*>(wy_tab[Y - y_begin]);
             const float wy[4] = {w4.x, w4.y, w4.z, w4.w};
-            float v[7];
+            float v[4];
 #pragma unroll
-            for (int ch = 0; ch < 7; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
+            for (int ch = 0; ch < 4; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
             const float win = hann[Y] * hx;
             const float s = cell_score_fast(v, inv_bw, inv_bh, win, D);
             const unsigned long long key = make_key(s, (unsigned)(Y * G + X));
@@ -355,7 +368,7 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     const long long G = (long long)Ho * up;
     SMOT_REQUIRE(G <= 256 * DEC_MAX_COLS, "decode: grid %lld too wide (max %d)", G, 256 * DEC_MAX_COLS);
     const size_t smem = (size_t)7 * Ho * Ho * sizeof(float);
-    SMOT_REQUIRE(smem <= 64 * 1024, "decode: Ho=%d too large for LDS", Ho);
+    SMOT_REQUIRE(smem <= 64 * 1024 && Ho <= 64, "decode: Ho=%d too large for LDS", Ho);
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE((L.logits || L.part) && sr && boxes && hann && cand_ws && bb && conf, "decode: null pointer");
     SMOT_REQUIRE(((uintptr_t)cand_ws & 7) == 0, "decode: cand_ws must be 8-byte aligned");
