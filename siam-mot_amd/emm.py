@@ -145,14 +145,18 @@ class EMM(nn.Module):
             raise NotImplementedError("siammot_amd.EMM is an inference path; training "
                                       "(track_core.py:45-47,56-67) is out of scope")
         assert len(boxes) == 1                                           # track_core.py:75
-        fe = self.feature_extractor.pooler_x
+        st = self.__dict__.get("_static")
+        if st is None:                   # submodule / attribute lookups go through nn.Module.__getattr__: once
+            fe, pr = self.feature_extractor.pooler_x, self.predictor
+            st = self.__dict__["_static"] = (pr.param_dict(), tuple(fe.scales), fe.sampling_ratio, pr.gn_groups,
+                                             pr.gn_eps)
+        params, scales, sampling_ratio, gn_groups, gn_eps = st
         # one library call: pooling -> xcorr -> predictor -> decode (+ the clamp of clip_to_image)
-        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, cat([b.bbox for b in sr], dim=0),
-                                    template_features, self.predictor.param_dict(), self.rx, self.rz,
-                                    fe.scales, fe.sampling_ratio, self.pad_pixels, sigma=self.sigma,
-                                    use_centerness=self.use_centerness,
+        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, sr[0].bbox if len(sr) == 1 else cat([b.bbox for b in sr], dim=0),
+                                    template_features, params, self.rx, self.rz, scales, sampling_ratio,
+                                    self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
                                     clip_wh=None if self.amodal else boxes[0].size,
-                                    gn_groups=self.predictor.gn_groups, gn_eps=self.predictor.gn_eps)
+                                    gn_groups=gn_groups, gn_eps=gn_eps)
         track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
         return {}, track_result, {}
 
@@ -160,9 +164,12 @@ class EMM(nn.Module):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""
         detection = [detection]
         tu = self.track_utils
-        fz = self.feature_extractor.pooler_z
         det = detection[0]
-        x, sr_bbox = ops.emm_extract_cache(features, det.bbox, self.rz, fz.scales, fz.sampling_ratio,
+        sz = self.__dict__.get("_static_z")
+        if sz is None:
+            fz = self.feature_extractor.pooler_z
+            sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
+        x, sr_bbox = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1],
                                            tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
         w, h = det.size
         sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
@@ -175,12 +182,13 @@ def wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=False):
     """reference track_core.py:165-181 (one image per call)."""
     out = []
     n0 = 0
+    whole = len(boxes) == 1 and len(boxes[0]) == bb.shape[0]      # one image: no slicing views needed
     for _boxes in boxes:
         n1 = n0 + len(_boxes)
-        tb = _boxes.__class__(bb[n0:n1].reshape(-1, 4), _boxes.size, mode="xyxy")
+        tb = _boxes.__class__(bb if whole else bb[n0:n1].reshape(-1, 4), _boxes.size, mode="xyxy")
         tb.add_field("ids", _boxes.get_field("ids"))
         tb.add_field("labels", _boxes.get_field("labels"))
-        tb.add_field("scores", bb_conf[n0:n1])
+        tb.add_field("scores", bb_conf if whole else bb_conf[n0:n1])
         if not amodal:
             # as the reference: the returned (filtered) copy is discarded — boxes are clamped in
             # place, empty ones are NOT removed (track_core.py:177-178)

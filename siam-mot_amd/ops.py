@@ -96,7 +96,17 @@ def _dev_f32(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _stream():
+try:
+    _raw_stream = torch._C._cuda_getCurrentRawStream         # (device index) -> hipStream_t as int, ~0.2 us
+except AttributeError:                                        # pragma: no cover - older torch
+    _raw_stream = None
+
+
+def _stream(device=None):
+    """The current torch stream of ``device`` as a raw handle (launches are enqueued on it)."""
+    if _raw_stream is not None:
+        idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+        return ctypes.c_void_p(_raw_stream(idx))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -234,10 +244,11 @@ _hann_cache = {}
 def hann_window(G, device):
     """``torch.hann_window(G)`` (periodic) evaluated on the CPU — bit-identical to what the CPU
     reference multiplies in (track_core.py:157-158) — cached per device."""
-    key = (G, str(device))
-    if key not in _hann_cache:
-        _hann_cache[key] = torch.hann_window(G, dtype=torch.float).to(device)
-    return _hann_cache[key]
+    key = (G, device)
+    w = _hann_cache.get(key)
+    if w is None:
+        w = _hann_cache[key] = torch.hann_window(G, dtype=torch.float).to(device)
+    return w
 
 
 def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=True, return_index=False,
@@ -290,7 +301,7 @@ _ws_cache = {}
 def _workspace(device, n_floats):
     """Grow-only fp32 scratch per device (intermediates never leave the library; nothing persists
     semantically between calls)."""
-    key = str(device)
+    key = device
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty((int(n_floats * 1.25) + 1024,), dtype=torch.float32, device=device)
@@ -298,56 +309,162 @@ def _workspace(device, n_floats):
     return buf
 
 
+# ---- launch state reused across frames --------------------------------------------------------
+# A frame pair is ~80 us of GPU work, so the host side of the two one-call entry points has to stay well below
+# that: everything that does not change from frame to frame (per-level geometry arrays, the validated parameter
+# pointer block, the packed tower filters, the Hann window, the workspace) is cached; per call only the feature /
+# box pointers are refreshed and checked.
+_F32 = torch.float32
+
+
+class _LevelGeometry(object):
+    """ctypes arrays of one FPN geometry: heights / widths / scales / virtual pad cells, plus the pointer array
+    that is refilled every call."""
+    __slots__ = ("shapes", "L", "C", "fp", "hs", "ws", "sc", "pc", "a_fp", "a_hs", "a_ws", "a_sc", "a_pc", "keep")
+
+    def __init__(self, shapes, scales, pad_pixels):
+        L = len(scales)
+        self.shapes, self.L, self.C = shapes, L, shapes[0][1]
+        self.fp = (ctypes.c_void_p * L)()
+        self.hs = (ctypes.c_int * L)(*[sh[2] for sh in shapes])
+        self.ws = (ctypes.c_int * L)(*[sh[3] for sh in shapes])
+        self.sc = (ctypes.c_float * L)(*[float(v) for v in scales])
+        self.pc = (ctypes.c_int * L)(*[int(pad_pixels / ((2 ** i) * 4)) for i in range(L)])
+        self.a_fp, self.a_hs, self.a_ws = ctypes.addressof(self.fp), ctypes.addressof(self.hs), ctypes.addressof(self.ws)
+        self.a_sc, self.a_pc = ctypes.addressof(self.sc), ctypes.addressof(self.pc)
+        self.keep = [None] * L                   # contiguous copies of strided inputs, alive until the next call
+
+
+_geom_cache = {}
+
+
+def _geometry(features, scales, pad_pixels):
+    """Validate the per-level feature tensors and return the cached geometry with fresh pointers."""
+    L = len(scales)
+    shapes = tuple(tuple(features[l].shape) for l in range(L))
+    key = (shapes, tuple(scales), pad_pixels)
+    g = _geom_cache.get(key)
+    if g is None:
+        for sh in shapes:
+            if len(sh) != 4 or sh[0] != 1 or sh[1] != shapes[0][1]:
+                raise RuntimeError("siammot_amd: one image per call and one channel count, got feature shapes %s"
+                                   % (shapes,))
+        if len(_geom_cache) > 32:
+            _geom_cache.clear()
+        g = _geom_cache[key] = _LevelGeometry(shapes, scales, pad_pixels)
+    fp = g.fp
+    for l in range(L):
+        f = features[l]
+        if not (f.is_cuda and f.dtype is _F32 and f.is_contiguous()):
+            f = g.keep[l] = _dev_f32(f, "features[%d]" % l)         # raises, or copies a strided view
+        fp[l] = f.data_ptr()
+    return g
+
+
+class _ParamBlock(object):
+    """The 12 predictor tensors validated once, their pointers as a ctypes block, and the Winograd-packed tower
+    filters; revalidated per call by data pointer + version counter (a dozen attribute reads)."""
+    __slots__ = ("params", "tensors", "stamp", "pp", "a_pp", "packed", "C")
+
+    def __init__(self, params):
+        self.params = params                     # keeps the dict (and so its id) alive while cached
+        self.refresh()
+
+    def refresh(self):
+        w = [_dev_f32(self.params[k], k) for k in PREDICTOR_KEYS]
+        C = w[0].shape[0]
+        expect = {0: (C, C, 3, 3), 3: (C, C, 3, 3), 6: (2, C, 3, 3), 8: (1, C, 3, 3), 10: (4, C, 3, 3)}
+        for i, shp in expect.items():
+            if tuple(w[i].shape) != shp:
+                raise RuntimeError("siammot_amd: %s has shape %s, expected %s" % (PREDICTOR_KEYS[i], tuple(w[i].shape), shp))
+        self.tensors, self.C = w, C
+        self.stamp = [(t.data_ptr(), t._version) for t in w]
+        self.packed = tower_packed(self.params)
+        self.pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in w] + [self.packed.data_ptr() if self.packed is not None else None]))
+        self.a_pp = ctypes.addressof(self.pp)
+
+    def current(self):
+        p, st = self.params, self.stamp
+        for i, k in enumerate(PREDICTOR_KEYS):
+            t = p[k]
+            s = st[i]
+            if t.data_ptr() != s[0] or t._version != s[1]:
+                self.refresh()
+                break
+        return self
+
+
+_param_cache = {}
+
+
+def _param_block(params):
+    blk = _param_cache.get(id(params))
+    if blk is None or blk.params is not params:
+        if len(_param_cache) > 16:
+            _param_cache.clear()
+        blk = _param_cache[id(params)] = _ParamBlock(params)
+        return blk
+    return blk.current()
+
+
+def _chk(t, name, shape):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype is _F32):
+        _dev_f32(t, name)
+    if tuple(t.shape) != shape:
+        raise RuntimeError("siammot_amd: %s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_ratio, pad_pixels,
               sigma=0.4, use_centerness=True, clip_wh=None, gn_groups=32, gn_eps=1e-5, return_index=False,
               winograd=True):
     """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``)."""
-    lib = load_library()
-    boxes = _dev_f32(boxes, "boxes")
-    sr = _dev_f32(sr, "sr")
-    templates = _dev_f32(templates, "template_features")
-    N = boxes.shape[0]
+    lib = _lib or load_library()
+    g = _geometry(features, scales, pad_pixels)
+    N, C = boxes.shape[0], g.C
+    boxes = _chk(boxes, "boxes", (N, 4))
+    sr = _chk(sr, "sr", (N, 4))
+    templates = _chk(templates, "template_features", (N, C, rz, rz))
     dev = boxes.device
-    feats, fp, hs, ws_, sc = _level_arrays(features, scales)
-    C = feats[0].shape[1]
-    if tuple(templates.shape) != (N, C, rz, rz) or tuple(sr.shape) != (N, 4):
-        raise RuntimeError("siammot_amd.emm_track: %d boxes, templates %s, sr %s do not agree"
-                           % (N, tuple(templates.shape), tuple(sr.shape)))
-    L = len(scales)
-    pc = (ctypes.c_int * L)(*[int(pad_pixels / ((2 ** i) * 4)) for i in range(L)])
-    w = [_dev_f32(params[k], k) for k in PREDICTOR_KEYS]
+    blk = _param_block(params)
+    if blk.C != C:
+        raise RuntimeError("siammot_amd.emm_track: predictor has %d channels, features have %d" % (blk.C, C))
     ho = rx - rz + 1
-    packed = tower_packed(params) if (winograd and ho == 16) else None
-    pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in w] + [packed.data_ptr() if packed is not None else None]))
+    a_pp = blk.a_pp
+    if not (winograd and ho == 16) and blk.packed is not None:
+        pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in blk.tensors] + [None]))    # direct tower kernel
+        a_pp = ctypes.addressof(pp)
     work = _workspace(dev, lib.smot_emm_track_ws_floats(N, C, rx, rz))
-    bb = torch.empty((N, 4), dtype=torch.float32, device=dev)
-    conf = torch.empty((N,), dtype=torch.float32, device=dev)
+    bb = torch.empty((N, 4), dtype=_F32, device=dev)
+    conf = torch.empty((N,), dtype=_F32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
-    rc = lib.smot_emm_track_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C,
-                                _ptr(boxes), _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
-                                _cast(pp), int(gn_groups), float(gn_eps), _ptr(hann_window(ho * UP_SCALE, dev)),
-                                UP_SCALE, float(pad_pixels), float(1 - sigma), float(sigma),
-                                int(bool(use_centerness)),
+    rc = lib.smot_emm_track_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, C,
+                                boxes.data_ptr(), sr.data_ptr(), templates.data_ptr(), N, rx, rz, sampling_ratio,
+                                a_pp, gn_groups, gn_eps, hann_window(ho * UP_SCALE, dev).data_ptr(),
+                                UP_SCALE, pad_pixels, 1 - sigma, sigma, 1 if use_centerness else 0,
                                 float(clip_wh[0]) if clip_wh is not None else 0.0,
                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
-                                _ptr(work), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
-    _check(rc, "emm_track")
+                                work.data_ptr(), bb.data_ptr(), conf.data_ptr(),
+                                idx.data_ptr() if idx is not None else None, _stream(dev))
+    if rc:
+        _check(rc, "emm_track")
     return (bb, conf, idx) if return_index else (bb, conf)
 
 
 def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh):
     """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``)."""
-    lib = load_library()
-    boxes = _dev_f32(boxes, "boxes")
-    N = boxes.shape[0]
-    feats, fp, hs, ws_, sc = _level_arrays(features, scales)
-    C = feats[0].shape[1]
-    templates = torch.empty((N, C, rz, rz), dtype=torch.float32, device=boxes.device)
-    sr = torch.empty((N, 4), dtype=torch.float32, device=boxes.device)
-    rc = lib.smot_emm_extract_cache_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(sc), len(scales), C, _ptr(boxes), N,
-                                        int(rz), int(sampling_ratio), float(pad_pixels), float(search_expansion),
-                                        float(min_search_wh), _ptr(templates), _ptr(sr), _stream())
-    _check(rc, "emm_extract_cache")
+    lib = _lib or load_library()
+    g = _geometry(features, scales, 0)
+    N, C = boxes.shape[0], g.C
+    boxes = _chk(boxes, "boxes", (N, 4))
+    dev = boxes.device
+    templates = torch.empty((N, C, rz, rz), dtype=_F32, device=dev)
+    sr = torch.empty((N, 4), dtype=_F32, device=dev)
+    rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
+                                        rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
+                                        templates.data_ptr(), sr.data_ptr(), _stream(dev))
+    if rc:
+        _check(rc, "emm_extract_cache")
     return templates, sr
 
 
