@@ -85,6 +85,10 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #define W_TRACE(SLOT) \
     if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
     W_TRACE(0)
+    if (trace && tid == 0) {      // where this workgroup runs: HW_ID (cu/sh/se) and XCC_ID
+        trace[(size_t)blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_getreg(0xF804);
+        trace[(size_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_getreg(0xF814);
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_per_tower = C >> 4;
@@ -94,6 +98,9 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int n = (slot / tiles) * 8 + xcd;
     const int tile = slot % tiles;
     if (n >= N) return;
+    // (Workgroups b and b + 256 share a CU — HW_ID trace in tools/debug/tower_bench.py.  Delaying the second
+    // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
+    // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
     const int tower = tile / tiles_per_tower;
     const int oc0 = (tile - tower * tiles_per_tower) * 16;
     const float* __restrict__ in = resp + (size_t)n * C * 256;

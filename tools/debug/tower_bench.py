@@ -9,6 +9,7 @@ rs = np.random.RandomState(0)
 boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
 P = {k: torch.from_numpy(v).to(dev) for k, v in gi.predictor_params(rs, 128, boxes).items()}
 ABLS = os.environ.get("ABLS", "0").split(",")
+STAGGERS = [v for v in os.environ.get("STAGGERS", "").split(",") if v]
 for n in (30, 100):
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     for abl in ABLS:
@@ -24,6 +25,21 @@ for n in (30, 100):
             ts.append(ms / cnt * 1e3)
         print(json.dumps({"tracks": n, "variant": abl, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
 os.environ["SMOT_WINO_ABL"] = "0"
+for stg in STAGGERS:
+    os.environ["SMOT_WINO_STAGGER"] = stg
+    for n in (30, 100):
+        resp = torch.randn(n, 128, 16, 16, device=dev) * 15
+        f = lambda: ops.emm_predictor(resp, P)
+        for _ in range(200): f()
+        torch.cuda.synchronize()
+        ts = []
+        for rep in range(5):
+            ops.kernel_timer_begin(ops.TIMER_TOWER, 300)
+            for _ in range(300): f()
+            ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
+            ts.append(ms / cnt * 1e3)
+        print(json.dumps({"tracks": n, "stagger": stg, "tower_event_us_min": round(min(ts), 2)}), flush=True)
+os.environ["SMOT_WINO_STAGGER"] = "0"
 # phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
 lib = ops.load_library()
 for n in (30, 100):
@@ -41,3 +57,20 @@ for n in (30, 100):
     print(json.dumps({"tracks": n, "blocks": len(t), "phase_ticks_mean": [round(float(x), 1) for x in d.mean(0)],
                       "phase_ticks_max": [int(x) for x in d.max(0)], "block_total_mean": round(float((t[:, 5] - t[:, 0]).mean()), 1),
                       "kernel_span_ticks": int(t[:, 5].max() - t0), "start_spread": int(t[:, 0].max() - t0)}), flush=True)
+
+    if n == 30:
+        tt = tr.view(grid, 8).cpu().numpy()
+        hw, xcc = tt[:, 6], tt[:, 7]
+        cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; xc = xcc & 0xF
+        key = xc * 10000 + se * 1000 + sh * 100 + cu
+        import collections
+        groups = collections.defaultdict(list)
+        for b in range(grid):
+            if tt[b, 5] != 0: groups[int(key[b])].append(b)
+        sizes = collections.Counter(len(v) for v in groups.values())
+        print(json.dumps({"cus_used": len(groups), "blocks_per_cu_hist": dict(sizes)}))
+        pairs = [v for v in groups.values() if len(v) == 2][:12]
+        print("sample co-resident pairs (block ids):", pairs)
+        diffs = collections.Counter((v[1] - v[0]) for v in groups.values() if len(v) == 2)
+        print("pair id differences:", diffs.most_common(6))
+        print("xcc of blocks 0..15:", [int(x) for x in xc[:16]])
