@@ -392,29 +392,29 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 
     W_TRACE(4)
     // ---- fused partial heads: this tile's 16 channels x 9 taps -> 4 head outputs per position ---------
+    // v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction, block = 4 neighbouring
+    // positions: A = the 4 head weights of one (channel, tap) (lane%4 = output), B = the lane's own activation,
+    // D[output][position] accumulates in 4 VGPRs per lane — the layout the stores below need.  256 MACs per
+    // 8-cycle instruction: twice the v_fmac rate with no padding waste, and half the instructions
+    // (2 LDS reads + 1 MFMA instead of 2 LDS reads + 4 FMAs per tap).  One fmaf chain per output, as before.
     {
         const int py = tid >> 4, px = tid & 15;
-        float h0 = 0.0f, h1 = 0.0f, h2 = 0.0f, h3 = 0.0f;
+        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* pl0 = planes + py * 18 + px;
+        const float* hwl = hw + (lane & 3);
 #pragma unroll 4
         for (int cl = 0; cl < 16; ++cl) {
             const float* pl = pl0 + cl * T_PLANE;
-            const float4* wrow = reinterpret_cast<const float4*>(hw + cl * 36);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const float a = pl[(tap / 3) * 18 + (tap % 3)];
-                const float4 w = wrow[tap];
-                h0 = fmaf(a, w.x, h0);
-                h1 = fmaf(a, w.y, h1);
-                h2 = fmaf(a, w.z, h2);
-                h3 = fmaf(a, w.w, h3);
-            }
+            for (int tap = 0; tap < 9; ++tap)
+                hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwl[(cl * 9 + tap) * 4], pl[(tap / 3) * 18 + (tap % 3)], hacc, 0,
+                                                          0, 0);
         }
         float* __restrict__ dst = part + ((size_t)n * tiles + tile) * 4 * 256 + tid;
-        dst[0 * 256] = h0;
-        dst[1 * 256] = h1;
-        dst[2 * 256] = h2;
-        dst[3 * 256] = h3;
+        dst[0 * 256] = hacc[0];
+        dst[1 * 256] = hacc[1];
+        dst[2 * 256] = hacc[2];
+        dst[3 * 256] = hacc[3];
     }
     W_TRACE(5)
 #undef W_TRACE
