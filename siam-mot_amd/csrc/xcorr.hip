@@ -21,6 +21,7 @@
 // No workgroup barrier is needed: each wave only touches its own LDS slab.
 #include "smot_common.h"
 #include "xcorr_patch2.h"
+#include "xcorr_mfma.h"
 #include <stdlib.h>
 
 namespace smot {
@@ -547,6 +548,63 @@ xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
     xcorr_patch2_compute<RX, RZ, MODE>(xs, zs, lane, out, plane0, planes);
 }
 
+// Fifth generation: the correlation on v_mfma_f32_4x4x1 (xcorr_mfma.h) — same staging as above into the MFMA
+// path's LDS image (row stride 40, four shifted template copies).
+template <int RX, int RZ>
+__global__ void __launch_bounds__(64, 4)
+xcorr_dw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out, int planes) {
+    constexpr int XP = RX * XM_XS, ZP = 4 * RZ * XM_ZC;
+    __shared__ __attribute__((aligned(16))) float sm[2 * XP + 2 * ZP];
+    float* xs = sm;
+    float* zs = sm + 2 * XP;
+    const int lane = threadIdx.x;
+    const int plane0 = blockIdx.x * 2;
+    constexpr int NX2 = (2 * RX * RX / 2 + 63) / 64;     // float2 per lane: a row of 30 is 15 float2
+    constexpr int NZ = (2 * RZ * RZ + 63) / 64;
+    const long long last2 = (long long)planes * (RX * RX / 2) - 1;
+    const float2* __restrict__ xg2 = reinterpret_cast<const float2*>(x);
+    float2 sx[NX2];
+#pragma unroll
+    for (int t = 0; t < NX2; ++t) {
+        long long gk = (long long)plane0 * (RX * RX / 2) + lane + 64 * t;
+        gk = gk < last2 ? gk : last2;                      // odd plane counts: re-read valid memory
+        sx[t] = xg2[gk];
+    }
+    const long long lastz = (long long)planes * (RZ * RZ) - 1;
+    float sz[NZ];
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) {
+        long long ge = (long long)plane0 * (RZ * RZ) + lane + 64 * t;
+        ge = ge < lastz ? ge : lastz;
+        sz[t] = z[ge];
+    }
+    xm_zero_template_pad<RZ>(zs, lane);
+    xm_zero_template_pad<RZ>(zs + ZP, lane);
+#pragma unroll
+    for (int t = 0; t < NX2; ++t) {
+        const int k = lane + 64 * t;
+        if (k < 2 * RX * RX / 2) {
+            const int e0 = 2 * k;
+            const int pl = e0 / (RX * RX);
+            const int el = e0 - pl * (RX * RX);
+            const int r = el / RX;
+            *reinterpret_cast<float2*>(xs + pl * XP + r * XM_XS + (el - r * RX)) = sx[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) {
+        const int e = lane + 64 * t;
+        if (e < 2 * RZ * RZ) {
+            const int pl = e / (RZ * RZ);
+            const int el = e - pl * (RZ * RZ);
+            const int u = el / RZ;
+            xm_store_template<RZ>(zs + pl * ZP, u, el - u * RZ, sz[t]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    xcorr_mfma_compute<RX, RZ>(xs, zs, lane, out, plane0, planes);
+}
+
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.
 __global__ void __launch_bounds__(256)
 xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -594,6 +652,8 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
             hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
         } else if (v0 == 'p' && v1 == 'k') {        // "pk": four planes per wave, packed FMA
             hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
+        } else if (v0 == 'm') {                     // "mfma": 4x4x1 matrix-instruction correlation
+            hipLaunchKernelGGL((xcorr_dw_mfma_kernel<30, 15>), g2, b64, 0, st, x, z, out, planes);
         } else if (v0 == 'f') {                     // "fill": default kernel without FMAs
             hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 1>), g2, b64, 0, st, x, z, out, planes);
         } else if (v0 == 'c') {                     // "compute": default kernel without global loads

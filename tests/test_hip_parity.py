@@ -223,6 +223,20 @@ def test_xcorr_full_size_properties(ops, n):
     assert float((ops.xcorr_depthwise(x[:k].contiguous(), z1[:k].contiguous()) - ref).abs().max()) < 5e-4
 
 
+@pytest.mark.parametrize("variant", ["mfma", "vfma", "patch", "wave"])
+def test_xcorr_kernel_generations_are_bitwise_equal(ops, variant, monkeypatch):
+    """Every generation accumulates each output as one fp32 fmaf chain in (u, v) order — including the
+    4x4x1 matrix-instruction kernel, whose extra zero-weight taps add exact zeros."""
+    rs = np.random.RandomState(17)
+    x = _d(rs.standard_normal((5, 9, 30, 30)).astype(np.float32))          # 45 planes: odd count, ragged tail
+    z = _d(rs.standard_normal((5, 9, 15, 15)).astype(np.float32))
+    ref = ops.xcorr_depthwise(x, z)
+    monkeypatch.setenv("SMOT_XCORR_VARIANT", variant)
+    got = ops.xcorr_depthwise(x, z)
+    monkeypatch.delenv("SMOT_XCORR_VARIANT")
+    assert torch.equal(got, ref), "max diff %g" % float((got - ref).abs().max())
+
+
 def test_xcorr_rejects_bad_inputs(ops):
     with pytest.raises(RuntimeError):
         ops.xcorr_depthwise(torch.zeros(1, 2, 30, 30), torch.zeros(1, 2, 15, 15))          # CPU tensors
@@ -507,6 +521,61 @@ def test_emm_configs_3_and_5(ops, label, channels, image_wh, n):
                                 _t(boxes[sample]), sr_ref, z_ref, image_wh)
     assert (iou(res0.bbox.cpu().numpy()[sample], bb.numpy()) >= 1 - 1e-3).all()
     _assert_close(res0.get_field("scores")[sample], conf, 0, 1e-4, label + " scores vs oracle")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_emm_random_geometry_against_oracle(ops, seed):
+    """Seeded fuzz of the box geometry: tiny, huge, thin, partly / fully outside, sub-pixel positions, every FPN
+    level, windows on both sides of the 32- and 64-column kernel paths.  Stage by stage against the oracle."""
+    from siammot_amd.structures import BoxList
+    case = dict(gi.EMM_CASES["default"], channels=32, image_wh=(640, 384))
+    rs = np.random.RandomState(1000 + seed)
+    W, H = case["image_wh"]
+    shapes = gi.feature_shapes(case["image_wh"], 32)
+    feats_a = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    feats_b = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+    n = 41
+    w = np.exp(rs.uniform(np.log(3), np.log(700), n))
+    h = np.exp(rs.uniform(np.log(3), np.log(500), n))
+    x1 = rs.uniform(-0.4 * w, W - 0.6 * w)
+    y1 = rs.uniform(-0.4 * h, H - 0.6 * h)
+    boxes = np.stack((x1, y1, x1 + w, y1 + h), 1).astype(np.float32)
+    boxes[0] = (-300.0, -300.0, -250.0, -200.0)                 # fully outside, far in the virtual border
+    boxes[1] = (10.0, 10.0, 11.0, 11.0)                         # one pixel
+    boxes[2] = (0.0, 100.0, 639.0, 104.0)                       # thin and image-wide (window > 64 columns)
+    params = gi.predictor_params(rs, 32, boxes[3:])
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in params.items()})
+    det = BoxList(_d(boxes), case["image_wh"], mode="xyxy")
+    det.add_field("ids", torch.arange(n, device=DEV))
+    det.add_field("labels", torch.ones(n, dtype=torch.int64, device=DEV))
+    with torch.no_grad():
+        z, sr, det_out = emm.extract_cache(tuple(_d(f) for f in feats_a), det)
+        _, result, _ = emm(tuple(_d(f) for f in feats_b), det_out, sr, template_features=z)
+    cfg = _cfg(case)
+    z_ref, sr_ref = O.extract_cache(cfg, [_t(f) for f in feats_a], _t(boxes))
+    assert torch.equal(sr[0].bbox.cpu(), sr_ref)
+    _assert_close(z, z_ref, 1e-5, 1e-5, "templates")
+    bb, conf, keep, inter = O.emm_forward(cfg, {k: _t(v) for k, v in params.items()}, [_t(f) for f in feats_b],
+                                          _t(boxes), sr_ref, z_ref, case["image_wh"], return_intermediates=True)
+    resp = ops.sr_xcorr_fused(tuple(_d(f) for f in feats_b), _d(boxes), sr[0].bbox, z, 30, 15, case["scales"], 2, 512)
+    mag = float(inter["response"].abs().max())
+    _assert_close(resp, inter["response"], 0, 2e-5 * max(mag, 1.0), "fused response")
+    got = result[0].bbox.cpu().numpy()
+    ious = iou(got, bb.numpy())
+    ok = ious >= 1 - 1e-3
+    if not ok.all():
+        # a different arg-max cell is acceptable only if the two cells tie in the fp64 oracle (module docstring)
+        p64 = {k: _t(v, torch.float64) for k, v in params.items()}
+        bb64, conf64, _, i64 = O.emm_forward(cfg, p64, [_t(f, torch.float64) for f in feats_b],
+                                             _t(boxes, torch.float64), sr_ref.double(), z_ref.double(),
+                                             case["image_wh"], return_intermediates=True)
+        bad = np.nonzero(~ok)[0]
+        assert len(bad) <= 2, "IoU vs oracle: %s" % ious
+        for t in bad:      # the GPU's box must then coincide with the fp64 oracle's choice, or with the fp32 one
+            alt = iou(got[t:t + 1], bb64.numpy()[t:t + 1].astype(np.float32))
+            assert alt[0] >= 1 - 1e-3, "track %d: IoU %.4f vs fp32 oracle, %.4f vs fp64 oracle" % (t, ious[t], alt[0])
+    _assert_close(result[0].get_field("scores")[torch.from_numpy(ok)], conf[torch.from_numpy(ok)], 0, 1e-4, "scores")
 
 
 def test_emm_training_mode_is_refused(ops):
