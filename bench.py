@@ -175,6 +175,34 @@ def cpu_baseline(n_tracks, budget_s=10.0, timeout_s=150.0):
                 "sample": "cpu leg exceeded %.0f s and was stopped" % timeout_s}
 
 
+def multi_stream_throughput(emm, feats, det, n_streams, dev, steps=600):
+    """S independent video streams (own track memory) on S HIP streams of one GPU: the serving configuration of
+    SURVEY.md §8(e) when a GPU hosts more than one camera.  Kernels of different streams overlap, filling the
+    ramp-up / tail of each other's launches.  Informational: `value` stays the single-stream number."""
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+    with torch.no_grad():
+        states = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                states.append(emm.extract_cache(feats[1], det))
+
+        def run(k_steps):
+            for k in range(k_steps):
+                for i, st in enumerate(streams):
+                    with torch.cuda.stream(st):
+                        z, sr, d = states[i]
+                        emm(feats[k & 1], d, sr, template_features=z)
+                        states[i] = emm.extract_cache(feats[k & 1], det)
+        run(100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"streams": n_streams, "steps_per_stream": steps, "value": n_streams * steps / dt, "unit": "frame-pairs/s",
+            "ms_per_step_per_stream": dt / steps * 1e3}
+
+
 def tower_roofline(n, total_ms, launches):
     algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
@@ -198,6 +226,9 @@ def main():
                          "idle states before the W warm-up steps (a 200-step run measured 0.29 ms/step, a 2000-step "
                          "run 0.16 ms/step on the same box); 0 disables")
     ap.add_argument("--tracks", type=int, default=30)
+    ap.add_argument("--extra-streams", type=int, default=2,
+                    help="after the timed region, also measure S independent video streams on S HIP streams of the same "
+                         "GPU (reported as `multi_stream`, not as `value`); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="skip the HIP-event bracketing of the xcorr launches (roofline fields become null)")
@@ -268,6 +299,9 @@ def main():
         elapsed = time.perf_counter() - t0
         xcorr_total_ms, xcorr_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_XCORR)
         tower_total_ms, tower_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_TOWER)
+    multi = None
+    if world == 1 and args.extra_streams > 1:
+        multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
@@ -340,6 +374,7 @@ def main():
         # matrix cores, i.e. it EXECUTES 2.25x fewer multiply-adds (reported separately, with the matrix-pipe
         # fraction they amount to).
         "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
+        "multi_stream": multi,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)

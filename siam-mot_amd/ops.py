@@ -298,10 +298,10 @@ def _level_arrays(features, scales):
 _ws_cache = {}
 
 
-def _workspace(device, n_floats):
-    """Grow-only fp32 scratch per device (intermediates never leave the library; nothing persists
-    semantically between calls)."""
-    key = device
+def _workspace(device, n_floats, stream=None):
+    """Grow-only fp32 scratch per (device, stream): intermediates never leave the library and nothing persists
+    semantically between calls, but two streams of one device run concurrently and must not share it."""
+    key = (device, stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < n_floats:
         buf = torch.empty((int(n_floats * 1.25) + 1024,), dtype=torch.float32, device=device)
@@ -434,7 +434,8 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     if not (winograd and ho == 16) and blk.packed is not None:
         pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in blk.tensors] + [None]))    # direct tower kernel
         a_pp = ctypes.addressof(pp)
-    work = _workspace(dev, lib.smot_emm_track_ws_floats(N, C, rx, rz))
+    stream = _stream(dev)
+    work = _workspace(dev, lib.smot_emm_track_ws_floats(N, C, rx, rz), stream.value)
     bb = torch.empty((N, 4), dtype=_F32, device=dev)
     conf = torch.empty((N,), dtype=_F32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
@@ -445,7 +446,7 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
                                 float(clip_wh[0]) if clip_wh is not None else 0.0,
                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
                                 work.data_ptr(), bb.data_ptr(), conf.data_ptr(),
-                                idx.data_ptr() if idx is not None else None, _stream(dev))
+                                idx.data_ptr() if idx is not None else None, stream)
     if rc:
         _check(rc, "emm_track")
     return (bb, conf, idx) if return_index else (bb, conf)
