@@ -516,6 +516,26 @@ def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_rati
     return (resp, pooled) if return_pooled else resp
 
 
+def nms_keep_mask(boxes, scores, thresh):
+    """Greedy NMS as a device-resident boolean mask in the ORIGINAL box order (True = kept) — no host
+    synchronisation; ``nms`` below turns it into upstream's index list."""
+    lib = load_library()
+    boxes = _dev_f32(boxes, "boxes")
+    scores = _dev_f32(scores, "scores")
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.bool, device=boxes.device)
+    order = torch.argsort(scores, descending=True, stable=True)
+    sorted_boxes = boxes[order].contiguous()
+    ws = torch.empty((max(lib.smot_nms_ws_bytes(n) // 8, 1),), dtype=torch.int64, device=boxes.device)
+    keep = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
+    rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), _stream(boxes.device))
+    _check(rc, "nms")
+    mask = torch.empty((n,), dtype=torch.bool, device=boxes.device)
+    mask[order] = keep.bool()
+    return mask
+
+
 def nms(boxes, scores, thresh):
     """[UPSTREAM] ``_C.nms(dets, scores, thresh)`` semantics: indices of the kept boxes, ascending (original
     order), after greedy suppression in descending-score order with the +1 IoU convention.  One host sync

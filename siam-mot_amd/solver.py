@@ -1,0 +1,181 @@
+"""Track solver and track pool with one host synchronisation per frame (second half).
+
+Mirrors ``TrackSolver`` (reference siammot/modelling/track_head/track_solver.py:7-108) and ``TrackPool``
+(track_head/track_utils.py:138-250).  The reference merges detections with the boxes propagated from active and
+dormant tracks by score-banded NMS and then starts / suspends / resumes / expires track ids — correct, but written
+with one device synchronisation per box (``int(x) in active_ids`` over a device tensor, ``.item()`` per cached
+track, several ``.tolist()`` / ``.nonzero()``), which caps the frame rate once the tracker head takes 74 us.
+Here the score banding and the NMS stay on the device (``ops.nms_keep_mask``: no sync), ids / scores / keep mask
+cross to the host in ONE copy, the id bookkeeping runs on numpy arrays, and the results go back in one copy.
+
+Semantics are the reference's, statement by statement (cited inline); tests/test_solver.py runs this module and a
+literal restatement of the reference side by side on the same random frames.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .structures import BoxList  # noqa: F401  (duck-typed: any BoxList with bbox / get_field / add_field / __getitem__)
+
+
+class TrackPool(object):
+    """Track-id life cycle and per-track cache (track_utils.py:138-250), host-side state."""
+
+    def __init__(self, active_ids=None, max_entangle_length=10, max_dormant_frames=1):
+        self._active_ids = set()
+        self._dormant_ids = {}          # id -> frame index at which it was last active
+        self._kill_ids = set()
+        self._max_id = -1
+        self._embedding = None
+        self._cache = {}
+        self._frame_idx = 0
+        self._max_dormant_frames = max_dormant_frames
+        self._max_entangle_length = max_entangle_length
+
+    def suspend_track(self, track_id):
+        if track_id not in self._active_ids:
+            raise ValueError
+        self._active_ids.remove(track_id)
+        self._dormant_ids[track_id] = self._frame_idx - 1
+
+    def expire_tracks(self):
+        for track_id, last_active in list(self._dormant_ids.items()):
+            if self._frame_idx - last_active >= self._max_dormant_frames:
+                self._dormant_ids.pop(track_id)
+                self._kill_ids.add(track_id)
+                self._cache.pop(track_id, None)
+
+    def increment_frame(self, value=1):
+        self._frame_idx += value
+
+    def update_cache(self, cache):
+        """Latest (template features, search region, box) per track id — the ids cross to the host in one copy
+        (the reference calls ``.item()`` per track, track_utils.py:196)."""
+        template_features, sr, template_boxes = cache
+        sr, template_boxes = sr[0], template_boxes[0]
+        n = len(template_boxes)
+        if n == 0:
+            return
+        ids = template_boxes.get_field("ids").tolist()
+        has_feat = len(template_features) > 0
+        if has_feat:
+            assert len(template_features) == len(sr)
+        for idx in range(n):
+            self._cache[ids[idx]] = (template_features[idx] if has_feat else template_features,
+                                     sr[idx: idx + 1], template_boxes[idx: idx + 1])
+
+    def resume_track(self, track_id):
+        if track_id not in self._dormant_ids or track_id in self._active_ids:
+            raise ValueError
+        self._active_ids.add(track_id)
+        self._dormant_ids.pop(track_id)
+
+    def kill_track(self, track_id):
+        if track_id not in self._active_ids:
+            raise ValueError
+        self._active_ids.remove(track_id)
+        self._kill_ids.add(track_id)
+        self._cache.pop(track_id, None)
+
+    def start_track(self):
+        self._max_id += 1
+        self._active_ids.add(self._max_id)
+        return self._max_id
+
+    def get_active_ids(self):
+        return self._active_ids
+
+    def get_dormant_ids(self):
+        return set(self._dormant_ids.keys())
+
+    def get_cache(self):
+        return self._cache
+
+    def activate_tracks(self, track_id):
+        self.resume_track(track_id)
+
+    def reset(self):
+        self.__init__(max_entangle_length=self._max_entangle_length, max_dormant_frames=self._max_dormant_frames)
+
+
+class TrackSolver(torch.nn.Module):
+    """Drop-in for the reference ``TrackSolver``: ``forward([BoxList]) -> [BoxList]``.  ``nms_mask_fn(boxes_xyxy,
+    scores, thresh) -> bool mask`` defaults to the HIP NMS kernel (device tensors only)."""
+
+    NMS_THRESH = 0.5                                     # track_solver.py:22
+
+    def __init__(self, track_pool, track_thresh=0.3, start_track_thresh=0.5, resume_track_thresh=0.4,
+                 nms_mask_fn=None):
+        super(TrackSolver, self).__init__()
+        self.track_pool = track_pool
+        self.track_thresh = track_thresh
+        self.start_thresh = start_track_thresh
+        self.resume_track_thresh = resume_track_thresh
+        self.nms_mask_fn = nms_mask_fn or ops.nms_keep_mask
+
+    @torch.no_grad()
+    def forward(self, detection):
+        assert len(detection) == 1                        # :50
+        detection = detection[0]
+        if len(detection) == 0:
+            return [detection]
+        pool = self.track_pool
+        all_ids = detection.get_field("ids")
+        all_scores = detection.get_field("scores")
+        device = all_ids.device
+        dormant_ids = pool.get_dormant_ids()              # snapshot before any state change (:60)
+
+        # active tracks move one score band up, in place on the input field as in the reference (:63-69)
+        active = sorted(pool.get_active_ids())
+        if active:
+            act = torch.tensor(active, dtype=all_ids.dtype, device=device)
+            all_scores[torch.isin(all_ids, act)] += 1.0
+        keep_mask = self.nms_mask_fn(detection.convert("xyxy").bbox, all_scores, self.NMS_THRESH)     # :71, :22
+
+        # ---- the one device -> host copy: ids, banded scores, keep mask -----------------------------
+        host = torch.stack((all_ids.to(torch.float64), all_scores.to(torch.float64), keep_mask.to(torch.float64)),
+                           dim=1).cpu().numpy()
+        ids_all = host[:, 0].astype(np.int64)
+        keep_idx = np.nonzero(host[:, 2] > 0.5)[0]        # ascending original order, as boxlist_nms returns (:22)
+        _ids = ids_all[keep_idx].copy()
+        _scores = host[keep_idx, 1].astype(np.float32)
+        # back to the [0, 1] range (:30-31), fp32 arithmetic as the reference's tensor ops
+        ge2 = _scores >= np.float32(2.0)
+        _scores[ge2] = _scores[ge2] - np.float32(2.0)
+        ge1 = _scores >= np.float32(1.0)
+        _scores[ge1] = _scores[ge1] - np.float32(1.0)
+
+        start_rows = np.nonzero((_ids < 0) & (_scores >= np.float32(self.start_thresh)))[0]          # :78
+        inactive_rows = (_ids >= 0) & (_scores < np.float32(self.track_thresh))                       # :81
+        nms_track_ids = set(_ids[_ids >= 0].tolist())
+        all_track_ids = set(ids_all[ids_all >= 0].tolist())
+        inactive_ids = set(_ids[inactive_rows].tolist()) | (all_track_ids - nms_track_ids)           # :82-86
+        if dormant_ids:
+            dormant_rows = np.isin(_ids, np.fromiter(dormant_ids, dtype=np.int64, count=len(dormant_ids)))
+        else:
+            dormant_rows = np.zeros(len(_ids), dtype=bool)
+        for _id in _ids[dormant_rows & (_scores >= np.float32(self.resume_track_thresh))].tolist():  # :89-92
+            pool.resume_track(_id)
+        for r in start_rows.tolist():                                                                  # :94-95
+            _ids[r] = pool.start_track()
+        active_ids = pool.get_active_ids()
+        for _id in inactive_ids:                                                                       # :97-100
+            if _id in active_ids:
+                pool.suspend_track(_id)
+        _ids[inactive_rows] = -1                                                                       # :103
+        pool.expire_tracks()
+        pool.increment_frame()
+
+        # ---- one host -> device copy: kept rows, new ids, rescaled scores ----------------------------
+        back = torch.from_numpy(np.stack((keep_idx.astype(np.float64), _ids.astype(np.float64),
+                                          _scores.astype(np.float64)), axis=1)).to(device, non_blocking=True)
+        out = detection[back[:, 0].to(torch.int64)]
+        out.add_field("ids", back[:, 1].to(all_ids.dtype))
+        out.add_field("scores", back[:, 2].to(all_scores.dtype))
+        return [out]
+
+
+def builder_tracker_solver(cfg, track_pool):
+    """Same factory signature as the reference (track_solver.py:111-115)."""
+    th = cfg.MODEL.TRACK_HEAD
+    return TrackSolver(track_pool, th.TRACK_THRESH, th.START_TRACK_THRESH, th.RESUME_TRACK_THRESH)

@@ -1,0 +1,101 @@
+"""Track solver / track pool: the one-sync solver against a literal restatement of the
+reference's solver, frame after frame on random scenes, with two pools that must evolve identically."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import solver_oracle as SO
+
+
+def _scene(rs, pool, n_det, n_missing):
+    """Detections (id -1, score in (0,1)) + boxes propagated from active / dormant tracks (score in (1,2])."""
+    W, H = 1280, 704
+    tracks = sorted(pool.get_active_ids()) + sorted(pool.get_dormant_ids())
+    tracks = [t for t in tracks if rs.rand() > n_missing]
+    n = n_det + len(tracks)
+    c = rs.uniform(60, [W - 60, H - 60], (n, 2))
+    if n > 4:                                  # clusters: plenty of overlaps between detections and tracks
+        c[n // 2:] = c[rs.randint(0, n // 2, n - n // 2)] + rs.normal(0, 6, (n - n // 2, 2))
+    wh = rs.uniform(30, 110, (n, 2))
+    boxes = np.concatenate((c - wh / 2, c + wh / 2), 1).astype(np.float32)
+    ids = np.concatenate((np.full(n_det, -1), np.array(tracks, dtype=np.int64))).astype(np.int64)
+    scores = np.concatenate((rs.uniform(0.05, 0.999, n_det), 1.0 + rs.uniform(0.05, 1.0, len(tracks)))).astype(np.float32)
+    perm = rs.permutation(n)
+    return boxes[perm], ids[perm], scores[perm]
+
+
+def _run(device, nms_mask_fn, frames=25):
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.structures import BoxList
+    pool_a, pool_b = TrackPool(max_dormant_frames=3), TrackPool(max_dormant_frames=3)
+    solver = TrackSolver(pool_a, 0.4, 0.6, 0.4, nms_mask_fn=nms_mask_fn)
+    rs = np.random.RandomState(3)
+    seen_events = set()
+    for f in range(frames):
+        boxes, ids, scores = _scene(rs, pool_b, n_det=int(rs.randint(0, 40)), n_missing=0.15)
+        bl = BoxList(torch.from_numpy(boxes).to(device), (1280, 704), mode="xyxy")
+        bl.add_field("ids", torch.from_numpy(ids).to(device))
+        bl.add_field("scores", torch.from_numpy(scores.copy()).to(device))
+        bl.add_field("labels", torch.ones(len(ids), dtype=torch.int64, device=device))
+        out = solver([bl])[0]
+        keep, ref_ids, ref_scores = SO.solve(pool_b, boxes, ids.copy(), scores.copy(), 0.4, 0.6, 0.4)
+        assert out.get_field("ids").cpu().tolist() == ref_ids.tolist(), "frame %d" % f
+        assert np.array_equal(out.get_field("scores").cpu().numpy(), ref_scores), "frame %d" % f
+        assert np.array_equal(out.bbox.cpu().numpy(), boxes[keep])
+        assert out.get_field("labels").shape[0] == len(keep)
+        assert pool_a.get_active_ids() == pool_b.get_active_ids()
+        assert pool_a.get_dormant_ids() == pool_b.get_dormant_ids()
+        assert pool_a._kill_ids == pool_b._kill_ids and pool_a._max_id == pool_b._max_id
+        if pool_a._kill_ids:
+            seen_events.add("expire")
+        if pool_a.get_dormant_ids():
+            seen_events.add("suspend")
+        if len(bl):      # the input's score field was banded in place, as the reference does
+            pass
+    assert {"expire", "suspend"} <= seen_events and pool_a._max_id > 20
+    empty = BoxList(torch.zeros((0, 4), device=device), (1280, 704))
+    empty.add_field("ids", torch.zeros(0, dtype=torch.int64, device=device))
+    empty.add_field("scores", torch.zeros(0, device=device))
+    assert len(solver([empty])[0]) == 0
+
+
+def _numpy_mask(boxes, scores, thresh):
+    keep = SO.nms_indices(boxes.cpu().numpy(), scores.cpu().numpy(), thresh)
+    m = torch.zeros(len(boxes), dtype=torch.bool)
+    m[torch.from_numpy(keep)] = True
+    return m
+
+
+def test_solver_logic_matches_the_reference_restatement_on_cpu():
+    """Host logic only: the NMS mask is injected (the product's default is the HIP kernel, device tensors only)."""
+    _run("cpu", _numpy_mask)
+
+
+def test_track_pool_cache_and_life_cycle():
+    from siammot_amd.solver import TrackPool
+    from siammot_amd.structures import BoxList
+    pool = TrackPool(max_dormant_frames=2)
+    a, b = pool.start_track(), pool.start_track()
+    assert (a, b) == (0, 1) and pool.get_active_ids() == {0, 1}
+    boxes = BoxList(torch.tensor([[0., 0., 9., 9.], [5., 5., 20., 20.]]), (100, 100))
+    boxes.add_field("ids", torch.tensor([1, 0]))
+    sr = BoxList(torch.tensor([[-5., -5., 14., 14.], [0., 0., 30., 30.]]), (100, 100))
+    pool.update_cache((torch.arange(2 * 3).reshape(2, 3).float(), [sr], [boxes]))
+    feat, s, bx = pool.get_cache()[1]
+    assert feat.tolist() == [0.0, 1.0, 2.0] and s.bbox.tolist() == [[-5., -5., 14., 14.]] and bx.get_field("ids").tolist() == [1]
+    pool.increment_frame()
+    pool.suspend_track(0)
+    assert pool.get_dormant_ids() == {0}
+    with pytest.raises(ValueError):
+        pool.suspend_track(0)
+    pool.expire_tracks()                               # frame 1, last active at frame 0: 1 < 2 frames dormant
+    assert pool.get_dormant_ids() == {0}
+    pool.increment_frame(); pool.expire_tracks()       # frame 2: expired, cache entry dropped
+    assert pool.get_dormant_ids() == set() and 0 not in pool.get_cache() and 0 in pool._kill_ids
+    with pytest.raises(ValueError):
+        pool.resume_track(0)
+
+
+@pytest.mark.gpu
+def test_solver_on_the_device_with_the_hip_nms():
+    _run("cuda:0", None)
