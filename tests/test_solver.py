@@ -4,7 +4,13 @@ import numpy as np
 import pytest
 import torch
 
+import os
+
 from oracle import solver_oracle as SO
+
+# the seeded sequence oracle/gen_golden_solver.py pushes through the REFERENCE's own TrackSolver / TrackPool
+SEQUENCE = dict(seed=3, frames=25, max_dormant_frames=3, thresholds=(0.4, 0.6, 0.4))
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "solver_sequence.npz")
 
 
 def _scene(rs, pool, n_det, n_missing):
@@ -24,12 +30,14 @@ def _scene(rs, pool, n_det, n_missing):
     return boxes[perm], ids[perm], scores[perm]
 
 
-def _run(device, nms_mask_fn, frames=25):
+def _run(device, nms_mask_fn, frames=SEQUENCE["frames"]):
     from siammot_amd.solver import TrackPool, TrackSolver
     from siammot_amd.structures import BoxList
-    pool_a, pool_b = TrackPool(max_dormant_frames=3), TrackPool(max_dormant_frames=3)
-    solver = TrackSolver(pool_a, 0.4, 0.6, 0.4, nms_mask_fn=nms_mask_fn)
-    rs = np.random.RandomState(3)
+    pool_a = TrackPool(max_dormant_frames=SEQUENCE["max_dormant_frames"])
+    pool_b = TrackPool(max_dormant_frames=SEQUENCE["max_dormant_frames"])
+    solver = TrackSolver(pool_a, *SEQUENCE["thresholds"], nms_mask_fn=nms_mask_fn)
+    rs = np.random.RandomState(SEQUENCE["seed"])
+    gold = np.load(GOLDEN)                      # outputs of the reference's own solver on this sequence
     seen_events = set()
     for f in range(frames):
         boxes, ids, scores = _scene(rs, pool_b, n_det=int(rs.randint(0, 40)), n_missing=0.15)
@@ -38,7 +46,13 @@ def _run(device, nms_mask_fn, frames=25):
         bl.add_field("scores", torch.from_numpy(scores.copy()).to(device))
         bl.add_field("labels", torch.ones(len(ids), dtype=torch.int64, device=device))
         out = solver([bl])[0]
-        keep, ref_ids, ref_scores = SO.solve(pool_b, boxes, ids.copy(), scores.copy(), 0.4, 0.6, 0.4)
+        keep, ref_ids, ref_scores = SO.solve(pool_b, boxes, ids.copy(), scores.copy(), *SEQUENCE["thresholds"])
+        # the oracle restatement is pinned to the reference ...
+        assert ref_ids.tolist() == gold["f%02d_ids" % f].tolist(), "oracle vs reference, frame %d" % f
+        assert np.array_equal(ref_scores, gold["f%02d_scores" % f]) and np.array_equal(boxes[keep], gold["f%02d_boxes" % f])
+        assert sorted(pool_b.get_active_ids()) == gold["f%02d_active" % f].tolist()
+        assert sorted(pool_b.get_dormant_ids()) == gold["f%02d_dormant" % f].tolist()
+        # ... and the product solver to both
         assert out.get_field("ids").cpu().tolist() == ref_ids.tolist(), "frame %d" % f
         assert np.array_equal(out.get_field("scores").cpu().numpy(), ref_scores), "frame %d" % f
         assert np.array_equal(out.bbox.cpu().numpy(), boxes[keep])
