@@ -203,6 +203,39 @@ def multi_stream_throughput(emm, feats, det, n_streams, dev, steps=600):
             "ms_per_step_per_stream": dt / steps * 1e3}
 
 
+def tracking_loop_throughput(n, dev, feats, steps=300):
+    """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> merge with this
+    frame's detections -> solver (score-banded NMS, id life cycle, ONE host sync) -> EMM.extract_cache + track
+    memory.  Detections are the n synthetic track boxes jittered by a pixel, so every track survives and the
+    track count stays n.  Informational (the solver is host-bound control logic, not part of the metric)."""
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_head import build_tracking_loop
+    image_wh = (NET_HW[1], NET_HW[0])
+    boxes = synthetic_boxes(n, image_wh).to(dev)
+    loop = build_tracking_loop(get_default_cfg(channels=CHANNELS), device=dev)
+    init_predictor(loop.track.tracker.predictor, boxes.cpu())
+    loop.track.tracker.to(dev)
+
+    def dets(k):
+        d = BoxList(boxes + float(k & 1), image_wh, mode="xyxy")
+        d.add_field("ids", torch.full((n,), -1, dtype=torch.int64, device=dev))
+        d.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
+        d.add_field("scores", torch.full((n,), 0.9, device=dev))
+        return d
+    for k in range(30):
+        out = loop(feats[k & 1], dets(k))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out = loop(feats[k & 1], dets(k))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
+            "tracked_in_last_frame": int((out.get_field("ids") >= 0).sum().item()),
+            "note": "head + solver + track memory, synthetic detections; host-bound (one sync per frame)"}
+
+
 def tower_roofline(n, total_ms, launches):
     algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
@@ -299,9 +332,10 @@ def main():
         elapsed = time.perf_counter() - t0
         xcorr_total_ms, xcorr_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_XCORR)
         tower_total_ms, tower_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_TOWER)
-    multi = None
+    multi = loop_stats = None
     if world == 1 and args.extra_streams > 1:
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
+        loop_stats = tracking_loop_throughput(n, dev, feats)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
@@ -375,6 +409,7 @@ def main():
         # fraction they amount to).
         "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
         "multi_stream": multi,
+        "tracking_loop": loop_stats,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)

@@ -18,6 +18,33 @@ from . import ops
 from .structures import BoxList  # noqa: F401  (duck-typed: any BoxList with bbox / get_field / add_field / __getitem__)
 
 
+class _CacheEntry(object):
+    """(template feature, search region, box) of one track, sliced out of the frame's memory on first use.
+    The reference slices three BoxLists / tensors per track per frame (track_utils.py:185-197) although only
+    dormant tracks are ever read back (track_head.py:83-86)."""
+    __slots__ = ("_src", "_idx", "_val")
+
+    def __init__(self, features, sr, boxes, idx):
+        self._src, self._idx, self._val = (features, sr, boxes), idx, None
+
+    def _materialise(self):
+        if self._val is None:
+            features, sr, boxes = self._src
+            i = self._idx
+            self._val = (features[i] if len(features) > 0 else features, sr[i: i + 1], boxes[i: i + 1])
+            self._src = None
+        return self._val
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return 3
+
+
 class TrackPool(object):
     """Track-id life cycle and per-track cache (track_utils.py:138-250), host-side state."""
 
@@ -57,12 +84,17 @@ class TrackPool(object):
         if n == 0:
             return
         ids = template_boxes.get_field("ids").tolist()
-        has_feat = len(template_features) > 0
-        if has_feat:
+        if len(template_features) > 0:
             assert len(template_features) == len(sr)
+        # a dormant track's entry must not be replaced by a lazy view of a memory that contains that very entry
+        # (its row is re-appended every frame): materialise entries of tracks that are not active first
+        active = self._active_ids
         for idx in range(n):
-            self._cache[ids[idx]] = (template_features[idx] if has_feat else template_features,
-                                     sr[idx: idx + 1], template_boxes[idx: idx + 1])
+            tid = ids[idx]
+            old = self._cache.get(tid)
+            if tid not in active and old is not None:
+                continue                                   # dormant: keep the entry it went dormant with
+            self._cache[tid] = _CacheEntry(template_features, sr, template_boxes, idx)
 
     def resume_track(self, track_id):
         if track_id not in self._dormant_ids or track_id in self._active_ids:
@@ -129,7 +161,8 @@ class TrackSolver(torch.nn.Module):
         active = sorted(pool.get_active_ids())
         if active:
             act = torch.tensor(active, dtype=all_ids.dtype, device=device)
-            all_scores[torch.isin(all_ids, act)] += 1.0
+            # N x A comparison: two tiny kernels (torch.isin sorts and costs ~170 us at these sizes)
+            all_scores += (all_ids[:, None] == act[None, :]).any(dim=1).to(all_scores.dtype)
         keep_mask = self.nms_mask_fn(detection.convert("xyxy").bbox, all_scores, self.NMS_THRESH)     # :71, :22
 
         # ---- the one device -> host copy: ids, banded scores, keep mask -----------------------------
@@ -172,6 +205,7 @@ class TrackSolver(torch.nn.Module):
         out = detection[back[:, 0].to(torch.int64)]
         out.add_field("ids", back[:, 1].to(all_ids.dtype))
         out.add_field("scores", back[:, 2].to(all_scores.dtype))
+        out.host_ids = _ids                      # the ids are already on the host: TrackHead filters without a sync
         return [out]
 
 

@@ -1,0 +1,53 @@
+"""A deterministic stand-in for the EMM module (CPU tensors) used to pin the tracking glue — TrackHead, solver,
+pool — against the reference's own classes: ``forward`` moves every template box by a fixed offset and scores it
+by a hash of its id; ``extract_cache`` stores the box corners as 'template features'."""
+import numpy as np
+import torch
+
+from siammot_amd.structures import BoxList
+
+SEQ = dict(seed=11, frames=30, max_dormant_frames=2, thresholds=(0.4, 0.6, 0.4), pad=512)
+
+
+class FakeTracker(torch.nn.Module):
+    def __init__(self, pad_pixels):
+        super(FakeTracker, self).__init__()
+        self.pad = pad_pixels
+
+    def forward(self, features, boxes, sr, targets=None, template_features=None):
+        b = boxes[0]
+        assert template_features.shape[0] == len(b) == len(sr[0])
+        assert torch.allclose(template_features[:, :, 0, 0], sr[0].bbox - self.pad + 1000.0, atol=1e-2)   # memory in step
+        ids = b.get_field("ids")
+        out = BoxList(b.bbox + 2.0, b.size, mode="xyxy")
+        out.add_field("ids", ids)
+        out.add_field("labels", b.get_field("labels"))
+        out.add_field("scores", (((ids * 37) % 100).to(torch.float32) / 100.0) * 0.9 + 0.05)   # some fall below thresholds
+        return {}, [out], {}
+
+    def extract_cache(self, features, detection):
+        sr = BoxList(detection.bbox + self.pad, [detection.size[0] + 2 * self.pad, detection.size[1] + 2 * self.pad], "xyxy")
+        for f in detection.fields():
+            sr.add_field(f, detection.get_field(f))
+        feats = (detection.bbox + 1000.0)[:, :, None, None].clone()
+        return feats, [sr], [detection]
+
+
+def detections(rs, frame, n_objects=14):
+    """Objects on slow linear paths; each is detected with probability 0.85; plus a few false positives."""
+    base = np.random.RandomState(1234)
+    c0 = base.uniform(100, [1100, 600], (n_objects, 2))
+    vel = base.uniform(-3, 3, (n_objects, 2))
+    wh = base.uniform(40, 100, (n_objects, 2))
+    c = c0 + vel * frame
+    det = rs.rand(n_objects) < 0.85
+    boxes = np.concatenate((c - wh / 2, c + wh / 2), 1)[det]
+    nfp = int(rs.randint(0, 3))
+    fp_c = rs.uniform(50, [1200, 650], (nfp, 2))
+    boxes = np.concatenate((boxes, np.concatenate((fp_c - 25, fp_c + 25), 1)), 0).astype(np.float32)
+    scores = rs.uniform(0.45, 0.99, len(boxes)).astype(np.float32)
+    bl = BoxList(torch.from_numpy(boxes), (1280, 704), mode="xyxy")
+    bl.add_field("ids", torch.full((len(boxes),), -1, dtype=torch.int64))
+    bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64))
+    bl.add_field("scores", torch.from_numpy(scores))
+    return bl

@@ -113,3 +113,59 @@ def test_track_pool_cache_and_life_cycle():
 @pytest.mark.gpu
 def test_solver_on_the_device_with_the_hip_nms():
     _run("cuda:0", None)
+
+
+def test_tracking_loop_matches_the_reference_classes():
+    """TrackHead + solver + pool of this repository replay the sequence that oracle/gen_golden_tracking.py pushed
+    through the reference's own TrackHead / TrackSolver / TrackPool (same deterministic fake tracker)."""
+    import types
+    from fake_tracker import SEQ, FakeTracker, detections
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.track_head import TrackHead, TrackingLoop
+    gold = np.load(os.path.join(os.path.dirname(GOLDEN), "tracking_sequence.npz"))
+    pool = TrackPool(max_dormant_frames=SEQ["max_dormant_frames"])
+    head = TrackHead(FakeTracker(SEQ["pad"]), types.SimpleNamespace(pad_pixels=SEQ["pad"]), pool).eval()
+    loop = TrackingLoop(head, TrackSolver(pool, *SEQ["thresholds"], nms_mask_fn=_numpy_mask)).eval()
+    rs = np.random.RandomState(SEQ["seed"])
+    feats = (torch.zeros(1),)
+    for f in range(SEQ["frames"]):
+        res = loop(feats, detections(rs, f))
+        assert res.get_field("ids").tolist() == gold["f%02d_ids" % f].tolist(), "frame %d" % f
+        assert np.array_equal(res.get_field("scores").numpy(), gold["f%02d_scores" % f])
+        assert np.array_equal(res.bbox.numpy(), gold["f%02d_boxes" % f])
+        mem = loop.track_memory
+        assert mem[2][0].get_field("ids").tolist() == gold["f%02d_mem_ids" % f].tolist(), "memory, frame %d" % f
+        assert np.array_equal(mem[0].numpy().reshape(len(mem[2][0]), -1), gold["f%02d_mem_feat" % f])
+    assert pool._max_id > 20 and len(pool.get_active_ids()) > 5
+    loop.reset()
+    assert loop.track_memory is None and pool.get_active_ids() == set()
+
+
+@pytest.mark.gpu
+def test_tracking_loop_with_the_hip_head_runs_and_stays_consistent():
+    """The real EMM head inside the loop (random features and weights: the propagated boxes are arbitrary, the
+    bookkeeping must still hold): unique ids, memory aligned with the pool, dormant tracks carried and expired."""
+    import golden_inputs as gi
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    cfg = get_default_cfg(channels=32)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 2
+    loop = build_tracking_loop(cfg, device="cuda:0")
+    pool = loop.track.track_pool
+    rs = np.random.RandomState(5)
+    shapes = gi.feature_shapes((1280, 704), 32)
+    started = 0
+    for f in range(12):
+        feats = tuple(torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda() for s in shapes)
+        out = loop(feats, detections(rs, f).to("cuda:0"))
+        ids = out.get_field("ids").cpu().numpy()
+        tracked = ids[ids >= 0]
+        assert len(np.unique(tracked)) == len(tracked)
+        assert set(tracked.tolist()) <= pool.get_active_ids()
+        z, sr, boxes = loop.track_memory
+        assert z.shape[0] == len(sr[0]) == len(boxes[0]) and (z.numel() == 0 or tuple(z.shape[1:]) == (32, 15, 15))
+        mem_ids = set(boxes[0].get_field("ids").cpu().tolist())
+        assert mem_ids == pool.get_active_ids() | (pool.get_dormant_ids() & set(pool.get_cache()))
+        started = max(started, pool._max_id + 1)
+    assert started >= 10
