@@ -162,7 +162,7 @@ def cpu_baseline(n_tracks, budget_s=10.0, timeout_s=150.0):
     """Run the CPU leg in a child process with a hard timeout so that bench.py always finishes."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--tracks", str(n_tracks),
-           "--cpu-budget", str(budget_s)]
+           "--cpu-budget", str(budget_s), "--channels", str(CHANNELS), "--net-hw", str(NET_HW[0]), str(NET_HW[1])]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         for line in reversed(res.stdout.strip().splitlines()):
@@ -259,6 +259,10 @@ def main():
                          "idle states before the W warm-up steps (a 200-step run measured 0.29 ms/step, a 2000-step "
                          "run 0.16 ms/step on the same box); 0 disables")
     ap.add_argument("--tracks", type=int, default=30)
+    ap.add_argument("--channels", type=int, default=CHANNELS,
+                    help="FPN channel count (128 = DLA-34-FPN, the metric's configuration; 256 = R-50-FPN, configs[4])")
+    ap.add_argument("--net-hw", type=int, nargs=2, default=list(NET_HW), metavar=("H", "W"),
+                    help="network input size (704 1280 = 720p under the default resize rule; 1056 1920 = configs[4])")
     ap.add_argument("--extra-streams", type=int, default=2,
                     help="after the timed region, also measure S independent video streams on S HIP streams of the same "
                          "GPU (reported as `multi_stream`, not as `value`); 0 disables")
@@ -268,6 +272,8 @@ def main():
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=10.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    globals()["CHANNELS"] = args.channels            # the helpers above read the module constants
+    globals()["NET_HW"] = tuple(args.net_hw)
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.tracks, args.cpu_budget)
         return
@@ -389,14 +395,16 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "EMM tracker-head frame pair (EMM.forward + EMM.extract_cache) on DLA-34-FPN 720p FPN maps "
-                        "(net input 704x1280, C=128, 5 levels), %d tracks, one stream per GPU; hot path only: "
-                        "backbone / RPN / box head / solver are outside the timed region" % n,
+            "workload": "EMM tracker-head frame pair (EMM.forward + EMM.extract_cache) on %s FPN maps "
+                        "(net input %dx%d, C=%d, 5 levels), %d tracks, one stream per GPU; hot path only: "
+                        "backbone / RPN / box head / solver are outside the timed region"
+                        % ("DLA-34-FPN 720p" if (CHANNELS, NET_HW) == (128, (704, 1280)) else "synthetic",
+                           NET_HW[0], NET_HW[1], CHANNELS, n),
             "tracks": n, "channels": CHANNELS, "rz": rz, "rx": rx, "prewarm_ms": args.prewarm_ms,
             "parallelism": "streams x%d (weights broadcast once: %d B)" % (world, bcast_bytes),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "sr_xcorr_fused_kernel<30,15,2,true> (search-region ROIAlign + depthwise xcorr)",
+            "bound": "hbm", "kernel": "sr_xcorr_fused8_kernel<30,15,2,true> (search-region ROIAlign + depthwise xcorr)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": fused_bytes,
