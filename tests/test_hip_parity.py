@@ -580,6 +580,28 @@ def test_emm_random_geometry_against_oracle(ops, seed):
     _assert_close(result[0].get_field("scores")[torch.from_numpy(ok)], conf[torch.from_numpy(ok)], 0, 1e-4, "scores")
 
 
+def test_emm_with_no_tracks_and_one_track(ops):
+    """Empty and single-track calls through the module (the reference guards the empty case one level up,
+    track_head.py:43-46; the library must still not launch a zero-sized grid)."""
+    from siammot_amd.structures import BoxList
+    case = dict(gi.EMM_CASES["default"], channels=32)
+    emm = _build_emm(case)
+    rs = np.random.RandomState(2)
+    feats = tuple(_d(rs.standard_normal(s).astype(np.float32)) for s in gi.feature_shapes(case["image_wh"], 32))
+    for n in (0, 1):
+        det = BoxList(_d(np.array([[30.0, 40.0, 90.0, 160.0]], np.float32)[:n].reshape(n, 4)), case["image_wh"])
+        det.add_field("ids", torch.arange(n, device=DEV))
+        det.add_field("labels", torch.ones(n, dtype=torch.int64, device=DEV))
+        with torch.no_grad():
+            z, sr, d = emm.extract_cache(feats, det)
+            assert tuple(z.shape) == (n, 32, 15, 15) and len(sr[0]) == n
+            _, res, _ = emm(feats, d, sr, template_features=z)
+        assert len(res[0]) == n and res[0].get_field("scores").shape[0] == n
+        if n:
+            assert torch.isfinite(res[0].bbox).all()
+    torch.cuda.synchronize()
+
+
 def test_emm_training_mode_is_refused(ops):
     emm = _build_emm(gi.EMM_CASES["default"])
     emm.train()
