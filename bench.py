@@ -236,13 +236,13 @@ def tracking_loop_throughput(n, dev, feats, steps=300):
             "note": "head + solver + track memory, synthetic detections; host-bound (one sync per frame)"}
 
 
-def tower_roofline(n, total_ms, launches):
+def tower_roofline(n, total_ms, launches, bracket_us):
     algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
-    sec = total_ms * 1e-3 / launches
+    sec = total_ms * 1e-3 / launches                     # raw event span (includes part of the bracket's own span)
     return {
         "bound": "mfma", "kernel": "tower_wino_kernel<0> (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)",
-        "flops_per_launch": algo, "avg_launch_us": sec * 1e6,
+        "flops_per_launch": algo, "avg_launch_us": sec * 1e6, "event_bracket_overhead_us": bracket_us,
         "achieved": algo / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": algo / sec / 1e12 / 157.3,
         "executed_mfma_flops_per_launch": executed, "executed_frac_of_peak": executed / sec / 1e12 / 157.3,
         "launches_timed": launches,
@@ -343,6 +343,11 @@ def main():
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
         loop_stats = tracking_loop_throughput(n, dev, feats)
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    # A bracketed span = kernel + part of the bracket's own span.  The span of an EMPTY bracket on the same stream
+    # (two hipEventRecords back to back, ~4.6 us on MI355X) is reported next to the spans as an upper bound of that
+    # share; `achieved` uses the RAW spans (conservative: rocprofv3 durations in profiles/ are 2-3 us shorter, and
+    # raw minus empty-bracket is 2 us shorter still than rocprofv3).
+    bracket_us = 0.0 if args.no_kernel_timer else ops.kernel_timer_bracket_overhead(200)
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
     if rank != 0:
@@ -408,14 +413,14 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "algorithmic_bytes_per_launch": fused_bytes,
-            "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer_stride": TIMER_STRIDE,
+            "avg_launch_us": xcorr_avg_s * 1e6, "event_bracket_overhead_us": bracket_us, "launches_timed": xcorr_launches, "timer_stride": TIMER_STRIDE,
             "xcorr_op": xop,
         },
         # the kernel with the largest share of GPU time: the two conv3x3 towers.  Algorithmic FLOPs are those of
         # the direct convolution the reference computes; the kernel runs it as Winograd F(2x2,3x3) on the fp32
         # matrix cores, i.e. it EXECUTES 2.25x fewer multiply-adds (reported separately, with the matrix-pipe
         # fraction they amount to).
-        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
+        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches, bracket_us),
         "multi_stream": multi,
         "tracking_loop": loop_stats,
     }

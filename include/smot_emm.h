@@ -229,6 +229,9 @@ int smot_xcorr_timer_end(double* total_ms, int* launches);
 void smot_debug_trace(long long* buf);
 int smot_kernel_timer_begin(int slot, int max_launches, int stride);
 int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
+/* Median span (microseconds) of `reps` EMPTY event brackets on `stream`: the part of a bracketed kernel span that
+ * is the instrumentation's own (bench.py reports spans with and without it). */
+int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* median_us);
 
 /*
  * One-call halves of a frame pair (same kernels, one FFI crossing each).

@@ -96,6 +96,39 @@ extern "C" int smot_kernel_timer_end(int slot, double* total_ms, int* launches) 
     return SMOT_OK;
 }
 
+// Span of an EMPTY event bracket on `stream` (median of `reps`): what the brackets above add to a kernel's span.
+extern "C" int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* median_us) {
+    using namespace smot;
+    SMOT_REQUIRE(reps > 0 && reps <= 4096 && median_us, "kernel_timer_bracket_overhead: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[2 * (size_t)reps];
+    for (int i = 0; i < 2 * reps; ++i) (void)hipEventCreate(&ev[i]);
+    for (int i = 0; i < reps; ++i) {
+        (void)hipEventRecord(ev[2 * i], st);
+        (void)hipEventRecord(ev[2 * i + 1], st);
+    }
+    (void)hipEventSynchronize(ev[2 * reps - 1]);
+    float* ms = new float[reps];
+    for (int i = 0; i < reps; ++i) {
+        ms[i] = 0.f;
+        (void)hipEventElapsedTime(&ms[i], ev[2 * i], ev[2 * i + 1]);
+    }
+    for (int i = 1; i < reps; ++i) {                  // insertion sort: reps is small
+        float v = ms[i];
+        int j = i - 1;
+        while (j >= 0 && ms[j] > v) {
+            ms[j + 1] = ms[j];
+            --j;
+        }
+        ms[j + 1] = v;
+    }
+    *median_us = (double)ms[reps / 2] * 1e3;
+    for (int i = 0; i < 2 * reps; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    delete[] ms;
+    return SMOT_OK;
+}
+
 extern "C" int smot_xcorr_timer_begin(int max_launches) { return smot_kernel_timer_begin(0, max_launches, 1); }
 extern "C" int smot_xcorr_timer_end(double* total_ms, int* launches) {
     return smot_kernel_timer_end(0, total_ms, launches);

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "smot_xcorr_timer_begin": (ctypes.c_int, [_i]),
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
     "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i, _i]),
+    "smot_kernel_timer_bracket_overhead": (ctypes.c_int, [_vp, _i, _vp]),
     "smot_kernel_timer_end": (ctypes.c_int, [_i, _vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
@@ -475,6 +476,14 @@ TIMER_XCORR, TIMER_TOWER = 0, 1
 def kernel_timer_begin(slot, max_launches, stride=1):
     """Start bracketing the kernels of ``slot`` with HIP events on their launch stream (bench.py)."""
     _check(load_library().smot_kernel_timer_begin(int(slot), int(max_launches), int(stride)), "kernel_timer_begin")
+
+
+def kernel_timer_bracket_overhead(reps=200):
+    """Median span (us) of an empty event bracket on the current stream."""
+    us = ctypes.c_double(0.0)
+    _check(load_library().smot_kernel_timer_bracket_overhead(_stream(), int(reps), ctypes.byref(us)),
+           "kernel_timer_bracket_overhead")
+    return us.value
 
 
 def kernel_timer_end(slot):
