@@ -43,6 +43,7 @@ def _stale():
         os.path.join(CSRC, "logit_src.h"),
         os.path.join(CSRC, "tower_common.h"),
         os.path.join(CSRC, "xcorr_mfma.h"),
+        os.path.join(CSRC, "xcorr_patch1.h"),
         os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"),
         os.path.abspath(__file__),
     ]

@@ -22,6 +22,7 @@
 #include "smot_common.h"
 #include "xcorr_patch2.h"
 #include "xcorr_mfma.h"
+#include "xcorr_patch1.h"
 #include <stdlib.h>
 
 namespace smot {
@@ -548,10 +549,51 @@ xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
     xcorr_patch2_compute<RX, RZ, MODE>(xs, zs, lane, out, plane0, planes);
 }
 
+// Sixth generation: one plane per wave, 2x2 output patches (xcorr_patch1.h) — twice the waves of the kernel above.
+template <int RX, int RZ>
+__global__ void __launch_bounds__(64, 4)
+xcorr_dw_patch1_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out, int planes) {
+    constexpr int XS = XP1_XS, ZS = XP1_ZS;
+    __shared__ __attribute__((aligned(16))) float sm[RX * XS + RZ * ZS];
+    float* xs = sm;
+    float* zs = sm + RX * XS;
+    const int lane = threadIdx.x;
+    const int plane = blockIdx.x;
+    (void)planes;
+    constexpr int NX2 = (RX * RX / 2 + 63) / 64;         // float2 per lane (a row of 30 is 15 float2: no straddling)
+    constexpr int NZ = (RZ * RZ + 63) / 64;
+    const float2* __restrict__ xg2 = reinterpret_cast<const float2*>(x + (size_t)plane * RX * RX);
+    const float* __restrict__ zg = z + (size_t)plane * RZ * RZ;
+    float2 sx[NX2];
+    float sz[NZ];
+#pragma unroll
+    for (int t = 0; t < NX2; ++t) sx[t] = xg2[min(lane + 64 * t, RX * RX / 2 - 1)];
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) sz[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+#pragma unroll
+    for (int t = 0; t < NX2; ++t) {
+        const int k = lane + 64 * t;
+        if (k < RX * RX / 2) {
+            const int r = (2 * k) / RX;
+            *reinterpret_cast<float2*>(xs + r * XS + (2 * k - r * RX)) = sx[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NZ; ++t) {
+        const int e = lane + 64 * t;
+        if (e < RZ * RZ) {
+            const int u = e / RZ;
+            zs[u * ZS + (e - u * RZ)] = sz[t];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    xcorr_patch1_compute<RX, RZ>(xs, zs, lane, out, plane);
+}
+
 // Fifth generation: the correlation on v_mfma_f32_4x4x1 (xcorr_mfma.h) — same staging as above into the MFMA
 // path's LDS image (row stride 40, four shifted template copies).
 template <int RX, int RZ>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, 2)
 xcorr_dw_mfma_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out, int planes) {
     constexpr int XP = RX * XM_XS, ZP = 4 * RZ * XM_ZC;
     __shared__ __attribute__((aligned(16))) float sm[2 * XP + 2 * ZP];
@@ -652,6 +694,8 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
             hipLaunchKernelGGL((xcorr_dw_patch_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
         } else if (v0 == 'p' && v1 == 'k') {        // "pk": four planes per wave, packed FMA
             hipLaunchKernelGGL((xcorr_dw_pk_kernel<30, 15, 0>), g4, b64, 0, st, x, z, out, planes);
+        } else if (v0 == 'o') {                     // "one": one plane per wave, 2x2 patches
+            hipLaunchKernelGGL((xcorr_dw_patch1_kernel<30, 15>), dim3(planes), b64, 0, st, x, z, out, planes);
         } else if (v0 == 'm') {                     // "mfma": 4x4x1 matrix-instruction correlation
             hipLaunchKernelGGL((xcorr_dw_mfma_kernel<30, 15>), g2, b64, 0, st, x, z, out, planes);
         } else if (v0 == 'f') {                     // "fill": default kernel without FMAs

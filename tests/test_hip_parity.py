@@ -223,7 +223,7 @@ def test_xcorr_full_size_properties(ops, n):
     assert float((ops.xcorr_depthwise(x[:k].contiguous(), z1[:k].contiguous()) - ref).abs().max()) < 5e-4
 
 
-@pytest.mark.parametrize("variant", ["mfma", "vfma", "patch", "wave"])
+@pytest.mark.parametrize("variant", ["one", "mfma", "vfma", "patch", "wave"])
 def test_xcorr_kernel_generations_are_bitwise_equal(ops, variant, monkeypatch):
     """Every generation accumulates each output as one fp32 fmaf chain in (u, v) order — including the
     4x4x1 matrix-instruction kernel, whose extra zero-weight taps add exact zeros."""

@@ -80,7 +80,7 @@ def main():
             rec("roi_align_sr30", "default", timed(lambda: ops.roi_align_levels(feats, sr, boxes, 30, scales, 2,
                                                                                  [128, 64, 32, 16])))
             rec("roi_align_z15", "default", timed(lambda: ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)))
-            for var in ("default", "mfma", "pk", "patch", "wave", "fill", "compute"):
+            for var in ("default", "one", "mfma", "pk", "patch", "wave", "fill", "compute"):
                 os.environ["SMOT_XCORR_VARIANT"] = var
                 t = timed(lambda: ops.xcorr_depthwise(x, z), batch=50)
                 rec("xcorr", var, t, {"algorithmic_GBps_at_min": round(xbytes / t[0] / 1e3, 1),
