@@ -210,7 +210,9 @@ def tower_packed(params):
     if hit is not None and hit[0]() is wc and hit[1]() is wr and hit[2] == ver:
         return hit[3]
     packed = torch.empty((nfl,), dtype=torch.float32, device=wc.device)
-    _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), _stream()), "tower_pack")
+    _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), _stream(wc.device)), "tower_pack")
+    # the image is cached and may be consumed from another stream: finish it now (once per weight set)
+    torch.cuda.current_stream(wc.device).synchronize()
     for k in [k for k, v in _pack_cache.items() if v[0]() is None or v[1]() is None]:
         del _pack_cache[k]
     _pack_cache[key] = (weakref.ref(wc), weakref.ref(wr), ver, packed)
