@@ -107,7 +107,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int nk = C >> 2;
     const int nstages = C / W_STAGE_IC;
 
-    {   // zero the stage buffers once: the halos stay zero for the whole main loop
+    {   // zero the stage buffers once: the halos stay zero for the whole main loop (a halo-only fill was measured
+        // slower: its scattered ds_write_b32 and index arithmetic cost more than 14 ds_write_b128 per thread)
         float4* z = reinterpret_cast<float4*>(sm);
         for (int e = tid; e < W_RING * W_BUF / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -318,7 +319,12 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             dst[0] = p0;
             dst[16 * W_XOC] = p1;
         }
-    for (int e = tid; e < 16 * T_PLANE; e += 256) planes[e] = 0.0f;
+    for (int e = tid; e < 16 * 68; e += 256) {          // halo of the head planes (interiors are written below)
+        const int pl = e / 68, c = e - pl * 68;
+        const int row = c < 18 ? 0 : (c < 36 ? 17 : 1 + ((c - 36) >> 1));
+        const int col = c < 18 ? c : (c < 36 ? c - 18 : (((c - 36) & 1) ? 17 : 0));
+        planes[pl * T_PLANE + row * 18 + col] = 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int idx = tid + 256 * j;
@@ -331,19 +337,22 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     __syncthreads();
 
     W_TRACE(3)
-    // thread = (output channel ocl = tid/16, tiles 16t + x16): 4 tiles x 2x2 outputs
+    // thread = (output channel ocl = tid/16, tiles 4*x16 + t): 4 tiles x 2x2 outputs, one ds_read_b128 per (i, b)
     const int ocl = tid >> 4, x16 = tid & 15;
     float y[4][2][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int b = 0; b < 2; ++b) {
+        const float* src = X + (b * 16 + ocl) * W_XOC + 4 * x16;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(src + 0 * 32 * W_XOC);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(src + 1 * 32 * W_XOC);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(src + 2 * 32 * W_XOC);
+        const f32x4 x3 = *reinterpret_cast<const f32x4*>(src + 3 * 32 * W_XOC);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const float* src = X + (b * 16 + ocl) * W_XOC + 16 * t + x16;
-            const float x0 = src[0 * 32 * W_XOC], x1 = src[1 * 32 * W_XOC];
-            const float x2 = src[2 * 32 * W_XOC], x3 = src[3 * 32 * W_XOC];
-            y[t][0][b] = (x0 + x1) + x2;
-            y[t][1][b] = (x1 - x2) - x3;
+        for (int t = 0; t < 4; ++t) {
+            y[t][0][b] = (x0[t] + x1[t]) + x2[t];
+            y[t][1][b] = (x1[t] - x2[t]) - x3[t];
         }
+    }
 
     // ---- GroupNorm (two-pass, fp32) + affine + ReLU --------------------------------------------------
     const float inv_cnt = 1.0f / (float)(cpg * 256);
@@ -378,7 +387,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         float* pl = planes + ocl * T_PLANE;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ty = (x16 >> 2) + 4 * (t >> 1), tx = 2 * (x16 & 3) + (t & 1);
+            // tile 4*x16 + t  ->  MFMA N-tile t' = x16/4, lane xl = 4*(x16%4) + t  ->  (ty, tx) as in the main loop
+            const int ty = (x16 & 3) + 4 * (x16 >> 3), tx = 2 * t + ((x16 >> 2) & 1);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
