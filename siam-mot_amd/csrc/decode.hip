@@ -20,6 +20,7 @@
 // separate kernels); NaN scores win and ties go to the lowest flat index, as torch.argmax on CPU.
 #include "smot_common.h"
 #include "logit_src.h"
+#include <stdlib.h>
 
 namespace smot {
 
@@ -135,12 +136,16 @@ __device__ __forceinline__ float interp4_fma(float a, float b, float c, float d,
 
 constexpr int DEC_MAX_COLS = 4;   // output columns per lane: G <= 1024
 
-__global__ void __launch_bounds__(256)
+// SPLIT: workgroups of 256*SPLIT threads; the band's output rows are divided among the SPLIT thread groups
+// (SPLIT = 2 halves the serial row walk of a lane at the price of a duplicated horizontal pass).
+template <int SPLIT>
+__global__ void __launch_bounds__(256 * SPLIT)
 decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
                    const float* __restrict__ hann, DecodeParams D,
                    unsigned long long* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
-    __shared__ unsigned long long wbest[4];
+    __shared__ unsigned long long wbest[4 * SPLIT];
+    const int tcol = threadIdx.x & 255, part = threadIdx.x >> 8;
     __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
     __shared__ float dv[4][4][64];     // ranking planes {cls0-cls1, center, l+r, t+b} of the band's 4 source rows
     const int n = blockIdx.x;
@@ -154,26 +159,29 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     } else if (blockIdx.y == 0) {
         // Ho == 16, band-0 workgroup: all 7 x 256 combined logits (it also leaves them in HBM for pass 2);
         // thread = position; the 7 channels' tile loads are independent (56 in flight at C = 128)
-        float c7[7];
+        if (part == 0) {
+            float c7[7];
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch) c7[ch] = L.combine(n, ch, threadIdx.x);
+            for (int ch = 0; ch < 7; ++ch) c7[ch] = L.combine(n, ch, tcol);
 #pragma unroll
-        for (int ch = 0; ch < 7; ++ch) {
-            lg[ch * 256 + threadIdx.x] = c7[ch];
-            L.logits_out[((size_t)n * 7 + ch) * 256 + threadIdx.x] = c7[ch];
+            for (int ch = 0; ch < 7; ++ch) {
+                lg[ch * 256 + tcol] = c7[ch];
+                L.logits_out[((size_t)n * 7 + ch) * 256 + tcol] = c7[ch];
+            }
         }
     } else {
         // other bands only touch their four source rows f-1..f+2 (clamped): 7 x 4 x 16 = 448 logits
+        constexpr int NJ = (448 + 256 * SPLIT - 1) / (256 * SPLIT);
         float c2[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = threadIdx.x + 256 * j;                  // (ch, k, col)
+        for (int j = 0; j < NJ; ++j) {
+            const int e = threadIdx.x + 256 * SPLIT * j;          // (ch, k, col)
             const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
             c2[j] = (e < 448) ? L.combine(n, ch, row * 16 + (e & 15)) : 0.0f;
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int e = threadIdx.x + 256 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int e = threadIdx.x + 256 * SPLIT * j;
             const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
             if (e < 448) lg[ch * 256 + row * 16 + (e & 15)] = c2[j];   // clamped duplicates write equal values
         }
@@ -195,7 +203,7 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     int rows[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
-    for (int e = threadIdx.x; e < 4 * Ho; e += 256) {              // (k, col)
+    for (int e = threadIdx.x; e < 4 * Ho; e += 256 * SPLIT) {      // (k, col)
         const int k = e / Ho, col = e - k * Ho;
         const float* q = lg + rows[k] * Ho + col;
         const int hw = Ho * Ho;
@@ -213,7 +221,7 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     bool have = false;
 #pragma unroll 1
     for (int j = 0; j < DEC_MAX_COLS; ++j) {
-        const int X = threadIdx.x + 256 * j;
+        const int X = tcol + 256 * j;
         if (X >= G) break;
         int bx;
         float tx, wx[4];
@@ -232,7 +240,9 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
                 h[ch][k] = interp4_fma(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
             }
         const float hx = hann[X];
-        for (int Y = y_begin; Y < y_end; ++Y) {
+        const int rows_per_part = (y_end - y_begin + SPLIT - 1) / SPLIT;
+        const int y0p = y_begin + part * rows_per_part, y1p = min(y_end, y0p + rows_per_part);
+        for (int Y = y0p; Y < y1p; ++Y) {
             const float4 w4 = *reinterpret_cast<const float4*>(wy_tab[Y - y_begin]);
             const float wy[4] = {w4.x, w4.y, w4.z, w4.w};
             float v[4];
@@ -259,7 +269,7 @@ decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long b = wbest[0];
-        for (int w = 1; w < 4; ++w) b = (wbest[w] > b) ? wbest[w] : b;
+        for (int w = 1; w < 4 * SPLIT; ++w) b = (wbest[w] > b) ? wbest[w] : b;
         cand[(size_t)n * gridDim.y + blockIdx.y] = b;
     }
 }
@@ -381,7 +391,17 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     D.sigma = sigma;
     D.use_centerness = use_centerness;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(cand_ws);
-    hipLaunchKernelGGL(decode_band_kernel, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand);
+    // thread groups per band: more of them shorten a lane's serial row walk (latency) but repeat the horizontal
+    // pass (work) — worth it while the launch does not fill the chip.  SMOT_DECODE_SPLIT=1|2|4 overrides.
+    const char* sp = getenv("SMOT_DECODE_SPLIT");
+    const int split = sp ? atoi(sp) : ((long long)N * (Ho + 1) <= 768 ? 2 : 1);
+    if (split == 4) {
+        hipLaunchKernelGGL(decode_band_kernel<4>, dim3(N, Ho + 1), dim3(1024), smem, st, L, boxes, hann, D, cand);
+    } else if (split == 2) {
+        hipLaunchKernelGGL(decode_band_kernel<2>, dim3(N, Ho + 1), dim3(512), smem, st, L, boxes, hann, D, cand);
+    } else {
+        hipLaunchKernelGGL(decode_band_kernel<1>, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand);
+    }
     int rc = check_launch("decode bands");
     if (rc) return rc;
     LogitSrc L2 = L;
