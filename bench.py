@@ -290,8 +290,9 @@ def main():
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
                              "--nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()       # ranks > GPUs only in the gloo smoke test
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     ops.load_library()
 
     n = args.tracks

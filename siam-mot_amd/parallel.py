@@ -20,7 +20,8 @@ def init_distributed(backend=None):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SMOT_DIST_BACKEND=gloo: smoke-test the multi-rank path on a box with fewer GPUs than ranks
+            backend = os.environ.get("SMOT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)

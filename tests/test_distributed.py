@@ -4,6 +4,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -77,3 +78,28 @@ def test_single_process_is_a_noop():
     assert parallel.max_over_ranks(3.5) == 3.5
     assert parallel.broadcast_module(torch.nn.Linear(2, 2)) == 0
     assert parallel.shard_streams(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The multi-rank flow of bench.py (rendezvous, weight broadcast, barrier, max-over-ranks, one JSON line from
+    rank 0) on a one-GPU box: two ranks on the same device with the gloo backend standing in for RCCL."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SMOT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "100",
+           "--warmup", "10", "--prewarm-ms", "50", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0): %s" % res.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 100 and d["scaling"] == "weak" and d["value"] > 0
+    assert "streams x2" in d["config"]["parallelism"] and "weights broadcast once: 0 B" not in d["config"]["parallelism"]
