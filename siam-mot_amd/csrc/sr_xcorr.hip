@@ -36,6 +36,9 @@ struct SrOut {
     float* sr;            // [R,4] or nullptr
     float pad, half_e, two_e, min_wh;
     long long* trace;     // phase trace (smot_debug_trace) or nullptr
+    int abl;              // timing ablation of the generation-2 kernel (wrong results): 2 = no correlation phase
+                          // (SMOT_FUSED_ABL=2).  A run-time switch around the row loads is NOT an option: the
+                          // branch makes hipcc wait for every pair of loads (measured +2 us).
 };
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
@@ -541,7 +544,7 @@ sr_xcorr_fused8_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     FX_TRACE(3)
     if constexpr (XCORR) {
         __syncthreads();                                  // both planes of every pair pooled
-        if (wave < 4) {
+        if (wave < 4 && S.abl != 2) {
             const int plane0 = n * C + c0 + 2 * wave;
             const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);
             if (nvalid > 0) {
@@ -620,7 +623,8 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace};
+    const char* abl_s = getenv("SMOT_FUSED_ABL");
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, abl_s ? atoi(abl_s) : 0};
     if (getenv("SMOT_FUSED_GEN1") != nullptr) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
                            boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
