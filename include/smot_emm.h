@@ -33,10 +33,22 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 2
+#define SMOT_ABI_VERSION 3
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
+
+/* Build flavour of the loaded library.  bit 0 = measurement build (libsmot_emm_debug.so, compiled with
+ * -DSMOT_DEBUG): kernel A/B switches and timing ablations exist and smot_debug_set_knob() is exported.  The
+ * product library (libsmot_emm.so) returns 0: it reads no environment variable and contains no switch that
+ * changes which kernel runs or what it computes. */
+int smot_build_info(void);
+
+#ifdef SMOT_DEBUG
+/* Measurement library only: set one A/B or ablation switch by its SMOT_* name (csrc/knobs.h), value spelled as
+ * the environment variable would be.  The environment itself is read once, when the library is loaded. */
+int smot_debug_set_knob(const char* name, const char* value);
+#endif
 
 /* Message describing the last non-zero return on the calling thread ("" if none). */
 const char* smot_last_error(void);

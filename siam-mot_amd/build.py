@@ -3,6 +3,11 @@
     python siam-mot_amd/build.py            # build if stale
     python siam-mot_amd/build.py --force
 
+Two libraries come out of the same sources:
+  csrc/libsmot_emm.so        the product: no environment variable is read, no kernel A/B switch, no ablation;
+  csrc/libsmot_emm_debug.so  the measurement build (-DSMOT_DEBUG, + xcorr_variants.hip): older kernel generations,
+                             A/B switches and timing ablations for tools/ and the A/B tests (csrc/knobs.h).
+
 The library is plain HIP behind a C ABI (include/smot_emm.h): no torch headers, so it is
 compiled with hipcc directly rather than through torch.utils.cpp_extension.
 """
@@ -14,6 +19,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
+LIB_DEBUG = os.path.join(CSRC, "libsmot_emm_debug.so")
+DEBUG_ONLY_SOURCES = ["xcorr_variants.hip"]
 SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "preprocess.hip",
            "emm_fused.hip"]
 ARCH = "gfx950"
@@ -32,43 +39,58 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def _deps(sources):
+    hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    return [os.path.join(CSRC, s) for s in sources] + hdrs + [
+        os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"), os.path.abspath(__file__)]
+
+
+def _stale(lib, sources):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [
-        os.path.join(CSRC, "smot_common.h"),
-        os.path.join(CSRC, "roi_common.h"),
-        os.path.join(CSRC, "xcorr_patch2.h"),
-        os.path.join(CSRC, "logit_src.h"),
-        os.path.join(CSRC, "tower_common.h"),
-        os.path.join(CSRC, "xcorr_mfma.h"),
-        os.path.join(CSRC, "xcorr_patch1.h"),
-        os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"),
-        os.path.abspath(__file__),
-    ]
-    return any(os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in _deps(sources))
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
-    if not force and not _stale():
-        return LIB
+def _build_one(lib, sources, extra_flags, objdir, verbose):
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = _hipcc()
-    objs = []
-    for s in SOURCES:
-        obj = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", obj]
+    os.makedirs(objdir, exist_ok=True)
+    lib_t = os.path.getmtime(lib) if os.path.exists(lib) else 0.0
+    hdr_t = max(os.path.getmtime(d) for d in _deps([]))
+    jobs, objs = [], []
+    for s in sources:
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        src = os.path.join(CSRC, s)
+        # per-object staleness: recompile only what changed (a header change recompiles everything)
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t) and lib_t:
+            continue
+        jobs.append([hipcc] + FLAGS + extra_flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        objs.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH] + objs + ["-o", lib])
+    return lib
+
+
+def build(force=False, verbose=True, debug=True):
+    """Compile every HIP source for gfx950 and link the product library (and, with ``debug``, the measurement
+    library next to it).  Returns the product library's path."""
+    if force:
+        for lib in (LIB, LIB_DEBUG):
+            if os.path.exists(lib):
+                os.remove(lib)
+    if force or _stale(LIB, SOURCES):
+        _build_one(LIB, SOURCES, [], os.path.join(CSRC, "obj"), verbose)
+    if debug and (force or _stale(LIB_DEBUG, SOURCES + DEBUG_ONLY_SOURCES)):
+        _build_one(LIB_DEBUG, SOURCES + DEBUG_ONLY_SOURCES, ["-DSMOT_DEBUG"], os.path.join(CSRC, "obj_debug"), verbose)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, debug="--no-debug" not in sys.argv))

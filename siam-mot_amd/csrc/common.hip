@@ -1,5 +1,8 @@
 // Error reporting + ABI version for libsmot_emm.so.
 #include "smot_common.h"
+#include "knobs.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace smot {
 
@@ -15,6 +18,79 @@ void set_error(const char* fmt, ...) {
 }  // namespace smot
 
 extern "C" int smot_abi_version(void) { return SMOT_ABI_VERSION; }
+
+// bit 0: measurement build (-DSMOT_DEBUG: A/B switches and timing ablations exist).  The product library returns 0.
+extern "C" int smot_build_info(void) {
+#ifdef SMOT_DEBUG
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+#ifdef SMOT_DEBUG
+namespace smot {
+namespace {
+struct KnobName {
+    const char* name;
+    int Knobs::*field;
+};
+const KnobName kKnobNames[] = {
+    {"SMOT_NO_FUSE", &Knobs::no_fuse},           {"SMOT_ROI_GENERIC", &Knobs::roi_generic},
+    {"SMOT_TOWER_DIRECT", &Knobs::tower_direct}, {"SMOT_TOWER_WIDE", &Knobs::tower_wide},
+    {"SMOT_DECODE_SPLIT", &Knobs::decode_split}, {"SMOT_XCORR_VARIANT", &Knobs::xcorr_variant},
+    {"SMOT_DECODE_2PASS", &Knobs::decode_two_pass}, {"SMOT_FUSED_GEN", &Knobs::fused_gen},
+    {"SMOT_FUSED_ABL", &Knobs::fused_abl},
+    {"SMOT_WINO_ABL", &Knobs::wino_abl},
+    {"SMOT_TOWER_ABL", &Knobs::tower_abl},
+};
+int parse_knob(const char* name, const char* v) {
+    if (strcmp(name, "SMOT_XCORR_VARIANT") == 0) {
+        static const char* const names[] = {"default", "wave", "patch", "pk", "one", "mfma", "fill", "compute"};
+        for (int i = 0; i < 8; ++i)
+            if (strcmp(v, names[i]) == 0) return i;
+    }
+    return atoi(v);
+}
+Knobs read_env() {                     // once, when the library is loaded
+    Knobs k;
+    for (const KnobName& kn : kKnobNames) {
+        const char* v = getenv(kn.name);
+        if (v != nullptr && v[0] != 0) k.*(kn.field) = parse_knob(kn.name, v);
+    }
+    return k;
+}
+}  // namespace
+Knobs& knobs_mut() {
+    static Knobs k = read_env();
+    return k;
+}
+namespace {
+struct KnobInit {
+    KnobInit() { (void)knobs_mut(); }
+} g_knob_init;
+}  // namespace
+}  // namespace smot
+
+// Measurement library only: set one switch by its SMOT_* name (value as the environment variable would spell
+// it).  Returns SMOT_ERR_BAD_ARG for an unknown name or an out-of-range value.
+extern "C" int smot_debug_set_knob(const char* name, const char* value) {
+    using namespace smot;
+    SMOT_REQUIRE(name && value, "debug_set_knob: null argument");
+    for (const KnobName& kn : kKnobNames)
+        if (strcmp(kn.name, name) == 0) {
+            const int v = parse_knob(name, value);
+            if (kn.field == &Knobs::decode_split)
+                SMOT_REQUIRE(v == 0 || v == 1 || v == 2 || v == 4, "SMOT_DECODE_SPLIT must be 0, 1, 2 or 4 (got %d)", v);
+            if (kn.field == &Knobs::xcorr_variant)
+                SMOT_REQUIRE(v >= 0 && v <= XV_COMPUTE, "SMOT_XCORR_VARIANT out of range (%d)", v);
+            knobs_mut().*(kn.field) = v;
+            return SMOT_OK;
+        }
+    set_error("debug_set_knob: unknown switch %s", name);
+    return SMOT_ERR_BAD_ARG;
+}
+#endif
 
 namespace smot {
 long long* g_trace = nullptr;

@@ -20,7 +20,7 @@
 // separate kernels); NaN scores win and ties go to the lowest flat index, as torch.argmax on CPU.
 #include "smot_common.h"
 #include "logit_src.h"
-#include <stdlib.h>
+#include "knobs.h"
 
 namespace smot {
 
@@ -392,9 +392,9 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     D.use_centerness = use_centerness;
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(cand_ws);
     // thread groups per band: more of them shorten a lane's serial row walk (latency) but repeat the horizontal
-    // pass (work) — worth it while the launch does not fill the chip.  SMOT_DECODE_SPLIT=1|2|4 overrides.
-    const char* sp = getenv("SMOT_DECODE_SPLIT");
-    const int split = sp ? atoi(sp) : ((long long)N * (Ho + 1) <= 768 ? 2 : 1);
+    // pass (work) — worth it while the launch does not fill the chip.  (Measurement library: SMOT_DECODE_SPLIT
+    // = 1|2|4 overrides; validated where it is set.)
+    const int split = knobs().decode_split ? knobs().decode_split : ((long long)N * (Ho + 1) <= 768 ? 2 : 1);
     if (split == 4) {
         hipLaunchKernelGGL(decode_band_kernel<4>, dim3(N, Ho + 1), dim3(1024), smem, st, L, boxes, hann, D, cand);
     } else if (split == 2) {

@@ -6,7 +6,7 @@
 //   smot_emm_extract_cache_fwd == EMM.extract_cache                             (reference EMM/track_core.py:81-98)
 #include "smot_common.h"
 #include "logit_src.h"
-#include <stdlib.h>
+#include "knobs.h"
 
 namespace smot {
 int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tower_w, const float* cls_gn_w,
@@ -51,7 +51,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     float* logits = tower + (size_t)N * 2 * C * ho * ho;
     float* cand = logits + (size_t)N * 8 * ho * ho;       // 7 planes used; 8 keeps the 8-byte alignment
     int rc;
-    const bool no_fuse = getenv("SMOT_NO_FUSE") != nullptr;             // A/B measurements only
+    const bool no_fuse = knobs().no_fuse;             // A/B: measurement library only (constant false otherwise)
     if (rx == 30 && rz == 15 && sampling_ratio == 2 && !no_fuse) {
         // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
         rc = smot_sr_xcorr_fused_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
@@ -90,7 +90,7 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache: bad sizes");
     if (N == 0) return SMOT_OK;
-    if (rz == 15 && sampling_ratio == 2 && getenv("SMOT_ROI_GENERIC") == nullptr) {
+    if (rz == 15 && sampling_ratio == 2 && !knobs().roi_generic) {
         // one launch: separable template pooling, with the search regions written by the same kernel
         const float half_e = (float)((double)search_expansion / 2.0);
         const float two_e = (float)((double)search_expansion * 2.0);

@@ -20,7 +20,7 @@
 // as wave-uniform scalar loads.
 // A generic (any Ho / channel count) tower kernel covers shapes the MFMA tiling does not.
 #include "tower_common.h"
-#include <stdlib.h>
+#include "knobs.h"
 
 namespace smot {
 
@@ -33,8 +33,8 @@ constexpr int T_B_PER_THREAD = T_IC;              // one position of each plane 
 // MT = 2 halves the B-operand traffic per MFMA; MT = 1 doubles the number of workgroups, which is
 // what fills the chip (and puts two waves on every SIMD) at small track counts.
 // ABL: 0 = the kernel; 1 = per-chunk staging removed (every chunk recomputes buffer 0: wrong results,
-// timing only); 2 = fused partial heads removed.  Ablation builds for profiles/, selected with
-// SMOT_TOWER_ABL=1|2.
+// timing only); 2 = fused partial heads removed.  Instantiated in the measurement library only (knobs.h:
+// SMOT_TOWER_ABL).
 template <int MT, int ABL>
 __global__ void __launch_bounds__(256)
 tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
@@ -519,22 +519,25 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
     T.reg_w = reg_w;
     const bool pow2 = (C & (C - 1)) == 0;      // tile counts 1,2,4,...: what heads_combine is built for
     const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && pow2 && (C <= 512) && (cpg <= 16) && (16 % cpg == 0);
-    const bool wino = mfma_ok && tower_packed != nullptr && getenv("SMOT_TOWER_DIRECT") == nullptr;
+    const bool wino = mfma_ok && tower_packed != nullptr && !knobs().tower_direct;
     if (mfma_ok) {
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
         const int blocks32 = N * 2 * (C / 32);
         // measured (profiles/r01_m): 16-channel tiles 1.79 us/track @N=30; 32-channel tiles 2.06 us/track @N=100
-        const bool narrow = wino || blocks32 < 2 * 256 || getenv("SMOT_TOWER_WIDE") == nullptr;
+        const bool narrow = wino || blocks32 < 2 * 256 || !knobs().tower_wide;
         const int mt = narrow ? 1 : 2;
         const int tiles_per_tower = C / (16 * mt);
         const size_t smem = (size_t)2 * (T_STEPS * mt * 64 + T_B_FLOATS) * sizeof(float);
-        const char* abl_s = getenv("SMOT_TOWER_ABL");
-        const int abl = abl_s ? atoi(abl_s) : 0;
+#ifdef SMOT_DEBUG
+        const int abl = knobs().tower_abl;       // timing ablations (wrong results): measurement library only
         const void* fn = narrow ? (abl == 1 ? (const void*)tower_mfma_kernel<1, 1>
                                              : abl == 2 ? (const void*)tower_mfma_kernel<1, 2>
                                                         : (const void*)tower_mfma_kernel<1, 0>)
                                 : (const void*)tower_mfma_kernel<2, 0>;
+#else
+        const void* fn = narrow ? (const void*)tower_mfma_kernel<1, 0> : (const void*)tower_mfma_kernel<2, 0>;
+#endif
         static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};   // one opt-in per kernel
         bool seen = false;
         for (const void* d : attr_done) seen = seen || (d == fn);
@@ -559,10 +562,12 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
             if (rcw) return rcw;
         } else if (!narrow) {
             hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+#ifdef SMOT_DEBUG
         } else if (abl == 1) {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 1>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         } else if (abl == 2) {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 2>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+#endif
         } else {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         }

@@ -17,7 +17,7 @@
 // stores are fully coalesced.  Windows that exceed the LDS budget
 // (degenerate aspect ratios) fall back to direct gathers from the map, same arithmetic.
 #include "roi_common.h"
-#include <stdlib.h>
+#include "knobs.h"
 
 namespace smot {
 
@@ -243,7 +243,7 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
 
     // the two EMM pooler shapes (15x15 templates, 30x30 search regions, 2x2 samples) take the separable
     // wave-per-two-planes kernel of sr_xcorr.hip; everything else the generic kernel below
-    if (out_h == out_w && (out_h == 15 || out_h == 30) && sampling_ratio == 2 && getenv("SMOT_ROI_GENERIC") == nullptr)
+    if (out_h == out_w && (out_h == 15 || out_h == 30) && sampling_ratio == 2 && !knobs().roi_generic)
         return launch_roi_pool_separable(P, C, rois, num_levels > 1 ? level_boxes : rois, R, out_h, out, levels_out,
                                          (hipStream_t)stream);
     const int ch_per_block = RA_CH;

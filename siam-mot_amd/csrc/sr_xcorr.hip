@@ -22,8 +22,8 @@
 // aspect ratios) take a workgroup-uniform slow path: per-bin gathers, same arithmetic as roi_align.hip.
 #include "roi_common.h"
 #include "xcorr_patch2.h"
+#include "knobs.h"
 #include <type_traits>
-#include <stdlib.h>
 
 namespace smot {
 
@@ -544,7 +544,10 @@ sr_xcorr_fused8_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     FX_TRACE(3)
     if constexpr (XCORR) {
         __syncthreads();                                  // both planes of every pair pooled
-        if (wave < 4 && S.abl != 2) {
+#ifdef SMOT_DEBUG
+        if (S.abl == 2) return;                           // timing ablation: measurement library only
+#endif
+        if (wave < 4) {
             const int plane0 = n * C + c0 + 2 * wave;
             const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);
             if (nvalid > 0) {
@@ -566,7 +569,7 @@ int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, co
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace};
-    const bool gen1 = getenv("SMOT_FUSED_GEN1") != nullptr;         // A/B: two planes per wave, four waves
+    const bool gen1 = knobs().fused_gen == 1;         // A/B: two planes per wave, four waves
     if (out_size == 30 && gen1) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
                            (const float*)nullptr, (float*)nullptr, out, levels_out, none);
@@ -593,7 +596,7 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace};
-    if (getenv("SMOT_FUSED_GEN1") != nullptr) {
+    if (knobs().fused_gen == 1) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, boxes, boxes,
                            (const float*)nullptr, (float*)nullptr, templates, (int32_t*)nullptr, S);
     } else {
@@ -623,9 +626,8 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
-    const char* abl_s = getenv("SMOT_FUSED_ABL");
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, abl_s ? atoi(abl_s) : 0};
-    if (getenv("SMOT_FUSED_GEN1") != nullptr) {
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl};
+    if (knobs().fused_gen == 1) {
         hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
                            boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
     } else {

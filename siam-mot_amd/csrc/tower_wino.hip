@@ -26,7 +26,7 @@
 //   epilogue  = output transform (column half in registers, row half across the waves through LDS), two-pass
 //               GroupNorm + affine + ReLU, fused partial heads exactly as in predictor.hip.
 #include "tower_common.h"
-#include <stdlib.h>
+#include "knobs.h"
 
 namespace smot {
 
@@ -75,7 +75,7 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 
 // ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
 // loads inside the loop, 3 = no LDS reads / operand transform, 4 = no MFMAs, 5 = MFMAs + barriers only,
-// 6 = MFMAs only.  SMOT_WINO_ABL=n selects.
+// 6 = MFMAs only.  Instantiated in the measurement library only (knobs.h: SMOT_WINO_ABL).
 template <int ABL>
 __global__ void __launch_bounds__(256, 2)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
@@ -435,12 +435,11 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
     const size_t smem = (size_t)W_SMEM_FLOATS * sizeof(float);     // 58,752 B: two workgroups per CU
     const int tiles = 2 * (C / 16);
     const int grid = ((N + 7) / 8) * 8 * tiles;
-    const char* abl_s = getenv("SMOT_WINO_ABL");
-    const int abl = abl_s ? atoi(abl_s) : 0;
 #define W_LAUNCH(A)                                                                                             \
     hipLaunchKernelGGL(tower_wino_kernel<A>, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part, \
                        g_trace)
-    switch (abl) {
+#ifdef SMOT_DEBUG
+    switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only
         case 1: W_LAUNCH(1); break;
         case 2: W_LAUNCH(2); break;
         case 3: W_LAUNCH(3); break;
@@ -449,6 +448,9 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
         case 6: W_LAUNCH(6); break;
         default: W_LAUNCH(0); break;
     }
+#else
+    W_LAUNCH(0);
+#endif
 #undef W_LAUNCH
     return check_launch("predictor towers (winograd)");
 }

@@ -10,6 +10,7 @@ Operator ↔ reference map (reference paths relative to amazon-science/siam-mot)
     emm_predictor      EMMPredictor.forward        EMM/feature_extractor.py:62-69
     emm_decode         3x F.interpolate + get_locations + decode_response   EMM/track_core.py:69-77
 """
+import contextlib
 import ctypes
 import weakref
 import os
@@ -18,7 +19,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
-ABI_VERSION = 2
+# measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
+# implicitly — only through ``debug_library()`` (tools/, A/B tests).
+DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
+ABI_VERSION = 3
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -30,6 +34,7 @@ _f = ctypes.c_float
 
 _SIGNATURES = {
     "smot_abi_version": (ctypes.c_int, []),
+    "smot_build_info": (ctypes.c_int, []),
     "smot_last_error": (ctypes.c_char_p, []),
     "smot_roi_align_levels_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i,
                                                  _vp, _vp, _vp]),
@@ -59,6 +64,10 @@ _SIGNATURES = {
                                                   _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
+_DEBUG_SIGNATURES = {
+    "smot_debug_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+}
+DEBUG_EXPORTED_SYMBOLS = tuple(_DEBUG_SIGNATURES.keys())
 
 
 def load_library(path=None):
@@ -71,16 +80,53 @@ def load_library(path=None):
         raise RuntimeError(
             "siammot_amd: HIP library %s not found — build it with `python siam-mot_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    _lib = _open(path, _SIGNATURES)
+    return _lib
+
+
+def _open(path, signatures):
     lib = ctypes.CDLL(path)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in signatures.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     if lib.smot_abi_version() != ABI_VERSION:
         raise RuntimeError("siammot_amd: %s has ABI %d, host layer expects %d"
                            % (path, lib.smot_abi_version(), ABI_VERSION))
-    _lib = lib
     return lib
+
+
+_KNOB_DEFAULTS = {"SMOT_NO_FUSE": "0", "SMOT_ROI_GENERIC": "0", "SMOT_TOWER_DIRECT": "0", "SMOT_TOWER_WIDE": "0",
+                  "SMOT_DECODE_SPLIT": "0", "SMOT_XCORR_VARIANT": "default", "SMOT_DECODE_2PASS": "0",
+                  "SMOT_FUSED_GEN": "0", "SMOT_FUSED_ABL": "0", "SMOT_WINO_ABL": "0",
+                  "SMOT_TOWER_ABL": "0"}
+
+
+@contextlib.contextmanager
+def debug_library(**knobs):
+    """Measurement build as the current library inside the block (tools/ and A/B tests only), with the given
+    switches set (``debug_library(SMOT_XCORR_VARIANT="mfma")``; names as in csrc/knobs.h) and every switch
+    back at its default afterwards.  The product library is restored on exit."""
+    global _lib
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise RuntimeError("siammot_amd: measurement library %s not built (python siam-mot_amd/build.py)" % DEBUG_LIB_PATH)
+    load_library()                                  # make sure the product handle exists to return to
+    dbg = _open(DEBUG_LIB_PATH, dict(_SIGNATURES, **_DEBUG_SIGNATURES))
+    if not (dbg.smot_build_info() & 1):
+        raise RuntimeError("siammot_amd: %s is not a measurement build" % DEBUG_LIB_PATH)
+    prev, _lib = _lib, dbg
+
+    def set_all(values):
+        for k, v in values.items():
+            if dbg.smot_debug_set_knob(k.encode(), str(v).encode()) != 0:
+                raise RuntimeError("siammot_amd: " + dbg.smot_last_error().decode("utf-8", "replace"))
+    try:
+        set_all(_KNOB_DEFAULTS)
+        set_all(knobs)
+        yield dbg
+    finally:
+        set_all(_KNOB_DEFAULTS)
+        _lib = prev
 
 
 def _check(rc, what):
@@ -115,6 +161,44 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+class _Launch(object):
+    """Launch context of one binding: every tensor must live on ONE device, that device is made current for
+    the duration of the call (hipLaunchKernelGGL launches on the CURRENT device — a stream handle of another
+    device would be invalid there), and ``stream`` is that device's current torch stream.  A no-op switch when
+    the device is current already (the common case: ~0.5 us)."""
+    __slots__ = ("dev", "prev", "stream")
+
+    def __init__(self, *tensors):
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if not (isinstance(t, torch.Tensor) and t.is_cuda):
+                raise RuntimeError("siammot_amd: inputs must be device (ROCm) tensors — no CPU path exists")
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise RuntimeError("siammot_amd: inputs live on different devices (%s and %s)" % (dev, t.device))
+        if dev is None:
+            raise RuntimeError("siammot_amd: no device tensor among the inputs")
+        self.dev = dev
+        self.prev = None
+        self.stream = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev.index:
+            self.prev = cur
+            torch.cuda.set_device(self.dev.index)
+        self.stream = _stream(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 # ----------------------------------------------------------------------------------------------
 def roi_align_levels(features, rois, level_boxes, out_size, scales, sampling_ratio, pad_cells=None,
                      return_levels=False):
@@ -146,9 +230,10 @@ def roi_align_levels(features, rois, level_boxes, out_size, scales, sampling_rat
     pc = (ctypes.c_int * L)(*[int(p) for p in pad_cells[:L]])
     sc = (ctypes.c_float * L)(*[float(s) for s in scales])
     cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
-    rc = lib.smot_roi_align_levels_fwd(cast(fp), cast(hs), cast(ws), cast(pc), cast(sc), L, C,
-                                       _ptr(rois), _ptr(level_boxes), R, out_size, out_size,
-                                       int(sampling_ratio), _ptr(out), _ptr(levels), _stream())
+    with _Launch(rois, level_boxes, *feats) as ln:
+        rc = lib.smot_roi_align_levels_fwd(cast(fp), cast(hs), cast(ws), cast(pc), cast(sc), L, C,
+                                           _ptr(rois), _ptr(level_boxes), R, out_size, out_size,
+                                           int(sampling_ratio), _ptr(out), _ptr(levels), ln.stream)
     _check(rc, "roi_align_levels")
     return (out, levels) if return_levels else out
 
@@ -158,8 +243,9 @@ def search_region(boxes, pad_pixels, search_expansion, min_search_wh):
     lib = load_library()
     boxes = _dev_f32(boxes, "boxes")
     sr = torch.empty_like(boxes)
-    rc = lib.smot_search_region_fwd(_ptr(boxes), boxes.shape[0], float(pad_pixels), float(search_expansion),
-                                    float(min_search_wh), _ptr(sr), _stream())
+    with _Launch(boxes) as ln:
+        rc = lib.smot_search_region_fwd(_ptr(boxes), boxes.shape[0], float(pad_pixels), float(search_expansion),
+                                        float(min_search_wh), _ptr(sr), ln.stream)
     _check(rc, "search_region")
     return sr
 
@@ -176,7 +262,8 @@ def xcorr_depthwise(x, kernel):
     N, C, Rx, _ = x.shape
     Rz = kernel.shape[2]
     out = torch.empty((N, C, Rx - Rz + 1, Rx - Rz + 1), dtype=torch.float32, device=x.device)
-    rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, _stream())
+    with _Launch(x, kernel) as ln:
+        rc = lib.smot_xcorr_dw_fwd(_ptr(x), _ptr(kernel), _ptr(out), N, C, Rx, Rz, ln.stream)
     _check(rc, "xcorr_depthwise")
     return out
 
@@ -210,7 +297,8 @@ def tower_packed(params):
     if hit is not None and hit[0]() is wc and hit[1]() is wr and hit[2] == ver:
         return hit[3]
     packed = torch.empty((nfl,), dtype=torch.float32, device=wc.device)
-    _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), _stream(wc.device)), "tower_pack")
+    with _Launch(wc, wr) as ln:
+        _check(lib.smot_emm_tower_pack(_ptr(wc), _ptr(wr), C, _ptr(packed), ln.stream), "tower_pack")
     # the image is cached and may be consumed from another stream: finish it now (once per weight set)
     torch.cuda.current_stream(wc.device).synchronize()
     for k in [k for k, v in _pack_cache.items() if v[0]() is None or v[1]() is None]:
@@ -235,8 +323,9 @@ def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5, winograd=True):
     tower_ws = torch.empty((N, 2 * C, Ho, Ho), dtype=torch.float32, device=resp.device)
     logits = torch.empty((N, 7, Ho, Ho), dtype=torch.float32, device=resp.device)
     packed = tower_packed(params) if (winograd and Ho == 16) else None
-    rc = lib.smot_emm_predictor_fwd(_ptr(resp), N, C, Ho, *[_ptr(t) for t in w], int(gn_groups), float(gn_eps),
-                                    _ptr(packed), _ptr(tower_ws), _ptr(logits), _stream())
+    with _Launch(resp, *w) as ln:
+        rc = lib.smot_emm_predictor_fwd(_ptr(resp), N, C, Ho, *[_ptr(t) for t in w], int(gn_groups), float(gn_eps),
+                                        _ptr(packed), _ptr(tower_ws), _ptr(logits), ln.stream)
     _check(rc, "emm_predictor")
     return logits
 
@@ -269,12 +358,13 @@ def emm_decode(logits, sr, boxes, rx, rz, pad_pixels, sigma=0.4, use_centerness=
     bb = torch.empty((N, 4), dtype=torch.float32, device=dev)
     conf = torch.empty((N,), dtype=torch.float32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
-    rc = lib.smot_emm_decode_fwd(_ptr(logits), _ptr(sr), _ptr(boxes), _ptr(hann_window(G, dev)), N, Ho, UP_SCALE,
-                                 int(rx), int(rz), float(pad_pixels), float(1 - sigma), float(sigma),
-                                 int(bool(use_centerness)),
-                                 float(clip_wh[0]) if clip_wh is not None else 0.0,
-                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
-                                 _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), _stream())
+    with _Launch(logits, sr, boxes) as ln:
+        rc = lib.smot_emm_decode_fwd(_ptr(logits), _ptr(sr), _ptr(boxes), _ptr(hann_window(G, dev)), N, Ho, UP_SCALE,
+                                     int(rx), int(rz), float(pad_pixels), float(1 - sigma), float(sigma),
+                                     int(bool(use_centerness)),
+                                     float(clip_wh[0]) if clip_wh is not None else 0.0,
+                                     float(clip_wh[1]) if clip_wh is not None else 0.0,
+                                     _ptr(ws), _ptr(bb), _ptr(conf), _ptr(idx), ln.stream)
     _check(rc, "emm_decode")
     return (bb, conf, idx) if return_index else (bb, conf)
 
@@ -341,8 +431,9 @@ class _LevelGeometry(object):
 _geom_cache = {}
 
 
-def _geometry(features, scales, pad_pixels):
-    """Validate the per-level feature tensors and return the cached geometry with fresh pointers."""
+def _geometry(features, scales, pad_pixels, device):
+    """Validate the per-level feature tensors (all on ``device``) and return the cached geometry with fresh
+    pointers."""
     L = len(scales)
     shapes = tuple(tuple(features[l].shape) for l in range(L))
     key = (shapes, tuple(scales), pad_pixels)
@@ -360,8 +451,16 @@ def _geometry(features, scales, pad_pixels):
         f = features[l]
         if not (f.is_cuda and f.dtype is _F32 and f.is_contiguous()):
             f = g.keep[l] = _dev_f32(f, "features[%d]" % l)         # raises, or copies a strided view
+        if f.device != device:
+            raise RuntimeError("siammot_amd: features[%d] lives on %s, the boxes on %s" % (l, f.device, device))
         fp[l] = f.data_ptr()
     return g
+
+
+def _same_device(device, *named):
+    for name, t in named:
+        if t.device != device:
+            raise RuntimeError("siammot_amd: %s lives on %s, the boxes on %s" % (name, t.device, device))
 
 
 class _ParamBlock(object):
@@ -423,13 +522,16 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
               winograd=True):
     """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``)."""
     lib = _lib or load_library()
-    g = _geometry(features, scales, pad_pixels)
+    if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
+        _dev_f32(boxes, "boxes")                 # raises: no CPU path
+    dev = boxes.device
+    g = _geometry(features, scales, pad_pixels, dev)
     N, C = boxes.shape[0], g.C
     boxes = _chk(boxes, "boxes", (N, 4))
     sr = _chk(sr, "sr", (N, 4))
     templates = _chk(templates, "template_features", (N, C, rz, rz))
-    dev = boxes.device
     blk = _param_block(params)
+    _same_device(dev, ("sr", sr), ("template_features", templates), ("predictor weights", blk.tensors[0]))
     if blk.C != C:
         raise RuntimeError("siammot_amd.emm_track: predictor has %d channels, features have %d" % (blk.C, C))
     ho = rx - rz + 1
@@ -442,7 +544,11 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     bb = torch.empty((N, 4), dtype=_F32, device=dev)
     conf = torch.empty((N,), dtype=_F32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
-    rc = lib.smot_emm_track_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, C,
+    cur = torch.cuda.current_device()           # kernels launch on the CURRENT device: make it the tensors' device
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+    try:
+        rc = lib.smot_emm_track_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, C,
                                 boxes.data_ptr(), sr.data_ptr(), templates.data_ptr(), N, rx, rz, sampling_ratio,
                                 a_pp, gn_groups, gn_eps, hann_window(ho * UP_SCALE, dev).data_ptr(),
                                 UP_SCALE, pad_pixels, 1 - sigma, sigma, 1 if use_centerness else 0,
@@ -450,6 +556,9 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
                                 work.data_ptr(), bb.data_ptr(), conf.data_ptr(),
                                 idx.data_ptr() if idx is not None else None, stream)
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
     if rc:
         _check(rc, "emm_track")
     return (bb, conf, idx) if return_index else (bb, conf)
@@ -458,15 +567,24 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
 def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh):
     """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``)."""
     lib = _lib or load_library()
-    g = _geometry(features, scales, 0)
+    if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
+        _dev_f32(boxes, "boxes")                 # raises: no CPU path
+    dev = boxes.device
+    g = _geometry(features, scales, 0, dev)
     N, C = boxes.shape[0], g.C
     boxes = _chk(boxes, "boxes", (N, 4))
-    dev = boxes.device
     templates = torch.empty((N, C, rz, rz), dtype=_F32, device=dev)
     sr = torch.empty((N, 4), dtype=_F32, device=dev)
-    rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
-                                        rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
-                                        templates.data_ptr(), sr.data_ptr(), _stream(dev))
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+    try:
+        rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
+                                            rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
+                                            templates.data_ptr(), sr.data_ptr(), _stream(dev))
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
     if rc:
         _check(rc, "emm_extract_cache")
     return templates, sr
@@ -483,7 +601,7 @@ def kernel_timer_begin(slot, max_launches, stride=1):
 def kernel_timer_bracket_overhead(reps=200):
     """Median span (us) of an empty event bracket on the current stream."""
     us = ctypes.c_double(0.0)
-    _check(load_library().smot_kernel_timer_bracket_overhead(_stream(), int(reps), ctypes.byref(us)),
+    _check((_lib or load_library()).smot_kernel_timer_bracket_overhead(_stream(), int(reps), ctypes.byref(us)),
            "kernel_timer_bracket_overhead")
     return us.value
 
@@ -520,9 +638,10 @@ def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_rati
     ho = rx - rz + 1
     resp = torch.empty((N, C, ho, ho), dtype=torch.float32, device=boxes.device)
     pooled = torch.empty((N, C, rx, rx), dtype=torch.float32, device=boxes.device) if return_pooled else None
-    rc = lib.smot_sr_xcorr_fused_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
-                                     _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
-                                     _ptr(resp), _ptr(pooled), _stream())
+    with _Launch(boxes, sr, templates, *feats) as ln:
+        rc = lib.smot_sr_xcorr_fused_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
+                                         _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
+                                         _ptr(resp), _ptr(pooled), ln.stream)
     _check(rc, "sr_xcorr_fused")
     return (resp, pooled) if return_pooled else resp
 
@@ -540,7 +659,8 @@ def nms_keep_mask(boxes, scores, thresh):
     sorted_boxes = boxes[order].contiguous()
     ws = torch.empty((max(lib.smot_nms_ws_bytes(n) // 8, 1),), dtype=torch.int64, device=boxes.device)
     keep = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
-    rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), _stream(boxes.device))
+    with _Launch(boxes, scores) as ln:
+        rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), ln.stream)
     _check(rc, "nms")
     mask = torch.empty((n,), dtype=torch.bool, device=boxes.device)
     mask[order] = keep.bool()
@@ -561,7 +681,8 @@ def nms(boxes, scores, thresh):
     sorted_boxes = boxes[order].contiguous()
     ws = torch.empty((max(lib.smot_nms_ws_bytes(n) // 8, 1),), dtype=torch.int64, device=boxes.device)
     keep = torch.empty((n,), dtype=torch.uint8, device=boxes.device)
-    rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), _stream())
+    with _Launch(boxes, scores) as ln:
+        rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), ln.stream)
     _check(rc, "nms")
     return order[keep.bool()].sort()[0]
 
@@ -584,7 +705,8 @@ def preprocess_frame(frame, tables, out_hw, mean, std, to_bgr255):
     out = torch.empty((3, OH, OW), dtype=torch.float32, device=frame.device)
     m = (ctypes.c_float * 3)(*[float(v) for v in mean])
     s = (ctypes.c_float * 3)(*[float(v) for v in std])
-    rc = lib.smot_preprocess_fwd(_ptr(frame), H, W, _ptr(xb), _ptr(xk), xk.shape[1], _ptr(yb), _ptr(yk), yk.shape[1],
-                                 OH, OW, int(max_rows), _cast(m), _cast(s), int(bool(to_bgr255)), _ptr(out), _stream())
+    with _Launch(frame, xb, xk, yb, yk) as ln:
+        rc = lib.smot_preprocess_fwd(_ptr(frame), H, W, _ptr(xb), _ptr(xk), xk.shape[1], _ptr(yb), _ptr(yk), yk.shape[1],
+                                     OH, OW, int(max_rows), _cast(m), _cast(s), int(bool(to_bgr255)), _ptr(out), ln.stream)
     _check(rc, "preprocess_frame")
     return out

@@ -12,9 +12,13 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
+def _header_symbols(debug=False):
+    """Symbols include/smot_emm.h declares; with ``debug`` also those inside ``#ifdef SMOT_DEBUG`` blocks (the
+    measurement library's extra entry points)."""
     src = open(os.path.join(ROOT, "include", "smot_emm.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    if not debug:
+        src = re.sub(r"#ifdef SMOT_DEBUG.*?#endif", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(smot_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -32,6 +36,42 @@ def test_library_exports_every_declared_symbol():
     assert sorted(ops.EXPORTED_SYMBOLS) == declared       # the ctypes table covers the whole header
     ops.load_library()
     assert lib.smot_abi_version() == ops.ABI_VERSION
+    assert lib.smot_build_info() == 0                     # the product library is not a measurement build
+    assert not hasattr(lib, "smot_debug_set_knob")
+
+
+def test_product_library_reads_no_environment_and_has_no_ablation_kernels():
+    """VERDICT r1 #8 / ADVICE: switches that change which kernel runs (or make it compute something else) must
+    not exist in the product library, and nothing on the launch path may call getenv."""
+    import subprocess
+    import siammot_amd.ops as ops
+    nm = subprocess.run(["nm", "-D", "--undefined-only", ops.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in nm, "libsmot_emm.so imports getenv"
+    raw = open(ops.LIB_PATH, "rb").read()
+    for name in (b"SMOT_FUSED_ABL", b"SMOT_WINO_ABL", b"SMOT_TOWER_ABL", b"SMOT_NO_FUSE", b"SMOT_DECODE_SPLIT",
+                 b"SMOT_XCORR_VARIANT", b"xcorr_dw_wave_kernel", b"xcorr_dw_mfma_kernel", b"xcorr_dw_pk_kernel"):
+        assert name not in raw, "%s found in the product library" % name.decode()
+
+
+def test_measurement_library_exports_the_debug_entry_points():
+    import siammot_amd.ops as ops
+    if not os.path.exists(ops.DEBUG_LIB_PATH):
+        pytest.skip("measurement library not built")
+    lib = ctypes.CDLL(ops.DEBUG_LIB_PATH)
+    for name in _header_symbols(debug=True):
+        assert hasattr(lib, name), "libsmot_emm_debug.so lacks %s" % name
+    assert sorted(ops.EXPORTED_SYMBOLS + ops.DEBUG_EXPORTED_SYMBOLS) == _header_symbols(debug=True)
+    assert lib.smot_build_info() & 1
+    lib.smot_debug_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+    lib.smot_last_error.restype = ctypes.c_char_p
+    assert lib.smot_debug_set_knob(b"SMOT_DECODE_SPLIT", b"3") == -1      # validated where it is set
+    assert b"SMOT_DECODE_SPLIT" in lib.smot_last_error()
+    assert lib.smot_debug_set_knob(b"SMOT_NOT_A_SWITCH", b"1") == -1
+    assert lib.smot_debug_set_knob(b"SMOT_DECODE_SPLIT", b"2") == 0
+    assert lib.smot_debug_set_knob(b"SMOT_DECODE_SPLIT", b"0") == 0
+    with ops.debug_library(SMOT_XCORR_VARIANT="mfma") as dbg:
+        assert ops.load_library() is dbg
+    assert ops.load_library().smot_build_info() == 0      # product library restored
 
 
 def test_argument_errors_are_reported_without_a_device():

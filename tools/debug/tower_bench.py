@@ -9,11 +9,10 @@ rs = np.random.RandomState(0)
 boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
 P = {k: torch.from_numpy(v).to(dev) for k, v in gi.predictor_params(rs, 128, boxes).items()}
 ABLS = os.environ.get("ABLS", "0").split(",")
-STAGGERS = [v for v in os.environ.get("STAGGERS", "").split(",") if v]
 for n in (30, 100):
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     for abl in ABLS:
-        os.environ["SMOT_WINO_ABL"] = abl
+      with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl)):
         f = lambda: ops.emm_predictor(resp, P, winograd=(abl != "direct"))
         for _ in range(200): f()
         torch.cuda.synchronize()
@@ -24,22 +23,6 @@ for n in (30, 100):
             ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
             ts.append(ms / cnt * 1e3)
         print(json.dumps({"tracks": n, "variant": abl, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
-os.environ["SMOT_WINO_ABL"] = "0"
-for stg in STAGGERS:
-    os.environ["SMOT_WINO_STAGGER"] = stg
-    for n in (30, 100):
-        resp = torch.randn(n, 128, 16, 16, device=dev) * 15
-        f = lambda: ops.emm_predictor(resp, P)
-        for _ in range(200): f()
-        torch.cuda.synchronize()
-        ts = []
-        for rep in range(5):
-            ops.kernel_timer_begin(ops.TIMER_TOWER, 300)
-            for _ in range(300): f()
-            ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
-            ts.append(ms / cnt * 1e3)
-        print(json.dumps({"tracks": n, "stagger": stg, "tower_event_us_min": round(min(ts), 2)}), flush=True)
-os.environ["SMOT_WINO_STAGGER"] = "0"
 # phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
 lib = ops.load_library()
 for n in (30, 100):

@@ -80,21 +80,23 @@ def main():
             rec("roi_align_sr30", "default", timed(lambda: ops.roi_align_levels(feats, sr, boxes, 30, scales, 2,
                                                                                  [128, 64, 32, 16])))
             rec("roi_align_z15", "default", timed(lambda: ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)))
+            t = timed(lambda: ops.xcorr_depthwise(x, z), batch=50)
+            rec("xcorr", "product library", t, {"algorithmic_GBps_at_min": round(xbytes / t[0] / 1e3, 1),
+                                                "frac_of_8TBps": round(xbytes / t[0] / 1e3 / 8000.0, 4)})
+            # older generations and phase ablations: measurement library only (csrc/knobs.h)
             for var in ("default", "one", "mfma", "pk", "patch", "wave", "fill", "compute"):
-                os.environ["SMOT_XCORR_VARIANT"] = var
-                t = timed(lambda: ops.xcorr_depthwise(x, z), batch=50)
+                with ops.debug_library(SMOT_XCORR_VARIANT=var):
+                    t = timed(lambda: ops.xcorr_depthwise(x, z), batch=50)
                 rec("xcorr", var, t, {"algorithmic_GBps_at_min": round(xbytes / t[0] / 1e3, 1),
                                       "frac_of_8TBps": round(xbytes / t[0] / 1e3 / 8000.0, 4)})
-            os.environ.pop("SMOT_XCORR_VARIANT", None)
             t = timed(lambda: ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512), batch=50)
             rec("sr_pool+xcorr fused", "default", t)
             rec("predictor", "winograd", timed(lambda: ops.emm_predictor(resp, params)))
             rec("predictor", "direct", timed(lambda: ops.emm_predictor(resp, params, winograd=False)))
             for abl in ("1", "2"):
-                os.environ["SMOT_TOWER_ABL"] = abl
-                rec("predictor", "direct ablation %s" % abl,
-                    timed(lambda: ops.emm_predictor(resp, params, winograd=False)))
-            os.environ.pop("SMOT_TOWER_ABL", None)
+                with ops.debug_library(SMOT_TOWER_ABL=abl):
+                    rec("predictor", "direct ablation %s" % abl,
+                        timed(lambda: ops.emm_predictor(resp, params, winograd=False)))
             rec("decode", "default", timed(lambda: ops.emm_decode(logits, sr, boxes, 30, 15, 512)))
             rec("search_region", "default", timed(lambda: ops.search_region(boxes, 512, 1.0, 0)))
 
@@ -104,9 +106,8 @@ def main():
                 emm(feats, dd, ssr, template_features=zz)
                 state = emm.extract_cache(feats, det)
             rec("frame_pair(EMM.forward+extract_cache)", "fused", timed(frame_pair, batch=10))
-            os.environ["SMOT_NO_FUSE"] = "1"
-            rec("frame_pair(EMM.forward+extract_cache)", "unfused", timed(frame_pair, batch=10))
-            os.environ.pop("SMOT_NO_FUSE", None)
+            with ops.debug_library(SMOT_NO_FUSE=1):
+                rec("frame_pair(EMM.forward+extract_cache)", "unfused", timed(frame_pair, batch=10))
 
 
 if __name__ == "__main__":
