@@ -16,7 +16,9 @@ modules outside the hot path) — `config.workload` says so.
 
 Multi-GPU (--gpus N): one process per GPU, each running its own independent stream (SURVEY.md §8e);
 the predictor weights are broadcast once from rank 0 over RCCL before timing; no per-frame
-collective.  Weak scaling: value = N * K / max-over-ranks(elapsed).
+collective.  Weak scaling: value = N * K / max-over-ranks(elapsed).  ``python bench.py --gpus N`` without a
+torchrun environment launches its own ranks (re-executes itself under ``torch.distributed.run`` on 127.0.0.1);
+rank 0 prints the one JSON line either way.
 
 The JSON line also carries:
   roofline     — for the depthwise cross-correlation kernel (the graded kernel): algorithmic bytes
@@ -24,6 +26,9 @@ The JSON line also carries:
                  recorded on the launch stream around every xcorr launch of the timed region.
   cpu_baseline — the CPU oracle (oracle/emm_oracle.py, the reference's torch-CPU ops) timed on this
                  host's cores on the same workload (rank 0, N=1 only), bounded to ~10-20 s.
+  parity       — the LAST result of the timed loop compared, outside the timed region, with the CPU oracle on the
+                 same inputs, and the same kernels on frames 0/1 compared with tests/golden/bench_n<N>.npz, the
+                 output of the reference's own code on these tensors (oracle/gen_golden_bench.py).
 """
 import argparse
 import json
@@ -42,6 +47,10 @@ METRIC = "frame-pairs/sec at 720p, 30 active tracks; EMM xcorr HBM GB/s vs peak"
 NET_HW = (704, 1280)       # 720p under MIN_SIZE_TEST 800 / MAX 1280 / divisibility 32
 CHANNELS = 128
 TIMER_STRIDE = 16          # kernel event brackets on every 16th step of the timed region
+MIN_TIMER_SAMPLES = 200    # bracketed launches per instrumented kernel (a short post-loop tops the count up)
+FEATURE_SETS = 8           # distinct synthetic frames the timed loop rotates through: 8 x 38.4 MB = 307 MB, more
+                           # than the 256 MiB Infinity Cache, so window reads are not served by a cache that two
+                           # alternating frames would stay resident in
 TRACK_SIZES = [(32, 64), (64, 128), (100, 200), (160, 320)]    # (w,h): FPN levels 0,0,1,2
 
 
@@ -213,7 +222,7 @@ def tracking_loop_throughput(n, dev, feats, steps=300):
     from siammot_amd.track_head import build_tracking_loop
     image_wh = (NET_HW[1], NET_HW[0])
     boxes = synthetic_boxes(n, image_wh).to(dev)
-    loop = build_tracking_loop(get_default_cfg(channels=CHANNELS), device=dev)
+    loop = build_tracking_loop(get_default_cfg(channels=CHANNELS), device=dev, refine_tracks=False)
     init_predictor(loop.track.tracker.predictor, boxes.cpu())
     loop.track.tracker.to(dev)
 
@@ -249,6 +258,108 @@ def tower_roofline(n, total_ms, launches, bracket_us):
     }
 
 
+def box_iou(a, b):
+    """Plain continuous IoU of matching rows (the north star's 1e-3 IoU bar)."""
+    ix = (torch.minimum(a[:, 2], b[:, 2]) - torch.maximum(a[:, 0], b[:, 0])).clamp(min=0)
+    iy = (torch.minimum(a[:, 3], b[:, 3]) - torch.maximum(a[:, 1], b[:, 1])).clamp(min=0)
+    inter = ix * iy
+    ua = (a[:, 2] - a[:, 0]).clamp(min=0) * (a[:, 3] - a[:, 1]).clamp(min=0)
+    ub = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
+    union = ua + ub - inter
+    return torch.where(union > 0, inter / union.clamp(min=1e-12), torch.ones_like(union))
+
+
+def _parity_stats(bb, conf, idx, bb_ref, conf_ref, idx_ref):
+    bb, conf, bb_ref, conf_ref = (t.detach().double().cpu() for t in (bb, conf, bb_ref, conf_ref))
+    same = (idx.cpu().long() == idx_ref.cpu().long())
+    return {"tracks": int(bb.shape[0]), "argmax_exact_frac": float(same.double().mean()) if len(same) else 1.0,
+            "min_iou": float(box_iou(bb, bb_ref).min()) if len(same) else 1.0,
+            "max_box_err_px": float((bb - bb_ref).abs().max()) if len(same) else 0.0,
+            "max_score_err": float((conf - conf_ref).abs().max()) if len(same) else 0.0}
+
+
+def parity_report(emm, ops, feats_last, state_last, result_last, feats01, det, boxes_cpu, image_wh, n):
+    """Outside the timed region: (a) the LAST result of the timed loop vs the CPU oracle on the same inputs
+    (what the timed kernels produced, checked by the checker); (b) frames 0 -> 1 and 1 -> 0 through the same
+    entry points vs tests/golden/bench_n<N>.npz, the reference's own output on these tensors."""
+    from oracle import emm_oracle as O            # checker only — never the product path
+    import numpy as np
+    fe, pr = emm.feature_extractor.pooler_x, emm.predictor
+    params = pr.param_dict()
+
+    def hip_track(feats, d, sr, z):
+        return ops.emm_track(feats, d[0].bbox, sr[0].bbox, z, params, emm.rx, emm.rz, tuple(fe.scales),
+                             fe.sampling_ratio, emm.pad_pixels, sigma=emm.sigma, use_centerness=emm.use_centerness,
+                             clip_wh=None if emm.amodal else d[0].size, gn_groups=pr.gn_groups, gn_eps=pr.gn_eps,
+                             return_index=True)
+    out = {}
+    with torch.no_grad():
+        z, sr, d = state_last
+        bb, conf, idx = hip_track(feats_last, d, sr, z)
+        torch.cuda.synchronize()
+        # the re-run IS the timed computation: bit-identical boxes and scores
+        out["rerun_bitwise_equal_to_timed_result"] = bool(
+            torch.equal(bb, result_last[0].bbox) and torch.equal(conf, result_last[0].get_field("scores")))
+        cfg = O.EMMConfig(channels=CHANNELS)
+        p_cpu = {k: v.detach().cpu() for k, v in params.items()}
+        torch.set_num_threads(_cpu_threads())
+        f_cpu = [f.cpu() for f in feats_last]
+        bb_o, conf_o, _, inter = O.emm_forward(cfg, p_cpu, f_cpu, boxes_cpu, sr[0].bbox.cpu(), z.cpu(), image_wh,
+                                               return_intermediates=True, reference_ops=True)
+        idx_o = inter["idx"]
+        out["vs_oracle_fp32"] = _parity_stats(bb, conf, idx, bb_o, conf_o, idx_o)
+        out["vs_oracle_fp32"]["what"] = "last frame pair of the timed loop; oracle/emm_oracle.py on the same inputs"
+        gpath = os.path.join(ROOT, "tests", "golden", "bench_n%d.npz" % n)
+        out["vs_reference_golden"] = None
+        if os.path.exists(gpath) and feats01 is not None:
+            g = np.load(gpath)
+            csum = np.stack([[float(t.double().sum()) for t in f] + [float(t.double().abs().sum()) for t in f]
+                             for f in feats01])
+            if not np.allclose(csum, g["feat_checksum"], rtol=1e-9, atol=1e-6):
+                out["vs_reference_golden"] = {"skipped": "synthetic inputs differ from the ones the golden file was "
+                                                         "generated on (another torch generator?)"}
+            else:
+                worst = None
+                for tag, (a, b) in (("ab", (0, 1)), ("ba", (1, 0))):
+                    zz, ssr, dd = emm.extract_cache(feats01[a], det)
+                    bb, conf, idx = hip_track(feats01[b], dd, ssr, zz)
+                    torch.cuda.synchronize()
+                    st = _parity_stats(bb, conf, idx, torch.from_numpy(g["bb_" + tag]),
+                                       torch.from_numpy(g["scores_" + tag]), torch.from_numpy(g["idx_" + tag]))
+                    st["sr_bit_exact"] = bool(np.array_equal(ssr[0].bbox.cpu().numpy(), g["sr_" + tag]))
+                    if worst is None:
+                        worst = st
+                    else:
+                        worst = {"tracks": worst["tracks"] + st["tracks"],
+                                 "argmax_exact_frac": (worst["argmax_exact_frac"] * worst["tracks"]
+                                                       + st["argmax_exact_frac"] * st["tracks"])
+                                 / (worst["tracks"] + st["tracks"]),
+                                 "min_iou": min(worst["min_iou"], st["min_iou"]),
+                                 "max_box_err_px": max(worst["max_box_err_px"], st["max_box_err_px"]),
+                                 "max_score_err": max(worst["max_score_err"], st["max_score_err"]),
+                                 "sr_bit_exact": worst["sr_bit_exact"] and st["sr_bit_exact"]}
+                worst["what"] = ("frames 0->1 and 1->0 vs tests/golden/bench_n%d.npz = the reference's own EMM code "
+                                 "on these tensors (oracle/gen_golden_bench.py)" % n)
+                out["vs_reference_golden"] = worst
+    return out
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` without a torchrun environment: start the N ranks ourselves (one process per
+    GPU, rendezvous on 127.0.0.1) and let rank 0 print the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: required by RCCL on this host driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,12 +374,19 @@ def main():
                     help="FPN channel count (128 = DLA-34-FPN, the metric's configuration; 256 = R-50-FPN, configs[4])")
     ap.add_argument("--net-hw", type=int, nargs=2, default=list(NET_HW), metavar=("H", "W"),
                     help="network input size (704 1280 = 720p under the default resize rule; 1056 1920 = configs[4])")
+    ap.add_argument("--feature-sets", type=int, default=FEATURE_SETS,
+                    help="distinct synthetic frames the timed loop rotates through (8 x 38 MB exceeds the 256 MiB "
+                         "Infinity Cache; 2 = the cache-warm loop of round 1)")
     ap.add_argument("--extra-streams", type=int, default=2,
                     help="after the timed region, also measure S independent video streams on S HIP streams of the same "
                          "GPU (reported as `multi_stream`, not as `value`); 0 disables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the post-run comparison with the oracle / golden file")
     ap.add_argument("--no-kernel-timer", action="store_true",
                     help="skip the HIP-event bracketing of the xcorr launches (roofline fields become null)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let ranks share a device when fewer GPUs than ranks are visible (flow test only: the "
+                         "collective backend becomes gloo and the JSON says so)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-budget", type=float, default=10.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -277,6 +395,8 @@ def main():
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args.tracks, args.cpu_budget)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     from siammot_amd import ops, parallel
     from siammot_amd.config import get_default_cfg
@@ -284,15 +404,19 @@ def main():
     from siammot_amd.structures import BoxList
     from siammot_amd.track_utils import build_track_utils
 
-    rank, world, local_rank = parallel.init_distributed()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs a ROCm device (the product path has no CPU fallback)"
-    dev_index = local_rank % torch.cuda.device_count()       # ranks > GPUs only in the gloo smoke test
-    torch.cuda.set_device(dev_index)
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world_env))
+    n_dev = torch.cuda.device_count()
+    shared = world_env > n_dev
+    if shared and not (args.allow_shared_gpu or os.environ.get("SMOT_DIST_BACKEND") == "gloo"):
+        raise SystemExit("bench.py: %d ranks but only %d GPU(s) visible (--allow-shared-gpu runs the flow with "
+                         "ranks sharing devices over gloo; it is not a scaling measurement)" % (world_env, n_dev))
+    dev_index = int(os.environ.get("LOCAL_RANK", "0")) % n_dev     # ranks > GPUs only in the shared-device flow test
+    torch.cuda.set_device(dev_index)                          # before the process group: RCCL binds to this device
     dev = torch.device("cuda", dev_index)
+    rank, world, local_rank = parallel.init_distributed(backend="gloo" if shared else None, device=dev)
     ops.load_library()
 
     n = args.tracks
@@ -304,18 +428,33 @@ def main():
         init_predictor(emm.predictor, boxes_cpu)
     emm = emm.to(dev)
     bcast_bytes = parallel.broadcast_module(emm, src=0)       # one RCCL broadcast over xGMI; 0 at N=1
-    feats = [synthetic_features(100 + rank * 2 + k, dev) for k in range(2)]   # two alternating frames
+    K = max(2, args.feature_sets)
+    feats = [synthetic_features(100 + rank * K + k, dev) for k in range(K)]     # the frames the loop rotates through
     det = BoxList(boxes_cpu.to(dev), image_wh, mode="xyxy")
     det.add_field("ids", torch.arange(n, device=dev))
     det.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
 
     def step(k, state):
         z, sr, d = state
-        _, result, _ = emm(feats[k & 1], d, sr, template_features=z)       # frame t: track
-        return emm.extract_cache(feats[k & 1], det), result                # frame t: new templates / SRs
+        f = feats[k % K]
+        _, result, _ = emm(f, d, sr, template_features=z)                  # frame t: track
+        return emm.extract_cache(f, det), result                           # frame t: new templates / SRs
+
+    def timed_run(steps, k0=0):
+        nonlocal state
+        prev = state
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(k0, k0 + steps):
+            prev = state
+            state, result = step(k, state)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        return time.perf_counter() - t0, prev, result
 
     with torch.no_grad():
-        state = emm.extract_cache(feats[1], det)
+        state = emm.extract_cache(feats[K - 1], det)
         t_pre = time.perf_counter()
         while (time.perf_counter() - t_pre) * 1e3 < args.prewarm_ms:     # setup, not part of W or K
             for k in range(32):
@@ -327,23 +466,40 @@ def main():
             # events are created here, outside the timed region.  An event pair costs ~3 us of stream time, so the
             # two instrumented kernels are bracketed on every TIMER_STRIDE-th step only (bracketing all of them
             # slows the frame pair from 80 to 94 us); the samples still come from inside the timed region.
-            ops.kernel_timer_begin(ops.TIMER_XCORR, args.steps, TIMER_STRIDE)
-            ops.kernel_timer_begin(ops.TIMER_TOWER, args.steps, TIMER_STRIDE)
-        parallel.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            state, result = step(k, state)
-        torch.cuda.synchronize()
-        parallel.barrier()
-        elapsed = time.perf_counter() - t0
+            cap = args.steps + MIN_TIMER_SAMPLES * 4 + 8
+            ops.kernel_timer_begin(ops.TIMER_XCORR, cap, TIMER_STRIDE)
+            ops.kernel_timer_begin(ops.TIMER_TOWER, cap, TIMER_STRIDE)
+        elapsed, state_before_last, result = timed_run(args.steps)
+        last_k = args.steps - 1
+        post_steps = 0
+        if not args.no_kernel_timer:
+            # top the bracket samples up to MIN_TIMER_SAMPLES with a post-loop of the same frame pairs (NOT part of
+            # `value`): the driver's default --steps 20 leaves two samples otherwise
+            have = (args.steps + TIMER_STRIDE - 1) // TIMER_STRIDE
+            if have < MIN_TIMER_SAMPLES:
+                post_steps = (MIN_TIMER_SAMPLES - have) * TIMER_STRIDE
+                st_keep = state
+                timed_run(post_steps, k0=args.steps)
+                state = st_keep
         xcorr_total_ms, xcorr_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_XCORR)
         tower_total_ms, tower_launches = (0.0, 0) if args.no_kernel_timer else ops.kernel_timer_end(ops.TIMER_TOWER)
+        # cache-warm variant of the same loop (two alternating frames, as round 1 measured it): informational
+        warm = None
+        if world == 1 and K > 2 and args.steps >= 100:
+            K_keep, K = K, 2
+            timed_run(min(200, args.steps))
+            w_elapsed, _, _ = timed_run(args.steps)
+            K = K_keep
+            warm = {"feature_sets": 2, "value": args.steps / w_elapsed, "unit": "frame-pairs/s",
+                    "ms_per_step": w_elapsed / args.steps * 1e3,
+                    "note": "two alternating frames (77 MB) stay resident in the 256 MiB Infinity Cache"}
     multi = loop_stats = None
     if world == 1 and args.extra_streams > 1:
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
         loop_stats = tracking_loop_throughput(n, dev, feats)
     elapsed = parallel.max_over_ranks(elapsed, dev)
+    backend = torch.distributed.get_backend() if parallel.is_distributed() else "none"
+    dist_world = torch.distributed.get_world_size() if parallel.is_distributed() else 1
     # A bracketed span = kernel + part of the bracket's own span.  The span of an EMPTY bracket on the same stream
     # (two hipEventRecords back to back, ~4.6 us on MI355X) is reported next to the spans as an upper bound of that
     # share; `achieved` uses the RAW spans (conservative: rocprofv3 durations in profiles/ are 2-3 us shorter, and
@@ -353,6 +509,11 @@ def main():
 
     if rank != 0:
         return
+    parity = None
+    if not args.no_parity:
+        golden_ok = (CHANNELS, NET_HW) == (128, (704, 1280))
+        parity = parity_report(emm, ops, feats[last_k % K], state_before_last, result,
+                               feats[:2] if golden_ok else None, det, boxes_cpu, image_wh, n)
     rx, rz = emm.rx, emm.rz
     ho = rx - rz + 1
     # the kernel that runs in the pipeline: search-region pooling fused with the cross-correlation
@@ -380,11 +541,14 @@ def main():
                "frac": xcorr_bytes / t / 1e9 / HBM_PEAK_GBS, "launches_timed": cnt,
                "note": "stand-alone operator, input resident in L2/MALL (not part of the frame-pair pipeline, which "
                        "runs the fused kernel)"}
-    traffic = None
+    traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "xcorr_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(str(n))
+            tj = json.load(open(tpath))
+            traffic = tj.get(str(n))
+            traffic_source = "static:profiles/xcorr_traffic.json (%s)" % tj.get(
+                "source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured by this run")
         except Exception:
             traffic = None
     out = {
@@ -407,14 +571,19 @@ def main():
                         % ("DLA-34-FPN 720p" if (CHANNELS, NET_HW) == (128, (704, 1280)) else "synthetic",
                            NET_HW[0], NET_HW[1], CHANNELS, n),
             "tracks": n, "channels": CHANNELS, "rz": rz, "rx": rx, "prewarm_ms": args.prewarm_ms,
-            "parallelism": "streams x%d (weights broadcast once: %d B)" % (world, bcast_bytes),
+            "feature_sets": K, "feature_bytes_rotated": int(sum(f.numel() for f in feats[0]) * 4 * K),
+            "parallelism": "streams x%d (one process per GPU, no per-frame collective); weights broadcast once: %d B; "
+                           "backend=%s, world_size=%d as reported by torch.distributed%s"
+                           % (world, bcast_bytes, {"nccl": "nccl (RCCL)"}.get(backend, backend), dist_world,
+                              "; RANKS SHARE DEVICES (flow test, not a scaling measurement)" if shared else ""),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "sr_xcorr_fused8_kernel<30,15,2,true> (search-region ROIAlign + depthwise xcorr)",
+            "bound": "hbm", "kernel": ops.fused_kernel_name() + " (search-region ROIAlign + depthwise xcorr)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": fused_bytes,
-            "avg_launch_us": xcorr_avg_s * 1e6, "event_bracket_overhead_us": bracket_us, "launches_timed": xcorr_launches, "timer_stride": TIMER_STRIDE,
+            "avg_launch_us": xcorr_avg_s * 1e6, "event_bracket_overhead_us": bracket_us, "launches_timed": xcorr_launches,
+            "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },
         # the kernel with the largest share of GPU time: the two conv3x3 towers.  Algorithmic FLOPs are those of
@@ -422,6 +591,8 @@ def main():
         # matrix cores, i.e. it EXECUTES 2.25x fewer multiply-adds (reported separately, with the matrix-pipe
         # fraction they amount to).
         "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches, bracket_us),
+        "parity": parity,
+        "cache_warm_loop": warm,
         "multi_stream": multi,
         "tracking_loop": loop_stats,
     }

@@ -593,6 +593,12 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
 TIMER_XCORR, TIMER_TOWER = 0, 1
 
 
+def fused_kernel_name():
+    """Name of the kernel ``smot_emm_track_fwd`` runs for search-region pooling + cross-correlation at the
+    DLA shape family (what bench.py's roofline and the rocprofv3 summaries in profiles/ refer to)."""
+    return "sr_xcorr_fused8_kernel<30,15,2,true>"
+
+
 def kernel_timer_begin(slot, max_launches, stride=1):
     """Start bracketing the kernels of ``slot`` with HIP events on their launch stream (bench.py)."""
     _check(load_library().smot_kernel_timer_begin(int(slot), int(max_launches), int(stride)), "kernel_timer_begin")

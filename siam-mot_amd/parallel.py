@@ -12,9 +12,11 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
+def init_distributed(backend=None, device=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
-    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    Returns (rank, world_size, local_rank).  No-op for a single process.  ``device`` (the rank's GPU, already made
+    current by the caller) is handed to the RCCL process group so that its communicator binds to that device
+    eagerly instead of guessing at the first collective."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -24,7 +26,10 @@ def init_distributed(backend=None):
             backend = os.environ.get("SMOT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world, **kw)
     return rank, world, local_rank
 
 

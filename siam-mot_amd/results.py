@@ -7,6 +7,9 @@ the BoxList lives on the GPU; here each frame's boxes, scores, labels and ids cr
 ``AnnoEntity`` is gluoncv's class in the reference (an un-vendored dependency); the fields the reference
 fills are restated on a plain object.
 """
+import json
+import os
+
 import torch
 
 
@@ -80,3 +83,129 @@ def mot_challenge_rows(entities):
         x, y, w, h = e.bbox
         rows.append("%d,%d,%.2f,%.2f,%.2f,%.2f,%.4f,-1,-1,-1" % (e.frame_num + 1, e.id, x, y, w, h, e.confidence))
     return rows
+
+
+class ResultSample(object):
+    """What ``do_inference`` accumulates per video (inferencer.py:24-75: ``sample.get_copy_without_entities()`` +
+    ``add_entity``) and ``DatasetInference._inference_on_video`` dumps / loads as ``<output_dir>/<sample id>.json``
+    (inferencer.py:118-132).  The reference's container is gluoncv's ``DataSample`` [THIRD PARTY, un-vendored]; the
+    members the reference path uses are restated: id, width / height / fps metadata, the entity list, ``dump`` /
+    ``load`` as JSON, and the two queries ``_postprocess_tracks`` needs."""
+
+    def __init__(self, sample_id, width=None, height=None, fps=None):
+        self.id = sample_id
+        self.width, self.height, self.fps = width, height, fps
+        self.entities = []
+
+    def add_entity(self, entity):
+        self.entities.append(entity)
+
+    def get_copy_without_entities(self):
+        return ResultSample(self.id, self.width, self.height, self.fps)
+
+    def get_entities_with_id(self, track_id):
+        return [e for e in self.entities if e.id == track_id]
+
+    def get_entities_for_frame_num(self, frame_num):
+        return [e for e in self.entities if e.frame_num == frame_num]
+
+    def __len__(self):
+        return len({e.frame_num for e in self.entities})
+
+    def to_dict(self):
+        return {"id": self.id, "metadata": {"resolution": {"width": self.width, "height": self.height},
+                                            "fps": self.fps},
+                "entities": [e.to_dict() for e in self.entities]}
+
+    def dump(self, path):
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        tmp = path + ".tmp"
+        with open(tmp, "w") as f:
+            json.dump(self.to_dict(), f)
+        os.replace(tmp, path)                 # a crashed run never leaves a half-written cache behind
+
+    @classmethod
+    def load(cls, path):
+        with open(path) as f:
+            d = json.load(f)
+        res = d.get("metadata", {}).get("resolution", {})
+        s = cls(d["id"], res.get("width"), res.get("height"), d.get("metadata", {}).get("fps"))
+        for ed in d["entities"]:
+            e = AnnoEntity()
+            for k in AnnoEntity.__slots__:
+                setattr(e, k, ed.get(k))
+            s.entities.append(e)
+        return s
+
+
+def cached_video_result(output_dir, sample_id, run):
+    """``DatasetInference._inference_on_video`` (inferencer.py:118-132): load ``<output_dir>/<id>.json`` if it
+    exists, otherwise call ``run()`` (-> ResultSample) and dump its result there."""
+    cache_path = os.path.join(output_dir, "{}.json".format(sample_id))
+    if os.path.exists(cache_path):
+        return ResultSample.load(cache_path)
+    result = run()
+    result.dump(cache_path)
+    return result
+
+
+def postprocess_tracks(tracks, track_len=5, track_conf=0.7):
+    """``DatasetInference._postprocess_tracks`` (inferencer.py:134-153): keep tracks that last at least
+    ``track_len`` frames with a mean confidence of at least ``track_conf``."""
+    ids = []
+    for e in tracks.entities:
+        if e.id >= 0 and e.id not in ids:
+            ids.append(e.id)
+    out = tracks.get_copy_without_entities()
+    for i in ids:
+        ents = tracks.get_entities_with_id(i)
+        conf = sum(e.confidence for e in ents) / len(ents)
+        if len(ents) >= track_len and conf >= track_conf:
+            for e in ents:
+                out.add_entity(e)
+    return out
+
+
+class FrameSequenceRunner(object):
+    """The per-video loop of the reference's entry points (demos/demo_inference.py:94-122 ``process`` /
+    ``process_frame_sequence``; engine/inferencer.py:24-75 ``do_inference``) around this repository's pieces:
+
+        frame (RGB uint8) -> FramePreprocessor (GPU) -> ``detector(image) -> (FPN features, detections BoxList)``
+        -> TrackingLoop (HIP head + solver + track memory) -> resize to the source frame, xywh -> entities.
+
+    ``detector`` is the PyTorch-ROCm backbone + RPN + box head (outside this repository's scope); anything with
+    that call signature works.  Per frame the results cross to the host in one copy (``boxlist_to_host``)."""
+
+    def __init__(self, detector, tracking_loop, preprocessor, class_table=None):
+        self.detector = detector
+        self.loop = tracking_loop
+        self.preprocess = preprocessor
+        self.class_table = class_table
+
+    def process(self, frame):
+        orig_h, orig_w = int(frame.shape[0]), int(frame.shape[1])
+        image = self.preprocess(frame)
+        features, detections = self.detector(image)
+        out = self.loop(features, detections)
+        return to_original_xywh(out, (orig_w, orig_h))
+
+    def process_frame_sequence(self, frame_iterator):
+        """``frame_iterator``: what calling a video iterator returns.  Yields ``(frame_id, BoxList)`` like the
+        reference; the track pool is reset first (rcnn.py:37-39)."""
+        self.loop.reset()
+        for frame_id, frame in frame_iterator:
+            yield frame_id, self.process(frame)
+
+    def run_video(self, sample_id, video_iterator, fps=None, prefetch_depth=2):
+        """-> ResultSample with one entity per tracked / detected box per frame (do_inference)."""
+        from .video import prefetch
+        result = None
+        for frame_id, frame in prefetch(video_iterator(), prefetch_depth):
+            if result is None:
+                result = ResultSample(sample_id, int(frame.shape[1]), int(frame.shape[0]), fps)
+                self.loop.reset()
+            boxes = self.process(frame)
+            t = frame_id / fps if fps else None
+            for e in boxlists_to_entities([boxes], frame_id, [t], self.class_table):
+                result.add_entity(e)
+        return result if result is not None else ResultSample(sample_id, None, None, fps)

@@ -74,6 +74,15 @@ class BoxList(object):
         """Rescale boxes to a new ``(width, height)`` image size."""
         rw = float(size[0]) / float(self.size[0])
         rh = float(size[1]) / float(self.size[1])
+        if rw == rh:
+            # [UPSTREAM] BoxList.resize: equal ratios scale the stored coordinates directly, in whatever mode
+            # they are (xywh boxes are NOT taken through xyxy and its +-1: different fp32 results otherwise)
+            out = BoxList(self.bbox * rw, size, mode=self.mode)
+            for k, v in self.extra_fields.items():
+                if not isinstance(v, torch.Tensor) and hasattr(v, "resize"):
+                    v = v.resize(size, *args, **kwargs)
+                out.add_field(k, v)
+            return out
         x1, y1, x2, y2 = self._split_into_xyxy()
         out = BoxList(torch.cat((x1 * rw, y1 * rh, x2 * rw, y2 * rh), dim=-1), size, mode="xyxy")
         for k, v in self.extra_fields.items():

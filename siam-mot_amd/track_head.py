@@ -115,7 +115,20 @@ class TrackingLoop(torch.nn.Module):
 
 
 def build_tracking_loop(cfg, device="cuda", refine_tracks=None):
-    """EMM head + track utils + pool + solver from a config (roi_heads.py:87-101)."""
+    """EMM head + track utils + pool + solver from a config (roi_heads.py:87-101).
+
+    ``refine_tracks(features, [tracks]) -> [tracks]`` is the detector's half of the step (``_refine_tracks``,
+    roi_heads.py:60-84: the propagated boxes go through the box head as proposals and come back with the score
+    ``(det + track)/2`` in the (1, 2] band).  Without it the propagated boxes keep their matching score + 1 and are
+    not refined: the solver's thresholds then see different numbers than in the reference, so ids can differ from
+    the reference's on real video — a warning says so once."""
+    if refine_tracks is False:            # explicit: a detector-less loop (benchmarks, synthetic streams)
+        refine_tracks = None
+    elif refine_tracks is None:
+        import warnings
+        warnings.warn("siammot_amd.build_tracking_loop: no refine_tracks callable — propagated boxes are scored "
+                      "track_conf + 1 instead of the reference's box-head refinement (roi_heads.py:60-84); "
+                      "reference-equivalent tracking needs the detector's box head", stacklevel=2)
     from .emm import EMM
     from .solver import TrackPool, builder_tracker_solver
     from .track_utils import build_track_utils

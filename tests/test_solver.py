@@ -151,7 +151,7 @@ def test_tracking_loop_with_the_hip_head_runs_and_stays_consistent():
     from siammot_amd.track_head import build_tracking_loop
     cfg = get_default_cfg(channels=32)
     cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 2
-    loop = build_tracking_loop(cfg, device="cuda:0")
+    loop = build_tracking_loop(cfg, device="cuda:0", refine_tracks=False)
     pool = loop.track.track_pool
     rs = np.random.RandomState(5)
     shapes = gi.feature_shapes((1280, 704), 32)

@@ -1,0 +1,214 @@
+"""Frame iterators, result wire format and the JSON result cache: CPU tests of the host logic and
+one GPU test that feeds a device BoxList coming out of the HIP head through the result path with a single
+device->host copy."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _write_frames(folder, n, hw=(48, 64)):
+    from PIL import Image
+    rs = np.random.RandomState(3)
+    frames = []
+    for i in range(n):
+        # smooth content survives JPEG nearly unchanged; the index is encoded in the mean brightness
+        base = np.full(hw + (3,), 40 + 20 * i, dtype=np.uint8)
+        base[:, : hw[1] // 2, 0] += 10
+        frames.append(base)
+        Image.fromarray(base, "RGB").save(os.path.join(folder, "%06d.jpg" % i), quality=95)
+    (open(os.path.join(folder, "notes.txt"), "w")).write("not a frame")
+    return frames
+
+
+def test_image_folder_iterator_contract(tmp_path):
+    """demos/video_iterator.py:99-125: sorted *.jpg, (frame_idx, RGB uint8 [H,W,3]), len = frames produced,
+    frame_idxs selects and sorts."""
+    from siammot_amd.video import ImageFolderIterator, build_video_iterator
+    frames = _write_frames(str(tmp_path), 5)
+    it = build_video_iterator(str(tmp_path))
+    assert isinstance(it, ImageFolderIterator) and len(it) == 5 and it.video_len() == 5
+    got = list(it())
+    assert [i for i, _ in got] == [0, 1, 2, 3, 4]
+    for (i, f), ref in zip(got, frames):
+        assert f.dtype == np.uint8 and f.shape == ref.shape
+        assert np.abs(f.astype(int) - ref.astype(int)).max() <= 6        # JPEG round trip
+        assert abs(float(f.mean()) - float(ref.mean())) < 1.0
+    sub = ImageFolderIterator(str(tmp_path), frame_idxs=[3, 1])
+    assert len(sub) == 2 and [i for i, _ in sub()] == [1, 3]
+    assert list(ImageFolderIterator(str(tmp_path), frame_idxs=[])()) == []
+    with pytest.raises(FileNotFoundError):
+        ImageFolderIterator(str(tmp_path / "missing"))
+
+
+def test_container_readers_fail_loudly_without_a_decoder(tmp_path):
+    from siammot_amd import video
+    p = tmp_path / "clip.mp4"
+    p.write_bytes(b"\x00" * 16)
+    for kind in ("decord", "cv2"):
+        try:
+            __import__(kind)
+            continue                                      # decoder present on this box: nothing to assert
+        except ImportError:
+            pass
+        with pytest.raises(RuntimeError, match="not installed"):
+            video.build_video_iterator(str(p), video_decode=kind)
+
+
+def test_prefetch_preserves_order_and_surfaces_errors():
+    from siammot_amd.video import ArrayVideoIterator, prefetch
+    frames = [np.full((4, 4, 3), i, dtype=np.uint8) for i in range(7)]
+    out = list(prefetch(ArrayVideoIterator(frames)(), depth=2))
+    assert [i for i, _ in out] == list(range(7)) and all(int(f[0, 0, 0]) == i for i, f in out)
+
+    def bad():
+        yield 0, frames[0]
+        raise ValueError("decoder died")
+    g = prefetch(bad(), depth=1)
+    assert next(g)[0] == 0
+    with pytest.raises(ValueError, match="decoder died"):
+        next(g)
+
+
+def _entity(frame, tid, conf, box=(1.0, 2.0, 3.0, 4.0)):
+    from siammot_amd.results import AnnoEntity
+    e = AnnoEntity()
+    e.bbox, e.confidence, e.labels, e.id, e.frame_num, e.time = list(box), conf, {"person": conf}, tid, frame, frame / 30.0
+    return e
+
+
+def test_result_sample_json_cache_and_postprocess(tmp_path):
+    """inferencer.py:118-153: <output_dir>/<id>.json is written once and re-used; short / unconfident tracks are
+    filtered out afterwards."""
+    from siammot_amd.results import ResultSample, cached_video_result, mot_challenge_rows, postprocess_tracks
+    runs = []
+
+    def run():
+        runs.append(1)
+        s = ResultSample("vid/a", 1920, 1080, 30.0)
+        for f in range(6):
+            s.add_entity(_entity(f, 0, 0.9))          # long and confident: kept
+            s.add_entity(_entity(f, 1, 0.5))          # long but unconfident
+            if f < 3:
+                s.add_entity(_entity(f, 2, 0.95))     # confident but short
+            s.add_entity(_entity(f, -1, 0.99))        # untracked detection
+        return s
+    out_dir = str(tmp_path / "out")
+    a = cached_video_result(out_dir, "vid/a", run)
+    b = cached_video_result(out_dir, "vid/a", run)
+    assert runs == [1]                                # second call came from the JSON cache
+    assert os.path.exists(os.path.join(out_dir, "vid/a.json"))
+    assert json.load(open(os.path.join(out_dir, "vid/a.json")))["metadata"]["resolution"] == {"width": 1920, "height": 1080}
+    assert [e.to_dict() for e in a.entities] == [e.to_dict() for e in b.entities] and len(b) == 6
+    kept = postprocess_tracks(b, track_len=5, track_conf=0.7)
+    assert sorted({e.id for e in kept.entities}) == [0] and len(kept.entities) == 6
+    rows = mot_challenge_rows(kept.entities)
+    assert rows[0] == "1,0,1.00,2.00,3.00,4.00,0.9000,-1,-1,-1" and len(rows) == 6
+
+
+def test_boxlist_resize_equal_ratio_keeps_the_mode():
+    """[UPSTREAM] BoxList.resize: with equal ratios the stored coordinates are scaled as they are (xywh boxes do
+    not take the xyxy round trip and its +-1)."""
+    from siammot_amd.structures import BoxList
+    b = BoxList(torch.tensor([[10.0, 20.0, 30.0, 40.0]]), (100, 50), mode="xywh")
+    r = b.resize((200, 100))
+    assert r.mode == "xywh" and r.bbox.tolist() == [[20.0, 40.0, 60.0, 80.0]]
+    r2 = b.resize((200, 50))                              # unequal ratios: through xyxy (TO_REMOVE = 1)
+    assert r2.mode == "xywh" and r2.bbox.tolist() == [[20.0, 20.0, 59.0, 40.0]]
+
+
+@pytest.mark.gpu
+def test_device_boxlist_from_the_hip_head_to_mot_rows_with_one_host_copy(tmp_path):
+    """EMM.forward on the GPU -> resize to the source frame -> boxlists_to_entities -> MOT rows, with device->host
+    synchronisation counted by torch's sync debug mode: exactly one copy (the reference's version synchronises
+    three times per BOX, boxlists_to_entities.py:25-33)."""
+    import warnings
+    import golden_inputs as gi
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.emm import EMM
+    from siammot_amd.results import ResultSample, boxlists_to_entities, mot_challenge_rows, to_original_xywh
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_utils import build_track_utils
+    dev = "cuda:0"
+    case = gi.EMM_CASES["default"]
+    inp = gi.emm_case_inputs("default")
+    cfg = get_default_cfg(channels=case["channels"])
+    emm = EMM(cfg, build_track_utils(cfg)).to(dev).eval()
+    emm.predictor.load_state_dict({k: torch.from_numpy(v) for k, v in inp["params"].items()})
+    n = len(case["boxes"])
+    det = BoxList(torch.from_numpy(inp["boxes"]).to(dev), case["image_wh"], mode="xyxy")
+    det.add_field("ids", torch.arange(n, device=dev))
+    det.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
+    with torch.no_grad():
+        z, sr, d = emm.extract_cache(tuple(torch.from_numpy(f).to(dev) for f in inp["features_a"]), det)
+        _, result, _ = emm(tuple(torch.from_numpy(f).to(dev) for f in inp["features_b"]), d, sr, template_features=z)
+    torch.cuda.synchronize()
+    out = result[0]
+    assert out.bbox.is_cuda
+    orig_wh = (1280, 960)                                  # the source frame: 2.5x the network input, both axes
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            ents = boxlists_to_entities([to_original_xywh(out, orig_wh)], 7, [0.25])
+        syncs = [x for x in w if "synchroniz" in str(x.message).lower()]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert len(syncs) == 1, "expected ONE device->host copy, saw %d: %s" % (len(syncs), [str(x.message)[:80] for x in syncs])
+    # contents: the reference's per-box loop on the host copy
+    ref = out.to("cpu").resize(orig_wh).convert("xywh")
+    assert len(ents) == n
+    for j, e in enumerate(ents):
+        assert e.bbox == ref.bbox[j].tolist() and e.confidence == ref.get_field("scores")[j].item()
+        assert e.id == j and e.frame_num == 7 and e.time == 0.25 and e.labels == {"person": e.confidence}
+    s = ResultSample("clip", *orig_wh, fps=4.0)
+    for e in ents:
+        s.add_entity(e)
+    path = str(tmp_path / "clip.json")
+    s.dump(path)
+    rows = mot_challenge_rows(ResultSample.load(path).entities)
+    assert len(rows) == n and rows[0].startswith("8,0,")
+
+
+@pytest.mark.gpu
+def test_frame_sequence_runner_over_an_image_folder(tmp_path):
+    """Folder of JPEG frames -> ImageFolderIterator -> FramePreprocessor (GPU) -> synthetic detector -> TrackingLoop
+    (HIP head + solver) -> ResultSample: every frame produces entities, ids persist across frames, and the JSON
+    cache round-trips."""
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.preprocess import FramePreprocessor
+    from siammot_amd.results import FrameSequenceRunner, cached_video_result
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_head import build_tracking_loop
+    from siammot_amd.video import ImageFolderIterator
+    dev = torch.device("cuda:0")
+    _write_frames(str(tmp_path), 6, hw=(96, 128))
+    cfg = get_default_cfg(channels=32)
+    loop = build_tracking_loop(cfg, device=dev, refine_tracks=False)
+    pre = FramePreprocessor(min_size=192, max_size=256, size_divisibility=32, device=dev)
+    boxes = torch.tensor([[20.0, 30.0, 80.0, 150.0], [120.0, 40.0, 200.0, 170.0]], device=dev)
+    g = torch.Generator().manual_seed(0)
+    feats = None
+
+    def detector(image):
+        nonlocal feats
+        _, h, w = image.shape
+        if feats is None:
+            feats = tuple(torch.randn((1, 32, h // s, w // s), generator=g).to(dev) for s in (4, 8, 16, 32, 64))
+        d = BoxList(boxes.clone(), (w, h), mode="xyxy")
+        d.add_field("ids", torch.full((2,), -1, dtype=torch.int64, device=dev))
+        d.add_field("labels", torch.ones(2, dtype=torch.int64, device=dev))
+        d.add_field("scores", torch.tensor([0.9, 0.8], device=dev))
+        return feats, d
+    runner = FrameSequenceRunner(detector, loop, pre)
+    res = cached_video_result(str(tmp_path / "out"), "folder", lambda: runner.run_video(
+        "folder", ImageFolderIterator(str(tmp_path)), fps=30.0))
+    assert (res.width, res.height) == (128, 96) and len(res) == 6
+    per_frame = [sorted(e.id for e in res.get_entities_for_frame_num(f)) for f in range(6)]
+    assert per_frame[0] == [0, 1] and all(set(p) >= {0, 1} for p in per_frame)      # the two tracks persist
+    again = cached_video_result(str(tmp_path / "out"), "folder", lambda: 1 / 0)     # served from the cache
+    assert len(again.entities) == len(res.entities)
+    ids = [fid for fid, _ in runner.process_frame_sequence(ImageFolderIterator(str(tmp_path), frame_idxs=[0, 2])())]
+    assert ids == [0, 2]

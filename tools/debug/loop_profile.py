@@ -7,7 +7,7 @@ from siammot_amd.track_head import build_tracking_loop
 dev = torch.device("cuda:0"); n = 30; image_wh = (1280, 704)
 boxes = bench.synthetic_boxes(n, image_wh).to(dev)
 feats = [bench.synthetic_features(100 + k, dev) for k in range(2)]
-loop = build_tracking_loop(get_default_cfg(channels=128), device=dev)
+loop = build_tracking_loop(get_default_cfg(channels=128), device=dev, refine_tracks=False)
 bench.init_predictor(loop.track.tracker.predictor, boxes.cpu()); loop.track.tracker.to(dev)
 def dets(k):
     d = BoxList(boxes + float(k & 1), image_wh, mode="xyxy")

@@ -6,7 +6,7 @@ from fake_tracker import detections
 from siammot_amd.config import get_default_cfg
 from siammot_amd.track_head import build_tracking_loop
 cfg = get_default_cfg(channels=128); cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 5
-loop = build_tracking_loop(cfg, device="cuda:0")
+loop = build_tracking_loop(cfg, device="cuda:0", refine_tracks=False)
 rs = np.random.RandomState(0)
 shapes = gi.feature_shapes((1280, 704), 128)
 feats = [tuple(torch.from_numpy(rs.standard_normal(s).astype(np.float32)).cuda() for s in shapes) for _ in range(2)]
