@@ -13,10 +13,13 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
                    const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
                    const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
-                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out);
+                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out,
+                   unsigned* zero_words, bool* zeroed);
 int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
                 int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
-                float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, hipStream_t st);
+                float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, bool tickets_zeroed,
+                hipStream_t st);
+unsigned* decode_tickets(float* cand_ws, int N, int Ho);
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
                          float two_e, float min_wh, float* templates, float* sr, hipStream_t st);
@@ -68,8 +71,10 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     // towers only: when the matrix-core path applies the per-tile partial head sums stay in `tower` and the
     // decode kernels sum them while loading (no combine launch, no logits round trip)
     int tiles = 0;
+    bool tickets_zeroed = false;           // the Winograd tower kernel zeroes the decode kernel's tickets on its way
     rc = predictor_impl(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11],
-                        gn_groups, gn_eps, p[12], tower, logits, stream, &tiles);
+                        gn_groups, gn_eps, p[12], tower, logits, stream, &tiles, decode_tickets(cand, N, ho),
+                        &tickets_zeroed);
     if (rc) return rc;
     LogitSrc L;
     L.logits = tiles > 0 ? nullptr : logits;
@@ -80,7 +85,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     L.reg_b = p[11];
     L.logits_out = logits;
     return decode_impl(L, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma, use_centerness,
-                       clip_w, clip_h, cand, bb, conf, idx, (hipStream_t)stream);
+                       clip_w, clip_h, cand, bb, conf, idx, tickets_zeroed, (hipStream_t)stream);
 }
 
 extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,

@@ -495,7 +495,9 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
                    const float* cls_gn_b, const float* reg_tower_w, const float* reg_gn_w, const float* reg_gn_b,
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
                    const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
-                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out) {
+                   const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out,
+                   unsigned* zero_words, bool* zeroed) {
+    if (zeroed) *zeroed = false;
     if (tiles_out) *tiles_out = 0;
     SMOT_REQUIRE(N >= 0 && C > 0 && Ho > 0 && gn_groups > 0, "predictor: bad sizes N=%d C=%d Ho=%d groups=%d", N, C,
                  Ho, gn_groups);
@@ -558,8 +560,9 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         timer_mark(1, 0, st);
         if (wino) {
             SMOT_REQUIRE(((uintptr_t)tower_packed & 15) == 0, "predictor: tower_packed must be 16-byte aligned");
-            int rcw = launch_tower_wino(resp, tower_packed, T, N, C, cpg, gn_eps, tower_ws, st);
+            int rcw = launch_tower_wino(resp, tower_packed, T, N, C, cpg, gn_eps, tower_ws, zero_words, st);
             if (rcw) return rcw;
+            if (zeroed) *zeroed = (zero_words != nullptr);
         } else if (!narrow) {
             hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
 #ifdef SMOT_DEBUG
@@ -633,6 +636,6 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
                                       smot_stream_t stream) {
     return smot::predictor_impl(resp, N, C, Ho, cls_tower_w, cls_gn_w, cls_gn_b, reg_tower_w, reg_gn_w, reg_gn_b, cls_w,
                                 cls_b, center_w, center_b, reg_w, reg_b, gn_groups, gn_eps, tower_packed, tower_ws,
-                                logits, stream, nullptr);
+                                logits, stream, nullptr, nullptr, nullptr);
 }
 

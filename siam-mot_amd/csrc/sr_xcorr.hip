@@ -55,276 +55,7 @@ __device__ __forceinline__ gptr_t uniform_base(const float* p) {
     return reinterpret_cast<gptr_t>(a);
 }
 
-// XCORR = true : pooling + cross-correlation (resp = response [N,C,16,16]; x_debug optional pooled planes)
-// XCORR = false: pooling only — the separable pooler as a stand-alone ROIAlign for RX in {15, 30}
-//                (resp unused, x_debug = output [R,C,RX,RX], z unused); smot_roi_align_levels_fwd
-//                dispatches here for those shapes.
-template <int RX, int RZ, int G, bool XCORR>
-__global__ void __launch_bounds__(256, 3)      // <= 168 VGPRs: three workgroups per CU (LDS allows three)
-sr_xcorr_fused_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
-                      const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
-                      int32_t* __restrict__ levels_out, SrOut S) {
-    constexpr int HO = XCORR ? RX - RZ + 1 : 16;
-    constexpr int NS = RX * G;                   // samples per axis (60)
-    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
-    static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP,
-                  "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
-    __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
-    __shared__ int y_lo[NS], y_hi[NS], x_lo[NS], x_hi[NS];
-    __shared__ float wy_lo[NS], wy_hi[NS], wx_lo[NS], wx_hi[NS];
-    __shared__ int wbound[4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x;
-    const int c0 = blockIdx.y * FX_CH;
-#define FX_TRACE(SLOT)                                                                      \
-    if (S.trace && tid == 0)                                                                \
-        S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
-    FX_TRACE(0)
-    float* xs = sm + wave * (2 * XP + 2 * ZP);
-    float* zs = xs + 2 * XP;
-
-    // ---- roi geometry (same sequence as roi_align_levels_kernel) ----------------------------
-    const float* roi = sr + (size_t)n * 4;
-    int lvl = 0;
-    if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
-    lvl = __builtin_amdgcn_readfirstlane(lvl);           // workgroup-uniform: keep level data in SGPRs
-    if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
-    if (!XCORR && S.sr != nullptr && blockIdx.y == 0 && tid == 0) {
-        const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
-        const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
-        const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
-        const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
-        const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
-        S.sr[n * 4 + 0] = sub_rn(bx1, w_ext);
-        S.sr[n * 4 + 1] = sub_rn(by1, h_ext);
-        S.sr[n * 4 + 2] = add_rn(bx2, w_ext);
-        S.sr[n * 4 + 3] = add_rn(by2, h_ext);
-    }
-    const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
-    const float scale = P.scale[lvl];
-    const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
-    const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
-    const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
-    const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
-    // templates of this wave's planes: issue the loads now, park them in LDS after the tables (hides their latency)
-    const int plane0 = n * C + c0 + 2 * wave;            // first of this wave's two planes
-    const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);   // planes this wave really owns
-    constexpr int NZ = XCORR ? (2 * RZ * RZ + 63) / 64 : 1;
-    float zreg[NZ];
-    if (XCORR && nvalid > 0) {
-        const float* __restrict__ zg = z + (size_t)plane0 * (RZ * RZ);
-        const int zcount = nvalid * RZ * RZ;
-#pragma unroll
-        for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, zcount - 1)];
-    }
-    // Sample tables: wave 0 = the y axis, wave 1 = the x axis, lane = sample.  The bounding window of the touched
-    // real cells is a wave-wide min/max (no LDS atomics), and the entries are re-based before they are stored
-    // (zero-weight entries point at a safe cell; x entries become window-relative lane ids): one barrier.
-    if (wave < 2) {
-        int lo = 0, hi = 0;
-        float wl = 0.0f, wh = 0.0f;
-        if (lane < NS) {
-            if (wave == 0) {
-                axis_sample(y1, bin_h, G, lane, H, pad, &lo, &hi, &wl, &wh);
-            } else {
-                axis_sample(x1, bin_w, G, lane, W, pad, &lo, &hi, &wl, &wh);
-            }
-        }
-        int mn = 0x7fffffff, mx = -1;
-        if (wl != 0.0f) {
-            mn = lo;
-            mx = lo;
-        }
-        if (wh != 0.0f) {
-            mn = min(mn, hi);
-            mx = max(mx, hi);
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            mn = min(mn, __shfl_xor(mn, m));
-            mx = max(mx, __shfl_xor(mx, m));
-        }
-        if (lane < NS) {
-            if (wave == 0) {
-                y_lo[lane] = (wl != 0.0f) ? lo : mn;
-                y_hi[lane] = (wh != 0.0f) ? hi : mn;
-                wy_lo[lane] = wl;
-                wy_hi[lane] = wh;
-            } else {
-                x_lo[lane] = (wl != 0.0f) ? lo - mn : 0;
-                x_hi[lane] = (wh != 0.0f) ? hi - mn : 0;
-                wx_lo[lane] = wl;
-                wx_hi[lane] = wh;
-            }
-        }
-        if (lane == 0) {
-            wbound[2 * wave] = mn;
-            wbound[2 * wave + 1] = mx;
-        }
-    }
-    __syncthreads();
-    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
-    if (ymax < ymin || xmax < xmin) {
-        // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
-        if (nvalid > 0) {
-            if (XCORR)
-                for (int e = lane; e < nvalid * HO * HO; e += 64) resp[(size_t)plane0 * HO * HO + e] = 0.0f;
-            if (x_debug != nullptr)
-                for (int e = lane; e < nvalid * RX * RX; e += 64) x_debug[(size_t)plane0 * RX * RX + e] = 0.0f;
-        }
-        return;
-    }
-    const int ww = xmax - xmin + 1;
-    const bool fast = (ww <= 64);                        // workgroup-uniform
-    if (nvalid <= 0) return;
-    FX_TRACE(1)
-
-    // ---- templates of this wave's planes -> LDS (225 floats per plane, fetched before the tables) ----
-    if (XCORR) {
-#pragma unroll
-        for (int t = 0; t < NZ; ++t) {
-            const int e = lane + 64 * t;
-            if (e < 2 * RZ * RZ) {
-                const int pl = e / (RZ * RZ);
-                const int el = e - pl * (RZ * RZ);
-                const int u = el / RZ;
-                zs[pl * ZP + u * ZS + (el - u * RZ)] = zreg[t];
-            }
-        }
-    }
-
-    FX_TRACE(2)
-    // ---- pooling --------------------------------------------------------------------------
-    const float* __restrict__ fbase = P.feat[lvl];
-    if (fast) {
-        // DUAL (window <= 32 columns, the common case: three of the four benchmark box sizes): the two planes
-        // of the wave are pooled side by side, plane = lane / 32 — half the load, bpermute and FMA instructions
-        // per plane.  Otherwise one plane per pass over all 64 lanes.
-        auto pool = [&](auto dual_tag) {
-            constexpr bool DUAL = decltype(dual_tag)::value;
-            const int half = DUAL ? (lane >> 5) : 0;                 // plane handled by this lane (DUAL)
-            const int col = DUAL ? (lane & 31) : lane;
-            // lanes beyond the window re-read its last column: their values are never gathered
-            const int gcol = xmin + min(col, ww - 1);
-            // a wave that owns a single plane (odd channel tails) lets its upper half shadow plane 0
-            const unsigned plane_off = (DUAL && half == 1 && nvalid > 1) ? (unsigned)(H * W) * 4u : 0u;
-            // lane pw's horizontal taps (pw < RX)
-            const int pw = col < RX ? col : 0;
-            int sxl[G], sxh[G];
-            float hxw[G], lxw[G];
-#pragma unroll
-            for (int ix = 0; ix < G; ++ix) {
-                sxl[ix] = (x_lo[pw * G + ix] + 32 * half) << 2;      // ds_bpermute takes byte addresses (lane*4)
-                sxh[ix] = (x_hi[pw * G + ix] + 32 * half) << 2;
-                hxw[ix] = wx_lo[pw * G + ix];
-                lxw[ix] = wx_hi[pw * G + ix];
-            }
-            // Batches of 15 pooled rows (60 row loads per lane).  The pooling is latency-bound — every batch
-            // is one memory round trip — so the loads of batch k+1 are issued before batch k is consumed (two
-            // named register sets), and only the first round trip is exposed.
-            constexpr int PHB = 15;
-            constexpr int BPP = RX / PHB;                    // batches per plane
-            static_assert(RX % PHB == 0, "pooled size must be a multiple of the batch");
-            const int nb = DUAL ? BPP : nvalid * BPP;
-            float va[PHB][G][2], vb[PHB][G][2];
-            auto issue = [&](int k, float (&v)[PHB][G][2]) {
-                const int pl = DUAL ? 0 : k / BPP, ph0 = (k - pl * BPP) * PHB;
-                const gptr_t fc = uniform_base(fbase + (size_t)(c0 + 2 * wave + pl) * H * W);
-#pragma unroll
-                for (int b = 0; b < PHB; ++b)
-#pragma unroll
-                    for (int iy = 0; iy < G; ++iy) {
-                        const int s = (ph0 + b) * G + iy;
-                        v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u + plane_off);
-                        v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u + plane_off);
-                    }
-            };
-            auto consume = [&](int k, float (&v)[PHB][G][2]) {
-                const int pl = DUAL ? 0 : k / BPP, ph0 = (k - pl * BPP) * PHB;
-                float* xplane = xs + (DUAL ? half : pl) * XP;
-#pragma unroll
-                for (int b = 0; b < PHB; ++b) {
-                    // the horizontal weights do not depend on the y-sample: add the two y-samples' column values
-                    // first, gather once (4 bpermutes per pooled row instead of 8).  The factorisation already
-                    // differs from the reference's rounding sequence at the 1e-7 level (tested to 1e-5).
-                    float col_sum = 0.0f;
-#pragma unroll
-                    for (int iy = 0; iy < G; ++iy) {
-                        const int s = (ph0 + b) * G + iy;
-                        col_sum = fmaf(wy_lo[s], v[b][iy][0], col_sum);
-                        col_sum = fmaf(wy_hi[s], v[b][iy][1], col_sum);
-                    }
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int ix = 0; ix < G; ++ix) {
-                        const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col_sum)));
-                        const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col_sum)));
-                        acc = fmaf(hxw[ix], a, acc);
-                        acc = fmaf(lxw[ix], c, acc);
-                    }
-                    if (col < RX && (!DUAL || half < nvalid))
-                        xplane[(ph0 + b) * XS + col] = acc * (1.0f / (float)(G * G));   // exact: /4
-                }
-            };
-            issue(0, va);
-#pragma unroll 1
-            for (int k = 0; k < nb; k += 2) {
-                if (k + 1 < nb) issue(k + 1, vb);
-                consume(k, va);
-                if (k + 2 < nb) issue(k + 2, va);
-                if (k + 1 < nb) consume(k + 1, vb);
-            }
-        };
-        if (ww <= 32) {
-            pool(std::true_type{});
-        } else {
-            pool(std::false_type{});
-        }
-    } else {
-        // slow path: per-bin gathers from the map (reference term order), lanes stride over the bins
-        for (int pl = 0; pl < nvalid; ++pl) {
-            const float* __restrict__ fc = fbase + (size_t)(c0 + 2 * wave + pl) * H * W;
-            float* xplane = xs + pl * XP;
-            for (int t = lane; t < RX * RX; t += 64) {
-                const int ph = t / RX, pwb = t - ph * RX;
-                float acc = 0.0f;
-#pragma unroll
-                for (int iy = 0; iy < G; ++iy)
-#pragma unroll
-                    for (int ix = 0; ix < G; ++ix) {
-                        const int sy = ph * G + iy, sx = pwb * G + ix;
-                        const int xl = x_lo[sx] + xmin, xh = x_hi[sx] + xmin;
-                        const float v1 = fc[y_lo[sy] * W + xl], v2 = fc[y_lo[sy] * W + xh];
-                        const float v3 = fc[y_hi[sy] * W + xl], v4 = fc[y_hi[sy] * W + xh];
-                        const float w1 = wy_lo[sy] * wx_lo[sx], w2 = wy_lo[sy] * wx_hi[sx];
-                        const float w3 = wy_hi[sy] * wx_lo[sx], w4 = wy_hi[sy] * wx_hi[sx];
-                        acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                    }
-                xplane[ph * XS + pwb] = acc / (float)(G * G);
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    FX_TRACE(3)
-    if (x_debug != nullptr) {
-        for (int e = lane; e < nvalid * RX * RX; e += 64) {
-            const int pl = e / (RX * RX);
-            const int el = e - pl * (RX * RX);
-            const int r = el / RX;
-            x_debug[(size_t)plane0 * RX * RX + e] = xs[pl * XP + r * XS + (el - r * RX)];
-        }
-    }
-    // a wave that owns a single plane (odd channel tails) computes garbage for the second half-wave
-    // and the tail guard below drops it
-    if constexpr (XCORR) xcorr_patch2_compute<RX, RZ, 0>(xs, zs, lane, resp, plane0, plane0 + nvalid);
-    FX_TRACE(4)
-#undef FX_TRACE
-}
-
-
+#ifdef SMOT_DEBUG
 // ---- second generation: one plane per wave, eight waves per workgroup ------------------------------------
 // Same workgroup = (track, 8 channels) and the same LDS image, but every wave pools ONE plane: twice the waves
 // (and row loads) in flight per workgroup, and for windows <= 32 columns the two half-waves take the two halves
@@ -559,29 +290,338 @@ sr_xcorr_fused8_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     FX_TRACE(4)
 #undef FX_TRACE
 }
+#endif  // SMOT_DEBUG (generation 2)
+
+// ---- third generation (default): sample tables in registers, wave-uniform addressing, gathers in bulk ------------
+// What the phase traces of generation 2 showed (profiles/r02a_fused_trace.jsonl, ticks per workgroup @30 tracks):
+// tables 4.3 k, pooling 14 k on average but 26 k for the 33..64-column windows, correlation 12 k.  The pooling was
+// neither bandwidth- nor LDS-bound; it was a chain of dependent round trips: per pooled row one LDS read of the
+// weights, four loads' waits, four ds_bpermute gathers waited for one by one — 15 rows x 2 batches x ~400 cycles —
+// behind a load-issue phase that spent a quarter-rate v_mul_lo_u32 + add per load, behind an LDS table + barrier.
+// This generation removes the chains:
+//   * every wave builds BOTH sample tables itself, lane = sample, in registers (no LDS image, no barrier); the
+//     window bounds come from one ballot per axis (the tables are monotone: first / last touched entry);
+//   * row offsets and vertical weights are read with v_readlane (constant lane) into SGPRs: the 60 row loads of a
+//     batch are buffer loads `voffset = lane column (+ plane), soffset = row` — no per-load VALU at all — and the
+//     vertical taps are FMAs with an SGPR weight;
+//   * all column sums of a batch are formed first, then all 60 gathers are issued back to back and waited for
+//     ONCE, then the horizontal taps run — two LDS round trips per batch instead of thirty;
+//   * windows <= 32 columns: a wave pools TWO planes side by side (plane = lane / 32, same rows and weights for
+//     both halves, so everything stays wave-uniform) and the two waves of a plane pair split the pooled rows:
+//     one batch of 60 loads per wave covers the pair; wider windows: one plane per wave, two batches, the second
+//     batch's loads in flight while the first is gathered; windows wider than a wave are walked in 64-column
+//     chunks by the same code (there is no separate slow path any more).
+// Arithmetic per output is generation 2's, term by term (same fmaf chains), so results are bit-identical to it.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float rl_f(float v, int lane_const) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
+}
+
+template <int RX, int RZ, int G, bool XCORR>
+__global__ void __launch_bounds__(512, 4)      // <= 128 VGPRs: two workgroups (16 waves) per CU
+sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
+                       const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
+                       int32_t* __restrict__ levels_out, SrOut S) {
+    constexpr int HO = XCORR ? RX - RZ + 1 : 16;
+    constexpr int NS = RX * G;                   // samples per axis
+    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
+    constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
+    static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
+                  "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
+    __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+    const int n = blockIdx.x;
+    const int c0 = blockIdx.y * FX_CH;
+#define FX_TRACE(SLOT)                                                                      \
+    if (S.trace && tid == 0)                                                                \
+        S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    FX_TRACE(0)
+
+    const float* roi = sr + (size_t)n * 4;
+    int lvl = 0;
+    if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
+    lvl = __builtin_amdgcn_readfirstlane(lvl);
+    if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
+    if (!XCORR && S.sr != nullptr && blockIdx.y == 0 && tid == 0) {
+        const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
+        const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
+        const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
+        const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
+        const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
+        S.sr[n * 4 + 0] = sub_rn(bx1, w_ext);
+        S.sr[n * 4 + 1] = sub_rn(by1, h_ext);
+        S.sr[n * 4 + 2] = add_rn(bx2, w_ext);
+        S.sr[n * 4 + 3] = add_rn(by2, h_ext);
+    }
+    const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
+    const float scale = P.scale[lvl];
+    const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
+    const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
+    const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
+    const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
+
+    // template of this wave's plane: issue the loads now, park them in LDS after the tables
+    const bool owns = (c0 + wave < C);                    // channel tails: this wave has no plane
+    const int plane = n * C + c0 + wave;
+    constexpr int NZ = XCORR ? (RZ * RZ + 63) / 64 : 1;
+    float zreg[NZ];
+    if (XCORR && owns) {
+        const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
+    }
+
+    // ---- sample tables, lane = sample, both axes in every wave -----------------------------------------------
+    int ylo = 0, yhi = 0, xlo = 0, xhi = 0;
+    float wyl = 0.0f, wyh = 0.0f, wxl = 0.0f, wxh = 0.0f;
+    if (lane < NS) {
+        axis_sample(y1, bin_h, G, lane, H, pad, &ylo, &yhi, &wyl, &wyh);
+        axis_sample(x1, bin_w, G, lane, W, pad, &xlo, &xhi, &wxl, &wxh);
+    }
+    // Bounding window of the touched real cells.  Cell indices are non-decreasing in the sample index and a zero
+    // low weight means "outside" (1 - frac is never 0), so the first touched entry holds the minimum and the last
+    // the maximum: one ballot + two readlanes per axis instead of a 6-step wave reduction of four values.
+    int ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1;
+    {
+        const unsigned long long my = __ballot(wyl != 0.0f || wyh != 0.0f);
+        const unsigned long long mx = __ballot(wxl != 0.0f || wxh != 0.0f);
+        if (my != 0ull) {
+            ymin = __builtin_amdgcn_readlane((wyl != 0.0f) ? ylo : yhi, __ffsll((long long)my) - 1);
+            ymax = __builtin_amdgcn_readlane((wyh != 0.0f) ? yhi : ylo, 63 - __clzll((long long)my));
+        }
+        if (mx != 0ull) {
+            xmin = __builtin_amdgcn_readlane((wxl != 0.0f) ? xlo : xhi, __ffsll((long long)mx) - 1);
+            xmax = __builtin_amdgcn_readlane((wxh != 0.0f) ? xhi : xlo, 63 - __clzll((long long)mx));
+        }
+    }
+    if (ymax < ymin || xmax < xmin) {
+        // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
+        if (owns) {
+            if (XCORR)
+                for (int e = lane; e < HO * HO; e += 64) resp[(size_t)plane * HO * HO + e] = 0.0f;
+            if (x_debug != nullptr)
+                for (int e = lane; e < RX * RX; e += 64) x_debug[(size_t)plane * RX * RX + e] = 0.0f;
+        }
+        return;
+    }
+    // re-base: zero-weight entries point at a safe cell; rows become byte offsets inside a plane, columns become
+    // window-relative
+    const unsigned yoffl = (unsigned)(((wyl != 0.0f) ? ylo : ymin) * W) * 4u;
+    const unsigned yoffh = (unsigned)(((wyh != 0.0f) ? yhi : ymin) * W) * 4u;
+    const int xl = (wxl != 0.0f) ? xlo - xmin : 0;
+    const int xh = (wxh != 0.0f) ? xhi - xmin : 0;
+    const int ww = xmax - xmin + 1;
+    FX_TRACE(1)
+
+    if (XCORR && owns) {
+        float* zs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;    // this wave's template
+#pragma unroll
+        for (int t = 0; t < NZ; ++t) {
+            const int e = lane + 64 * t;
+            if (e < RZ * RZ) {
+                const int u = e / RZ;
+                zs[u * ZS + (e - u * RZ)] = zreg[t];
+            }
+        }
+    }
+    FX_TRACE(2)
+
+    // ---- pooling ----------------------------------------------------------------------------------------------
+    const float* __restrict__ fbase = P.feat[lvl];
+    const unsigned plane_bytes = (unsigned)(H * W) * 4u;
+    // One batch = ROWS pooled rows of one plane (or of a plane pair side by side).  `PAIR`: lanes 32..63 pool the
+    // wave's second plane and the two waves of the pair split the pooled rows; `CHUNKED`: windows wider than 64
+    // columns (rare: small batches keep its loop-carried accumulators out of the register peak).
+    auto pool = [&](auto pair_tag, auto chunk_tag, auto rows_tag) {
+        constexpr bool PAIR = decltype(pair_tag)::value;
+        constexpr bool CHUNKED = decltype(chunk_tag)::value;
+        constexpr int ROWS = decltype(rows_tag)::value;
+        const int half = PAIR ? (lane >> 5) : 0;
+        const int col = PAIR ? (lane & 31) : lane;
+        const int pw = col < RX ? col : 0;
+        // this wave's plane(s) and destination(s) in the LDS image of the correlation
+        const int pl0 = PAIR ? 2 * (wave >> 1) : wave;                 // first plane within the workgroup
+        const bool has0 = (c0 + pl0 < C);
+        const bool has1 = PAIR && (c0 + pl0 + 1 < C);
+        if (!has0) return;
+        const bool mine = PAIR ? (half == 0 || has1) : true;           // this lane's plane exists
+        const unsigned lane_plane = (PAIR && half == 1 && has1) ? plane_bytes : 0u;
+        float* xdst = sm + ((pl0 + half) >> 1) * (2 * XP + 2 * ZP) + ((pl0 + half) & 1) * XP;
+        // buffer resource of the (first) plane: wave-uniform base, offsets are 32-bit
+        const float* pbase = fbase + (size_t)(c0 + pl0) * H * W;
+        unsigned long long pa = reinterpret_cast<unsigned long long>(pbase);
+        const unsigned pa_lo = __builtin_amdgcn_readfirstlane((unsigned)pa);
+        const unsigned pa_hi = __builtin_amdgcn_readfirstlane((unsigned)(pa >> 32));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            reinterpret_cast<void*>(((unsigned long long)pa_hi << 32) | pa_lo), 0, 0x7fffffff, 0x00020000);
+        // horizontal taps of this lane's pooled column: entries 2*pw, 2*pw+1 of the x table
+        int sxl[G], sxh[G];
+        float hxw[G], lxw[G];
+#pragma unroll
+        for (int ix = 0; ix < G; ++ix) {
+            sxl[ix] = __shfl(xl, pw * G + ix);
+            sxh[ix] = __shfl(xh, pw * G + ix);
+            hxw[ix] = __shfl(wxl, pw * G + ix);
+            lxw[ix] = __shfl(wxh, pw * G + ix);
+        }
+        const int row0 = PAIR ? (wave & 1) * RH : 0;           // first pooled row of this wave (wave-uniform)
+        const int nrows = PAIR ? RH : RX;
+        const int nchunk = CHUNKED ? (ww + 63) >> 6 : 1;
+#pragma unroll 1
+        for (int r0 = row0; r0 < row0 + nrows; r0 += ROWS) {
+            // rotate the y tables so that the block's entry (b, iy) sits at lane b*G + iy: constant-lane readlanes
+            const int rot = lane + r0 * G;
+            const unsigned ol = (unsigned)__shfl((int)yoffl, rot), oh = (unsigned)__shfl((int)yoffh, rot);
+            const float wl = (rot < 64) ? __shfl(wyl, rot) : 0.0f, wh = (rot < 64) ? __shfl(wyh, rot) : 0.0f;
+            float acc[ROWS];
+            if (CHUNKED) {
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) acc[b] = 0.0f;
+            }
+#pragma unroll 1
+            for (int ch = 0; ch < nchunk; ++ch) {
+                const int cbase = ch << 6;                                   // first window column of the chunk
+                const int wcol = CHUNKED ? min(cbase + col, ww - 1) : min(col, ww - 1);
+                const unsigned voff = (unsigned)(xmin + wcol) * 4u + lane_plane;
+                float v[ROWS][G][2];
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int e = b * G + iy;
+                        v[b][iy][0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rsrc, voff, __builtin_amdgcn_readlane((int)ol, e), 0));
+                        v[b][iy][1] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            rsrc, voff, __builtin_amdgcn_readlane((int)oh, e), 0));
+                    }
+                // fences: hipcc otherwise sinks the loads to their first use (4 loads, wait, use, next 4 loads ...)
+                __builtin_amdgcn_sched_barrier(0);
+                float cs[ROWS];
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    float c_ = 0.0f;
+#pragma unroll
+                    for (int iy = 0; iy < G; ++iy) {
+                        const int e = b * G + iy;
+                        c_ = fmaf(rl_f(wl, e), v[b][iy][0], c_);
+                        c_ = fmaf(rl_f(wh, e), v[b][iy][1], c_);
+                    }
+                    cs[b] = c_;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // gathers in two groups of rows: all ds_bpermutes of a group are issued back to back and waited for
+                // once (one LDS round trip per group instead of one per tap); two groups keep the register peak
+                // (column sums + gathered taps + tables) under the 128 the correlation phase is scheduled for
+                constexpr int GR = (ROWS + 1) / 2;
+                int al[G], ah[G];
+                bool inl[G], inh[G];
+#pragma unroll
+                for (int ix = 0; ix < G; ++ix) {
+                    const int tl = sxl[ix] - cbase, th = sxh[ix] - cbase;
+                    inl[ix] = !CHUNKED || (unsigned)tl < 64u;
+                    inh[ix] = !CHUNKED || (unsigned)th < 64u;
+                    al[ix] = ((tl & 63) + 32 * half) << 2;                    // ds_bpermute takes byte addresses
+                    ah[ix] = ((th & 63) + 32 * half) << 2;
+                }
+#pragma unroll
+                for (int g0 = 0; g0 < ROWS; g0 += GR) {
+                    float p[GR][G][2];
+#pragma unroll
+                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            p[b - g0][ix][0] = __int_as_float(__builtin_amdgcn_ds_bpermute(al[ix], __float_as_int(cs[b])));
+                            p[b - g0][ix][1] = __int_as_float(__builtin_amdgcn_ds_bpermute(ah[ix], __float_as_int(cs[b])));
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            if (!CHUNKED) {
+                                // (acc[b] is not live across the loads here: first written in this group)
+                                acc[b] = fmaf(hxw[ix], p[b - g0][ix][0], ix == 0 ? 0.0f : acc[b]);
+                                acc[b] = fmaf(lxw[ix], p[b - g0][ix][1], acc[b]);
+                            } else {      // a tap outside the chunk adds nothing (not even 0 * garbage)
+                                acc[b] = inl[ix] ? fmaf(hxw[ix], p[b - g0][ix][0], acc[b]) : acc[b];
+                                acc[b] = inh[ix] ? fmaf(lxw[ix], p[b - g0][ix][1], acc[b]) : acc[b];
+                            }
+                        }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < ROWS; ++b) {
+                const int ph = r0 + b;
+                if (col < RX && ph < row0 + nrows && ph < RX && mine) xdst[ph * XS + col] = acc[b] * (1.0f / (float)(G * G));   // exact: /4
+            }
+        }
+    };
+    if (ww <= 32) {
+        pool(std::true_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+    } else if (ww <= 64) {
+        pool(std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+    } else {
+        pool(std::false_type{}, std::true_type{}, std::integral_constant<int, (RH + 2) / 3>{});
+    }
+    FX_TRACE(3)
+    __syncthreads();                                      // every plane of the workgroup pooled (pairs share rows)
+    if (x_debug != nullptr && owns) {
+        const float* xs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
+        for (int e = lane; e < RX * RX; e += 64) {
+            const int r = e / RX;
+            x_debug[(size_t)plane * RX * RX + e] = xs[r * XS + (e - r * RX)];
+        }
+    }
+    if constexpr (XCORR) {
+#ifdef SMOT_DEBUG
+        if (S.abl == 2) return;                           // timing ablation: measurement library only
+#endif
+        if (wave < 4) {
+            const int plane0 = n * C + c0 + 2 * wave;
+            const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);
+            if (nvalid > 0) {
+                const float* xs2 = sm + wave * (2 * XP + 2 * ZP);
+                xcorr_patch2_compute<RX, RZ, 0>(xs2, xs2 + 2 * XP, lane, resp, plane0, plane0 + nvalid);
+            }
+        }
+    }
+    FX_TRACE(4)
+#undef FX_TRACE
+}
 
 }  // namespace smot
 
 
-// Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).
+// Launch the pooling(+correlation) kernel: generation 3 in the product library; the measurement library can
+// select generation 2 (SMOT_FUSED_GEN=2) for A/B runs.
 namespace smot {
+template <int RX, bool XCORR>
+static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C, const float* rois, const float* boxes,
+                         const float* z, float* resp, float* out, int32_t* levels_out, const SrOut& S) {
+#ifdef SMOT_DEBUG
+    if (knobs().fused_gen == 2) {
+        hipLaunchKernelGGL((sr_xcorr_fused8_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp,
+                           out, levels_out, S);
+        return;
+    }
+#endif
+    hipLaunchKernelGGL((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,
+                       levels_out, S);
+}
+
+// Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace};
-    const bool gen1 = knobs().fused_gen == 1;         // A/B: two planes per wave, four waves
-    if (out_size == 30 && gen1) {
-        hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
-    } else if (out_size == 30) {
-        hipLaunchKernelGGL((sr_xcorr_fused8_kernel<30, 15, 2, false>), grid, dim3(512), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
-    } else if (gen1) {
-        hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0};
+    if (out_size == 30) {
+        launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     } else {
-        hipLaunchKernelGGL((sr_xcorr_fused8_kernel<15, 15, 2, false>), grid, dim3(512), 0, st, P, C, rois, level_boxes,
-                           (const float*)nullptr, (float*)nullptr, out, levels_out, none);
+        launch_fused<15, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     }
     return check_launch("roi_pool_separable");
 }
@@ -595,14 +635,8 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace};
-    if (knobs().fused_gen == 1) {
-        hipLaunchKernelGGL((sr_xcorr_fused_kernel<15, 15, 2, false>), grid, dim3(256), 0, st, P, C, boxes, boxes,
-                           (const float*)nullptr, (float*)nullptr, templates, (int32_t*)nullptr, S);
-    } else {
-        hipLaunchKernelGGL((sr_xcorr_fused8_kernel<15, 15, 2, false>), grid, dim3(512), 0, st, P, C, boxes, boxes,
-                           (const float*)nullptr, (float*)nullptr, templates, (int32_t*)nullptr, S);
-    }
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0};
+    launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
     return check_launch("emm_extract_cache");
 }
 }  // namespace smot
@@ -627,13 +661,7 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl};
-    if (knobs().fused_gen == 1) {
-        hipLaunchKernelGGL((sr_xcorr_fused_kernel<30, 15, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, P, C, sr,
-                           boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
-    } else {
-        hipLaunchKernelGGL((sr_xcorr_fused8_kernel<30, 15, 2, true>), grid, dim3(512), 0, (hipStream_t)stream, P, C, sr,
-                           boxes, templates, resp, x_debug, (int32_t*)nullptr, none);
-    }
+    launch_fused<30, true>(grid, (hipStream_t)stream, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
     timer_mark(0, 1, (hipStream_t)stream);
     return check_launch("sr_xcorr_fused");
 }

@@ -29,7 +29,9 @@ __device__ __forceinline__ float group16_sum(float v) {
 constexpr int T_PLANE = 336;                      // 18*18 = 324 padded to 336
 
 // tower_wino.hip
+// zero_words: N words the kernel sets to zero (the decode kernel's per-track tickets: zeroed here, one launch
+// earlier in the same stream, instead of by a memset node of their own), or nullptr
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
-                      float* part, hipStream_t st);
+                      float* part, unsigned* zero_words, hipStream_t st);
 
 }  // namespace smot

@@ -79,7 +79,8 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 template <int ABL>
 __global__ void __launch_bounds__(256, 2)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
-                  int cpg, float eps, float* __restrict__ part, long long* __restrict__ trace) {
+                  int cpg, float eps, float* __restrict__ part, unsigned* __restrict__ zero_words,
+                  long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
 #define W_TRACE(SLOT) \
@@ -98,6 +99,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int n = (slot / tiles) * 8 + xcd;
     const int tile = slot % tiles;
     if (n >= N) return;
+    if (zero_words != nullptr && tile == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
     // (Workgroups b and b + 256 share a CU — HW_ID trace in tools/debug/tower_bench.py.  Delaying the second
     // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
     // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
@@ -431,13 +433,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 }
 
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
-                      float* part, hipStream_t st) {
+                      float* part, unsigned* zero_words, hipStream_t st) {
     const size_t smem = (size_t)W_SMEM_FLOATS * sizeof(float);     // 58,752 B: two workgroups per CU
     const int tiles = 2 * (C / 16);
     const int grid = ((N + 7) / 8) * 8 * tiles;
 #define W_LAUNCH(A)                                                                                             \
     hipLaunchKernelGGL(tower_wino_kernel<A>, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part, \
-                       g_trace)
+                       zero_words, g_trace)
 #ifdef SMOT_DEBUG
     switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only
         case 1: W_LAUNCH(1); break;

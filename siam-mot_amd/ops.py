@@ -596,7 +596,7 @@ TIMER_XCORR, TIMER_TOWER = 0, 1
 def fused_kernel_name():
     """Name of the kernel ``smot_emm_track_fwd`` runs for search-region pooling + cross-correlation at the
     DLA shape family (what bench.py's roofline and the rocprofv3 summaries in profiles/ refer to)."""
-    return "sr_xcorr_fused8_kernel<30,15,2,true>"
+    return "sr_xcorr_fused9_kernel<30,15,2,true>"
 
 
 def kernel_timer_begin(slot, max_launches, stride=1):

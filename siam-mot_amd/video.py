@@ -44,7 +44,7 @@ class ImageFolderIterator(object):
         up to the decoder's IDCT; both are libjpeg builds)."""
         from PIL import Image
         with Image.open(self.vr[frame_idx]) as im:
-            return np.asarray(im.convert("RGB"))
+            return np.array(im.convert("RGB"))          # a writable copy (torch.from_numpy wants one)
 
     def __call__(self):
         for idx in range(len(self)):

@@ -825,3 +825,119 @@ def test_emm_benchmark_config_vs_reference_golden(ops, n, golden_dir):
             assert (iou(bb.cpu().numpy(), gold["bb_" + tag]) >= 1 - 1e-3).all()
             _assert_close(bb, gold["bb_" + tag], 0, 1e-2, "boxes vs reference (%s)" % tag)
             _assert_close(conf, gold["scores_" + tag], 0, 1e-5, "scores vs reference (%s)" % tag)
+
+
+# ---- round 2 kernels: fused pooling generation 3, one-launch decode -----------------------------------------
+def _bench_geometry(n, seed):
+    import bench
+    image_wh = (1280, 704)
+    g = torch.Generator().manual_seed(seed)
+    feats = tuple(torch.randn((1, 128, 704 // s, 1280 // s), generator=g).to(DEV) for s in (4, 8, 16, 32, 64))
+    boxes = bench.synthetic_boxes(n, image_wh).to(DEV)
+    return feats, boxes
+
+
+@pytest.mark.parametrize("n", [30, 7])
+def test_fused_pooling_generation3_is_bitwise_generation2(ops, n):
+    """Generation 3 (tables in registers, wave-uniform buffer loads, bulk gathers, plane pairs) keeps generation
+    2's arithmetic term by term: pooled planes, responses and templates must be bit-identical to the round-1
+    kernel (kept in the measurement library) at the benchmark geometry — narrow (<= 32 columns) and 33..64-column
+    windows both occur."""
+    feats, boxes = _bench_geometry(n, 5)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    sr = ops.search_region(boxes, 512, 1.0, 0)
+    z = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)
+    r3, p3 = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512, return_pooled=True)
+    x3 = ops.roi_align_levels(feats, sr, boxes, 30, scales, 2, [128, 64, 32, 16])
+    with ops.debug_library(SMOT_FUSED_GEN=2):
+        z2 = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)
+        r2, p2 = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512, return_pooled=True)
+        x2 = ops.roi_align_levels(feats, sr, boxes, 30, scales, 2, [128, 64, 32, 16])
+    assert torch.equal(z, z2), "template pooler: max diff %g" % float((z - z2).abs().max())
+    assert torch.equal(p3, p2), "pooled planes: max diff %g" % float((p3 - p2).abs().max())
+    assert torch.equal(x3, x2) and torch.equal(x3, p3)
+    assert torch.equal(r3, r2), "responses: max diff %g" % float((r3 - r2).abs().max())
+
+
+def test_fused_pooling_odd_channel_counts_and_wide_windows(ops):
+    """Channel counts that leave plane pairs / workgroups half empty (C = 5, 9, 12), and windows wider than a wave
+    (chunked path): against the oracle, and the fused response against the stand-alone composition."""
+    rs = np.random.RandomState(31)
+    scales = (0.25, 0.125)
+    for C in (5, 9, 12):
+        feats = [rs.standard_normal((1, C, 96, 160)).astype(np.float32), rs.standard_normal((1, C, 48, 80)).astype(np.float32)]
+        # box 0: narrow window; box 1: 33..64 columns; box 2: > 64 columns at level 0 (small area, extreme aspect)
+        boxes = np.array([[100.0, 80.0, 140.0, 160.0], [200.0, 60.0, 300.0, 260.0], [20.0, 150.0, 420.0, 165.0]], np.float32)
+        sr = gi.np_search_region(boxes, 64, 1.0)
+        cfg = O.EMMConfig(channels=C, scales=scales, pad_pixels=64)
+        f_t = [_t(f) for f in feats]
+        padded = O.pad_features(f_t, 64)
+        x_ref = O.sr_pool(padded, _t(boxes), _t(sr), 30, scales, 2)
+        z_ref = O.sr_pool(f_t, _t(boxes), None, 15, scales, 2)
+        fd = [_d(f) for f in feats]
+        x = ops.roi_align_levels(fd, _d(sr), _d(boxes), 30, scales, 2, [16, 8])
+        z = ops.roi_align_levels(fd, _d(boxes), _d(boxes), 15, scales, 2)
+        _assert_close(x, x_ref, 1e-5, 1e-5, "SR pooling, C=%d" % C)
+        _assert_close(z, z_ref, 1e-5, 1e-5, "template pooling, C=%d" % C)
+        r, p = ops.sr_xcorr_fused(fd, _d(boxes), _d(sr), z, 30, 15, scales, 2, 64, return_pooled=True)
+        assert torch.equal(p, x)
+        assert torch.equal(r, ops.xcorr_depthwise(x, z))
+
+
+def _random_decode_case(rs, n, logit_scale):
+    wh = rs.uniform(20.0, 300.0, (n, 2))
+    xy = rs.uniform(0.0, 900.0, (n, 2))
+    boxes = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    side = np.stack((wh[:, 0], wh[:, 1], wh[:, 0], wh[:, 1]), 1)[:, :, None, None]
+    return dict(cls=(rs.standard_normal((n, 2, 16, 16)) * logit_scale).astype(np.float32),
+                center=(rs.standard_normal((n, 1, 16, 16)) * logit_scale).astype(np.float32),
+                reg=(np.abs(rs.standard_normal((n, 4, 16, 16))) * 0.5 * side).astype(np.float32),
+                boxes=boxes, sr=gi.np_search_region(boxes, 512, 1.0))
+
+
+def test_decode_one_launch_equals_two_pass_structure(ops):
+    """The one-launch decode (band winners published write-through, last-arriver ticket) against the round-1 band +
+    finalize launches kept in the measurement library: same boxes / scores / cells bit for bit wherever the fast
+    ranking had no near-tie — and repeated calls reuse the self-resetting tickets."""
+    case = dict(gi.DECODE_CASES["default"])
+    rs = np.random.RandomState(123)
+    for n in (1, 30, 100, 37):
+        d = _random_decode_case(rs, n, 2.0)
+        logits = torch.cat([_t(d[k]) for k in ("cls", "center", "reg")], 1).to(DEV)
+        args = (logits, _d(d["sr"]), _d(d["boxes"]), 30, 15, 512)
+        outs = [ops.emm_decode(*args, return_index=True, clip_wh=(1280, 704)) for _ in range(3)]
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+        with ops.debug_library(SMOT_DECODE_2PASS=1):
+            ref = ops.emm_decode(*args, return_index=True, clip_wh=(1280, 704))
+        same = outs[0][2] == ref[2]
+        assert float(same.float().mean()) >= 0.98
+        assert torch.equal(outs[0][0][same], ref[0][same]) and torch.equal(outs[0][1][same], ref[1][same])
+
+
+def test_decode_near_ties_elect_the_exact_argmax(ops):
+    """Nearly flat score maps (logits scaled down to 1e-3 .. 1e-5): thousands of cells within 1e-6 of the maximum,
+    where a ranking pass in fast math elects cells the reference does not.  The kernel re-scores every cell within
+    DEC_TOL of a band's best exactly, so its arg-max must be the fp32 oracle's — or differ by at most the libm
+    rounding of one exponential (2 ulp of the score) between torch-CPU and the device."""
+    case = dict(gi.DECODE_CASES["default"])
+    rs = np.random.RandomState(2024)
+    total = exact = 0
+    for scale in (1e-3, 1e-4, 1e-5, 0.0):
+        d = _random_decode_case(rs, 24, scale)
+        if scale == 0.0:
+            d["reg"][:] = 20.0                                     # identical cells: only the window differs
+        logits = torch.cat([_t(d[k]) for k in ("cls", "center", "reg")], 1)
+        bb, conf, idx = ops.emm_decode(logits.to(DEV), _d(d["sr"]), _d(d["boxes"]), 30, 15, 512, return_index=True)
+        idx = idx.cpu()
+        _, _, idx32, score32 = _decode_oracle(d, case, torch.float32)
+        n = torch.arange(idx.shape[0])
+        same = idx == idx32
+        s_h, s_o = score32[n, idx].double(), score32[n, idx32].double()
+        ulp = torch.maximum(s_o.abs(), torch.tensor(1e-30, dtype=torch.float64)) * 2.0 ** -23
+        ok = same | ((s_o - s_h).abs() <= 2 * ulp)
+        assert bool(ok.all()), "scale %g: tracks %s elect a cell whose oracle score is %s below the maximum" % (
+            scale, (~ok).nonzero().flatten().tolist(), (s_o - s_h)[~ok].tolist())
+        total += len(same)
+        exact += int(same.sum())
+    assert exact >= 0.9 * total, "only %d/%d arg-max cells identical to the fp32 oracle" % (exact, total)
