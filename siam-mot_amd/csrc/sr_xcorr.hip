@@ -475,8 +475,11 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         for (int r0 = row0; r0 < row0 + nrows; r0 += ROWS) {
             // rotate the y tables so that the block's entry (b, iy) sits at lane b*G + iy: constant-lane readlanes
             const int rot = lane + r0 * G;
-            const unsigned ol = (unsigned)__shfl((int)yoffl, rot), oh = (unsigned)__shfl((int)yoffh, rot);
-            const float wl = (rot < 64) ? __shfl(wyl, rot) : 0.0f, wh = (rot < 64) ? __shfl(wyh, rot) : 0.0f;
+            const unsigned ol = (unsigned)__shfl((int)yoffl, rot & 63), oh = (unsigned)__shfl((int)yoffh, rot & 63);
+            // (shuffle first, select afterwards: a ds_bpermute under a lane mask returns 0 for SOURCE lanes that are
+            // masked off, i.e. exactly the upper table entries the lower lanes want)
+            const float wl_s = __shfl(wyl, rot & 63), wh_s = __shfl(wyh, rot & 63);
+            const float wl = (rot < 64) ? wl_s : 0.0f, wh = (rot < 64) ? wh_s : 0.0f;
             float acc[ROWS];
             if (CHUNKED) {
 #pragma unroll
