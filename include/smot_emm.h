@@ -280,6 +280,44 @@ int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, co
                                float pad_pixels, float search_expansion, float min_search_wh,
                                float* templates, float* sr, smot_stream_t stream);
 
+/*
+ * Track solver: one launch for a frame's TrackSolver.forward + pool transitions + active-row filter.
+ *
+ * Replaces TrackSolver.forward (siammot/modelling/track_head/track_solver.py:36-108: score banding of active
+ * tracks :63-69, class-agnostic NMS at IoU 0.5 over detections + dormant + active boxes :22/:71 [UPSTREAM
+ * boxlist_nms -> _C.nms], band removal :30-31, start / inactive / resume decisions :78-92, id writes :94-103),
+ * the TrackPool transitions they trigger (track_head/track_utils.py:157-236: resume_track, start_track,
+ * suspend_track, expire_tracks, increment_frame) and TrackHead._get_track_targets (track_head/track_head.py:99-110).
+ * The reference synchronises with the host once per BOX here; this call never does.
+ *
+ *   det_* / trk_*  the frame's boxes in two segments (the detector's boxes; the boxes the tracker propagated —
+ *                  either may be empty): boxes [n,4] xyxy, scores [n] (IN/OUT: banded in place as the reference
+ *                  does), ids [n] int64 (-1 = no track), labels [n] int64 (may be NULL: 1).
+ *                  trk_score_bias is added to the propagated scores first (the +1 of roi_heads.py:67 when no box
+ *                  head refines them; 0 if they are already in the (1,2] band).
+ *   pool_state     device int32 [8 + 3*pool_capacity], PERSISTENT between frames: word 0 max_id (-1 for a fresh
+ *                  pool), word 1 frame_idx, word 2 n_active, word 3 n_dormant, words 4-7 reserved (0); then the
+ *                  active ids [pool_capacity], the dormant ids [pool_capacity] and the frame each dormant id was
+ *                  last active in [pool_capacity].  Read and rewritten by every call.
+ *   out_*          kept rows in ascending original order (boxes [M,4], scores back in [0,1], ids with new ids
+ *                  started and inactive ones set to -1, labels); M = n_det + n_trk rows of capacity each.
+ *   act_*          the rows of the output whose id is active after the update (the next frame's track targets).
+ *   record         device int32 [8 + 3*M + 3*pool_capacity]: K (kept), A (active rows), max_id, frame_idx,
+ *                  n_active, n_dormant, table overflow flag, M; kept original row [M]; kept id [M]; active-row id
+ *                  [M]; snapshot of the three pool tables.  The only thing the host has to read back.
+ * At most smot_track_solve_max_boxes() boxes / ids per call (one workgroup); more -> SMOT_ERR_UNSUPPORTED.
+ */
+int smot_track_solve_max_boxes(void);
+int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_t* det_ids,
+                         const int64_t* det_labels, int n_det,
+                         const float* trk_boxes, float* trk_scores, const int64_t* trk_ids,
+                         const int64_t* trk_labels, int n_trk, float trk_score_bias,
+                         float track_thresh, float start_thresh, float resume_thresh, float nms_thresh,
+                         int max_dormant_frames, int* pool_state, int pool_capacity,
+                         float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
+                         float* act_boxes, int64_t* act_ids, int64_t* act_labels, float* act_scores,
+                         int* record, smot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

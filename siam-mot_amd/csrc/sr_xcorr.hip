@@ -330,6 +330,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
     __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
+    __shared__ __attribute__((aligned(16))) int4 tab[2][64 + 2 * RH * G];   // y / x sample tables (+ zero pad)
+    __shared__ int wbound[4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -375,29 +377,52 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
     }
 
-    // ---- sample tables, lane = sample, both axes in every wave -----------------------------------------------
-    int ylo = 0, yhi = 0, xlo = 0, xhi = 0;
-    float wyl = 0.0f, wyh = 0.0f, wxl = 0.0f, wxh = 0.0f;
-    if (lane < NS) {
-        axis_sample(y1, bin_h, G, lane, H, pad, &ylo, &yhi, &wyl, &wyh);
-        axis_sample(x1, bin_w, G, lane, W, pad, &xlo, &xhi, &wxl, &wxh);
-    }
-    // Bounding window of the touched real cells.  Cell indices are non-decreasing in the sample index and a zero
-    // low weight means "outside" (1 - frac is never 0), so the first touched entry holds the minimum and the last
-    // the maximum: one ballot + two readlanes per axis instead of a 6-step wave reduction of four values.
-    int ymin = 0x7fffffff, ymax = -1, xmin = 0x7fffffff, xmax = -1;
-    {
-        const unsigned long long my = __ballot(wyl != 0.0f || wyh != 0.0f);
-        const unsigned long long mx = __ballot(wxl != 0.0f || wxh != 0.0f);
-        if (my != 0ull) {
-            ymin = __builtin_amdgcn_readlane((wyl != 0.0f) ? ylo : yhi, __ffsll((long long)my) - 1);
-            ymax = __builtin_amdgcn_readlane((wyh != 0.0f) ? yhi : ylo, 63 - __clzll((long long)my));
+    // ---- sample tables: wave 0 builds the y axis, wave 1 the x axis (lane = sample), one barrier ------------------
+    // (Every wave building both tables itself was measured: eight waves x two tables of ~150 VALU instructions each
+    // cost more issue slots on the CU than the barrier they saved: 5.1 k instead of 4.3 k ticks.)
+    // Entries are stored re-based and packed (16 bytes): y = {row byte offset lo, hi, weight lo, hi}, x = {window
+    // column lo, hi, weight lo, hi}; consumers fetch an entry with one ds_read_b128.
+    if (wave < 2) {
+        int lo = 0, hi = 0;
+        float wl = 0.0f, wh = 0.0f;
+        if (lane < NS) {
+            if (wave == 0) {
+                axis_sample(y1, bin_h, G, lane, H, pad, &lo, &hi, &wl, &wh);
+            } else {
+                axis_sample(x1, bin_w, G, lane, W, pad, &lo, &hi, &wl, &wh);
+            }
         }
-        if (mx != 0ull) {
-            xmin = __builtin_amdgcn_readlane((wxl != 0.0f) ? xlo : xhi, __ffsll((long long)mx) - 1);
-            xmax = __builtin_amdgcn_readlane((wxh != 0.0f) ? xhi : xlo, 63 - __clzll((long long)mx));
+        // Bounding window of the touched real cells.  Cell indices are non-decreasing in the sample index and a
+        // zero low weight means "outside" (1 - frac is never 0), so the first touched entry holds the minimum and
+        // the last the maximum: one ballot + two readlanes instead of a 6-step wave reduction.
+        int mn = 0x7fffffff, mx = -1;
+        const unsigned long long m = __ballot(wl != 0.0f || wh != 0.0f);
+        if (m != 0ull) {
+            mn = __builtin_amdgcn_readlane((wl != 0.0f) ? lo : hi, __ffsll((long long)m) - 1);
+            mx = __builtin_amdgcn_readlane((wh != 0.0f) ? hi : lo, 63 - __clzll((long long)m));
+        }
+        // re-base: zero-weight entries point at a safe cell; rows become byte offsets inside a plane, columns
+        // become window-relative
+        const int rl = (wl != 0.0f) ? lo : mn, rh = (wh != 0.0f) ? hi : mn;
+        int4 e;
+        if (wave == 0) {
+            e.x = (int)((unsigned)(rl * W) * 4u);
+            e.y = (int)((unsigned)(rh * W) * 4u);
+        } else {
+            e.x = (wl != 0.0f) ? lo - mn : 0;
+            e.y = (wh != 0.0f) ? hi - mn : 0;
+        }
+        e.z = __float_as_int(wl);
+        e.w = __float_as_int(wh);
+        tab[wave][lane] = e;
+        if (lane < 2 * RH * G) tab[wave][64 + lane] = make_int4(0, 0, 0, 0);      // the pad behind the table
+        if (lane == 0) {
+            wbound[2 * wave] = mn;
+            wbound[2 * wave + 1] = mx;
         }
     }
+    __syncthreads();
+    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
     if (ymax < ymin || xmax < xmin) {
         // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
         if (owns) {
@@ -408,12 +433,6 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         }
         return;
     }
-    // re-base: zero-weight entries point at a safe cell; rows become byte offsets inside a plane, columns become
-    // window-relative
-    const unsigned yoffl = (unsigned)(((wyl != 0.0f) ? ylo : ymin) * W) * 4u;
-    const unsigned yoffh = (unsigned)(((wyh != 0.0f) ? yhi : ymin) * W) * 4u;
-    const int xl = (wxl != 0.0f) ? xlo - xmin : 0;
-    const int xh = (wxh != 0.0f) ? xhi - xmin : 0;
     const int ww = xmax - xmin + 1;
     FX_TRACE(1)
 
@@ -463,23 +482,22 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         float hxw[G], lxw[G];
 #pragma unroll
         for (int ix = 0; ix < G; ++ix) {
-            sxl[ix] = __shfl(xl, pw * G + ix);
-            sxh[ix] = __shfl(xh, pw * G + ix);
-            hxw[ix] = __shfl(wxl, pw * G + ix);
-            lxw[ix] = __shfl(wxh, pw * G + ix);
+            const int4 e = tab[1][pw * G + ix];
+            sxl[ix] = e.x;
+            sxh[ix] = e.y;
+            hxw[ix] = __int_as_float(e.z);
+            lxw[ix] = __int_as_float(e.w);
         }
         const int row0 = PAIR ? (wave & 1) * RH : 0;           // first pooled row of this wave (wave-uniform)
         const int nrows = PAIR ? RH : RX;
         const int nchunk = CHUNKED ? (ww + 63) >> 6 : 1;
 #pragma unroll 1
         for (int r0 = row0; r0 < row0 + nrows; r0 += ROWS) {
-            // rotate the y tables so that the block's entry (b, iy) sits at lane b*G + iy: constant-lane readlanes
-            const int rot = lane + r0 * G;
-            const unsigned ol = (unsigned)__shfl((int)yoffl, rot & 63), oh = (unsigned)__shfl((int)yoffh, rot & 63);
-            // (shuffle first, select afterwards: a ds_bpermute under a lane mask returns 0 for SOURCE lanes that are
-            // masked off, i.e. exactly the upper table entries the lower lanes want)
-            const float wl_s = __shfl(wyl, rot & 63), wh_s = __shfl(wyh, rot & 63);
-            const float wl = (rot < 64) ? wl_s : 0.0f, wh = (rot < 64) ? wh_s : 0.0f;
+            // this block's y entries: entry (b, iy) into lane b*G + iy (constant-lane readlanes below); entries past
+            // the table (masked tail rows) read the zero pad: weight 0, offset 0
+            const int4 ye = tab[0][min(lane + r0 * G, 63 + 2 * RH * G)];
+            const unsigned ol = (unsigned)ye.x, oh = (unsigned)ye.y;
+            const float wl = __int_as_float(ye.z), wh = __int_as_float(ye.w);
             float acc[ROWS];
             if (CHUNKED) {
 #pragma unroll

@@ -62,6 +62,9 @@ _SIGNATURES = {
                                           _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_extract_cache_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f,
                                                   _vp, _vp, _vp]),
+    "smot_track_solve_max_boxes": (ctypes.c_int, []),
+    "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
+                                            _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 _DEBUG_SIGNATURES = {
@@ -691,6 +694,68 @@ def nms(boxes, scores, thresh):
         rc = lib.smot_nms_fwd(_ptr(sorted_boxes), n, float(thresh), _ptr(ws), _ptr(keep), ln.stream)
     _check(rc, "nms")
     return order[keep.bool()].sort()[0]
+
+
+_rec_pinned = {}
+
+
+def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity):
+    """``smot_track_solve_fwd``: one launch for TrackSolver.forward + the pool transitions + the active-row filter.
+
+    det / trk: ``(boxes [n,4] xyxy, scores [n], ids [n] int64, labels [n] int64 or None)`` device tensors or ``None``
+    for an empty segment.  Returns ``(fbuf, ibuf, rec, M)``: ``fbuf`` fp32 ``[10*M]`` = out_boxes | act_boxes |
+    out_scores | act_scores, ``ibuf`` int64 ``[4*M]`` = out_ids | out_labels | act_ids | act_labels (capacity M rows
+    each; the first K / A are valid) and ``rec``, the record as a host numpy int32 array — read back through a
+    pinned buffer after ONE stream synchronisation, the only one of the frame."""
+    lib = _lib or load_library()
+    segs = []
+    dev = pool_state.device
+    for seg in (det, trk):
+        if seg is None or seg[0].shape[0] == 0:
+            segs.append((0, 0, 0, 0, 0))
+            continue
+        b, s_, i_, l_ = seg
+        if not (b.is_cuda and b.dtype is _F32 and b.is_contiguous() and s_.dtype is _F32 and s_.is_contiguous()
+                and i_.dtype is torch.int64 and i_.is_contiguous()):
+            raise RuntimeError("siammot_amd.track_solve: boxes/scores must be contiguous fp32 and ids int64 device tensors")
+        if b.device != dev:
+            raise RuntimeError("siammot_amd.track_solve: boxes live on %s, the pool state on %s" % (b.device, dev))
+        if l_ is not None and not (l_.dtype is torch.int64 and l_.is_contiguous() and l_.device == dev):
+            raise RuntimeError("siammot_amd.track_solve: labels must be a contiguous int64 tensor on the boxes' device")
+        segs.append((b.data_ptr(), s_.data_ptr(), i_.data_ptr(), l_.data_ptr() if l_ is not None else 0, b.shape[0]))
+    M = segs[0][4] + segs[1][4]
+    nrec = 8 + 3 * M + 3 * pool_capacity
+    fbuf = torch.empty((10 * max(M, 1),), dtype=_F32, device=dev)
+    ibuf = torch.empty((4 * max(M, 1),), dtype=torch.int64, device=dev)
+    rec = torch.empty((nrec,), dtype=torch.int32, device=dev)
+    fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+    try:
+        rc = lib.smot_track_solve_fwd(segs[0][0], segs[0][1], segs[0][2], segs[0][3], segs[0][4],
+                                      segs[1][0], segs[1][1], segs[1][2], segs[1][3], segs[1][4], trk_score_bias,
+                                      thresholds[0], thresholds[1], thresholds[2], nms_thresh, max_dormant_frames,
+                                      pool_state.data_ptr(), pool_capacity,
+                                      fp, fp + 32 * M, ip, ip + 8 * M, fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,
+                                      rec.data_ptr(), _stream(dev))
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
+    if rc:
+        _check(rc, "track_solve")
+    host = _rec_pinned.get((dev, nrec))
+    if host is None:
+        if len(_rec_pinned) > 64:
+            _rec_pinned.clear()
+        host = _rec_pinned[(dev, nrec)] = torch.empty((nrec,), dtype=torch.int32).pin_memory()
+    host.copy_(rec, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()              # the frame's one host synchronisation
+    return fbuf, ibuf, host.numpy().copy(), M
+
+
+def track_solve_max_boxes():
+    return (_lib or load_library()).smot_track_solve_max_boxes()
 
 
 def preprocess_frame(frame, tables, out_hw, mean, std, to_bgr255):

@@ -48,6 +48,8 @@ class _CacheEntry(object):
 class TrackPool(object):
     """Track-id life cycle and per-track cache (track_utils.py:138-250), host-side state."""
 
+    DEVICE_CAPACITY = 512           # ids per table of the device-resident state (csrc/track_solver.hip: TS_MAXM)
+
     def __init__(self, active_ids=None, max_entangle_length=10, max_dormant_frames=1):
         self._active_ids = set()
         self._dormant_ids = {}          # id -> frame index at which it was last active
@@ -58,14 +60,58 @@ class TrackPool(object):
         self._frame_idx = 0
         self._max_dormant_frames = max_dormant_frames
         self._max_entangle_length = max_entangle_length
+        # The pool as the solver kernel sees it (ops.track_solve): an int32 tensor on the tracker's device, read
+        # and rewritten by the kernel every frame.  These Python sets are its MIRROR, refreshed from the record the
+        # kernel hands back; a mutation through the methods below marks the device copy stale instead.
+        self._dev_state = None
+        self._dev_stale = True
+
+    # ---- device-resident state -------------------------------------------------------------------
+    def device_state(self, device):
+        """The int32 state tensor on ``device`` (layout: include/smot_emm.h, smot_track_solve_fwd), uploaded from the
+        host mirror when the mirror was modified since the last kernel call."""
+        cap = self.DEVICE_CAPACITY
+        if self._dev_state is None or self._dev_state.device != device:
+            self._dev_state = torch.zeros((8 + 3 * cap,), dtype=torch.int32, device=device)
+            self._dev_stale = True
+        if self._dev_stale:
+            if len(self._active_ids) > cap or len(self._dormant_ids) > cap:
+                raise RuntimeError("TrackPool: more than %d active / dormant ids — beyond the device-resident solver" % cap)
+            h = np.zeros(8 + 3 * cap, dtype=np.int32)
+            h[0], h[1], h[2], h[3] = self._max_id, self._frame_idx, len(self._active_ids), len(self._dormant_ids)
+            h[8:8 + len(self._active_ids)] = sorted(self._active_ids)
+            dorm = sorted(self._dormant_ids.items())
+            h[8 + cap:8 + cap + len(dorm)] = [d[0] for d in dorm]
+            h[8 + 2 * cap:8 + 2 * cap + len(dorm)] = [d[1] for d in dorm]
+            self._dev_state.copy_(torch.from_numpy(h))
+            self._dev_stale = False
+        return self._dev_state
+
+    def _mirror(self, rec, M):
+        """Refresh the host mirror from the kernel's record (header + snapshot of the three tables)."""
+        cap = self.DEVICE_CAPACITY
+        na, nd = int(rec[4]), int(rec[5])
+        base = 8 + 3 * M
+        active = set(rec[base:base + na].tolist())
+        dormant = dict(zip(rec[base + cap:base + cap + nd].tolist(), rec[base + 2 * cap:base + 2 * cap + nd].tolist()))
+        gone = (self._active_ids | set(self._dormant_ids)) - active - set(dormant)
+        for tid in gone:                              # expire_tracks: killed ids lose their cache entry
+            self._cache.pop(tid, None)
+        self._kill_ids |= gone
+        self._active_ids, self._dormant_ids = active, dormant
+        self._max_id, self._frame_idx = int(rec[2]), int(rec[3])
+        if rec[6]:
+            raise RuntimeError("TrackPool: the device-resident id tables overflowed (%d ids per table)" % cap)
 
     def suspend_track(self, track_id):
         if track_id not in self._active_ids:
             raise ValueError
+        self._dev_stale = True
         self._active_ids.remove(track_id)
         self._dormant_ids[track_id] = self._frame_idx - 1
 
     def expire_tracks(self):
+        self._dev_stale = True
         for track_id, last_active in list(self._dormant_ids.items()):
             if self._frame_idx - last_active >= self._max_dormant_frames:
                 self._dormant_ids.pop(track_id)
@@ -73,6 +119,7 @@ class TrackPool(object):
                 self._cache.pop(track_id, None)
 
     def increment_frame(self, value=1):
+        self._dev_stale = True
         self._frame_idx += value
 
     def update_cache(self, cache):
@@ -83,7 +130,9 @@ class TrackPool(object):
         n = len(template_boxes)
         if n == 0:
             return
-        ids = template_boxes.get_field("ids").tolist()
+        ids = getattr(template_boxes, "host_ids", None)     # already on the host after the solver kernel's record
+        if ids is None:
+            ids = template_boxes.get_field("ids").tolist()
         if len(template_features) > 0:
             assert len(template_features) == len(sr)
         # a dormant track's entry must not be replaced by a lazy view of a memory that contains that very entry
@@ -99,17 +148,20 @@ class TrackPool(object):
     def resume_track(self, track_id):
         if track_id not in self._dormant_ids or track_id in self._active_ids:
             raise ValueError
+        self._dev_stale = True
         self._active_ids.add(track_id)
         self._dormant_ids.pop(track_id)
 
     def kill_track(self, track_id):
         if track_id not in self._active_ids:
             raise ValueError
+        self._dev_stale = True
         self._active_ids.remove(track_id)
         self._kill_ids.add(track_id)
         self._cache.pop(track_id, None)
 
     def start_track(self):
+        self._dev_stale = True
         self._max_id += 1
         self._active_ids.add(self._max_id)
         return self._max_id
@@ -145,12 +197,68 @@ class TrackSolver(torch.nn.Module):
         self.resume_track_thresh = resume_track_thresh
         self.nms_mask_fn = nms_mask_fn or ops.nms_keep_mask
 
+    def _device_path(self, *boxlists):
+        """The one-launch kernel applies: default NMS, device tensors, few enough boxes."""
+        if self.nms_mask_fn is not ops.nms_keep_mask or not hasattr(self.track_pool, "device_state"):
+            return False
+        n = 0
+        for b in boxlists:
+            if b is None:
+                continue
+            if not b.bbox.is_cuda:
+                return False
+            n += len(b)
+        return 0 < n <= ops.track_solve_max_boxes()
+
+    @staticmethod
+    def _segment(b):
+        if b is None or len(b) == 0:
+            return None
+        bx = b.convert("xyxy").bbox
+        sc, ids = b.get_field("scores"), b.get_field("ids")
+        lab = b.get_field("labels") if b.has_field("labels") else None
+        return (bx if bx.is_contiguous() else bx.contiguous(), sc, ids, lab)
+
+    @torch.no_grad()
+    def solve(self, detections, tracks=None, track_score_bias=0.0):
+        """One frame on the device-resident pool: ``detections`` (+ the boxes the tracker propagated, un-concatenated)
+        -> output BoxList.  ONE kernel launch, ONE host synchronisation (the record).  The result carries
+        ``host_ids`` (numpy) and ``active_rows`` (boxes / ids / labels / scores of the rows whose id is active now)
+        so that ``TrackHead`` builds the next track memory without touching the device again."""
+        pool = self.track_pool
+        ref = detections if detections is not None and len(detections) else tracks
+        dev = ref.bbox.device
+        fbuf, ibuf, rec, M = ops.track_solve(
+            self._segment(detections), self._segment(tracks), float(track_score_bias),
+            (float(self.track_thresh), float(self.start_thresh), float(self.resume_track_thresh)),
+            float(self.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY)
+        K, A = int(rec[0]), int(rec[1])
+        pool._mirror(rec, M)
+        ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
+        oi, ol, ai, al = ibuf.split((M, M, M, M))
+        out = ref.__class__(ob.view(M, 4)[:K], ref.size, mode="xyxy")
+        if ref.mode != "xyxy":
+            out = out.convert(ref.mode)
+        out.add_field("ids", oi[:K])
+        out.add_field("scores", osc[:K])
+        out.add_field("labels", ol[:K])
+        out.host_ids = rec[8 + M:8 + M + K].astype(np.int64)
+        act = ref.__class__(ab.view(M, 4)[:A], ref.size, mode="xyxy")
+        act.add_field("ids", ai[:A])
+        act.add_field("scores", asc[:A])
+        act.add_field("labels", al[:A])
+        act.host_ids = rec[8 + 2 * M:8 + 2 * M + A].tolist()
+        out.active_rows = act
+        return out
+
     @torch.no_grad()
     def forward(self, detection):
         assert len(detection) == 1                        # :50
         detection = detection[0]
         if len(detection) == 0:
             return [detection]
+        if self._device_path(detection):
+            return [self.solve(detection)]
         pool = self.track_pool
         all_ids = detection.get_field("ids")
         all_scores = detection.get_field("scores")

@@ -60,7 +60,8 @@ class TrackHead(torch.nn.Module):
         cache = self.track_pool.get_cache()
         if not cache or track_memory is None:
             return track_memory
-        dormant_caches = [cache[i] for i in self.track_pool.get_dormant_ids() if i in cache]
+        dormant = [i for i in self.track_pool.get_dormant_ids() if i in cache]
+        dormant_caches = [cache[i] for i in dormant]
         if not dormant_caches:
             return track_memory
         cached_features = [x[0][None, ...] for x in dormant_caches]
@@ -69,11 +70,17 @@ class TrackHead(torch.nn.Module):
         features = torch.cat(buffer_feat + cached_features)
         sr = cat_boxlist(list(track_memory[1]) + [x[1] for x in dormant_caches])
         boxes = cat_boxlist(list(track_memory[2]) + [x[2] for x in dormant_caches])
+        head_ids = getattr(track_memory[2][0], "host_ids", None)
+        if head_ids is not None:                               # keep the ids on the host for update_cache
+            boxes.host_ids = list(head_ids) + dormant
         return features, [sr], [boxes]
 
     def _get_track_targets(self, target):                                          # track_head.py:100-110
         if len(target) == 0:
             return target
+        rows = getattr(target, "active_rows", None)            # left by the one-launch solver: already filtered
+        if rows is not None:
+            return rows
         active = self.track_pool.get_active_ids()
         ids = target.get_field("ids")
         host_ids = getattr(target, "host_ids", None)          # left by siammot_amd.solver.TrackSolver
@@ -100,6 +107,13 @@ class TrackingLoop(torch.nn.Module):
     @torch.no_grad()
     def forward(self, features, detections):
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38
+        fast = getattr(self.solver, "_device_path", None)
+        if fast is not None and self.refine_tracks is None and fast(detections, tracks[0] if tracks else None):
+            # one launch for merge + solver + pool + active rows: the propagated boxes stay a segment of their own
+            # (no concatenation), their +1 score band is applied inside the kernel
+            out = self.solver.solve(detections, tracks[0] if tracks else None, track_score_bias=1.0)
+            self.track_memory = self.track.get_track_memory(features, [out])
+            return out
         dets = [detections]
         if tracks is not None:                                                     # roi_heads.py:43-45
             if self.refine_tracks is not None:

@@ -169,3 +169,93 @@ def test_tracking_loop_with_the_hip_head_runs_and_stays_consistent():
         assert mem_ids == pool.get_active_ids() | (pool.get_dormant_ids() & set(pool.get_cache()))
         started = max(started, pool._max_id + 1)
     assert started >= 10
+
+
+@pytest.mark.gpu
+def test_one_launch_solver_replays_the_reference_tracking_sequence():
+    """The device-resident path (one kernel for merge + NMS + decisions + pool + active rows, un-concatenated
+    segments, +1 band applied in the kernel) through TrackingLoop on the sequence the reference's own TrackHead /
+    TrackSolver / TrackPool produced (tests/golden/tracking_sequence.npz).  Ids, scores and boxes are compared per
+    id: the kernel keeps the pool tables in its own order, so dormant rows may sit in another order in the memory
+    than the reference's Python-set iteration gives — the per-track content must be identical."""
+    import types
+    from fake_tracker import SEQ, FakeTracker, detections
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.track_head import TrackHead, TrackingLoop
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(os.path.dirname(GOLDEN), "tracking_sequence.npz"))
+    pool = TrackPool(max_dormant_frames=SEQ["max_dormant_frames"])
+    head = TrackHead(FakeTracker(SEQ["pad"]), types.SimpleNamespace(pad_pixels=SEQ["pad"]), pool).eval()
+    solver = TrackSolver(pool, *SEQ["thresholds"])
+    loop = TrackingLoop(head, solver).eval()
+    rs = np.random.RandomState(SEQ["seed"])
+    feats = (torch.zeros(1, device=dev),)
+    launches = []
+    import siammot_amd.ops as ops
+    real = ops.track_solve
+    ops.track_solve = lambda *a, **k: (launches.append(1), real(*a, **k))[1]
+    try:
+        for f in range(SEQ["frames"]):
+            res = loop(feats, detections(rs, f).to(dev))
+            ids = res.get_field("ids").cpu().numpy()
+            g_ids = gold["f%02d_ids" % f]
+            # detections keep their order; propagated tracks follow in memory order: compare as (id, score, box) sets
+            # for tracked rows and positionally for the detection rows in front
+            def rows(i, s, b):
+                return sorted((int(a), float(c), tuple(map(float, d))) for a, c, d in zip(i, s, b))
+            assert rows(ids, res.get_field("scores").cpu().numpy(), res.bbox.cpu().numpy()) == \
+                rows(g_ids, gold["f%02d_scores" % f], gold["f%02d_boxes" % f]), "frame %d" % f
+            mem = loop.track_memory
+            m_ids = mem[2][0].get_field("ids").cpu().numpy()
+            assert sorted(m_ids.tolist()) == sorted(gold["f%02d_mem_ids" % f].tolist()), "memory ids, frame %d" % f
+            got = dict(zip(m_ids.tolist(), mem[0].cpu().numpy().reshape(len(m_ids), -1).tolist()))
+            want = dict(zip(gold["f%02d_mem_ids" % f].tolist(), gold["f%02d_mem_feat" % f].tolist()))
+            assert got == want, "memory features, frame %d" % f
+            assert mem[2][0].host_ids is not None and list(mem[2][0].host_ids) == m_ids.tolist()
+    finally:
+        ops.track_solve = real
+    assert len(launches) == SEQ["frames"]                      # every frame took the one-launch path
+    assert pool._max_id > 20 and len(pool.get_active_ids()) > 5
+
+
+@pytest.mark.gpu
+def test_one_launch_solver_edge_cases():
+    """Empty segments, only tracks, ids resumed and suspended in one frame, host-side pool edits between frames
+    (the device copy is refreshed), more boxes than the kernel takes (falls back to the multi-kernel path)."""
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.structures import BoxList
+    import siammot_amd.ops as ops
+    dev = torch.device("cuda:0")
+
+    def bl(boxes, ids, scores):
+        b = BoxList(torch.tensor(boxes, dtype=torch.float32, device=dev).reshape(-1, 4), (1280, 704))
+        b.add_field("ids", torch.tensor(ids, dtype=torch.int64, device=dev))
+        b.add_field("scores", torch.tensor(scores, dtype=torch.float32, device=dev))
+        b.add_field("labels", torch.ones(len(ids), dtype=torch.int64, device=dev))
+        return b
+    pool = TrackPool(max_dormant_frames=3)
+    solver = TrackSolver(pool, 0.4, 0.6, 0.4)
+    out = solver([bl([[0, 0, 50, 50], [200, 200, 260, 260], [400, 100, 450, 190]], [-1, -1, -1], [0.9, 0.7, 0.3])])[0]
+    assert out.get_field("ids").tolist() == [0, 1, -1] and pool.get_active_ids() == {0, 1} and pool._frame_idx == 1
+    assert out.active_rows.get_field("ids").tolist() == [0, 1] and out.host_ids.tolist() == [0, 1, -1]
+    # only propagated tracks (no detections): track 1 falls below the track threshold -> dormant
+    trk = bl([[2, 2, 52, 52], [202, 202, 262, 262]], [0, 1], [0.8, 0.2])
+    out = solver.solve(None, trk, track_score_bias=1.0)
+    assert out.get_field("ids").tolist() == [0, -1] and pool.get_active_ids() == {0} and pool.get_dormant_ids() == {1}
+    assert torch.allclose(out.get_field("scores"), torch.tensor([0.8, 0.2], device=dev))
+    assert trk.get_field("scores").tolist() == pytest.approx([2.8, 1.2])          # banded in place (+1 bias, +1 active)
+    # host-side edit between frames: the mirror is authoritative until the next kernel call uploads it
+    pool.resume_track(1)
+    out = solver([bl([[0, 0, 50, 50], [200, 200, 260, 260]], [0, 1], [1.9, 1.9])])[0]
+    assert out.get_field("ids").tolist() == [0, 1] and pool.get_active_ids() == {0, 1}
+    # an overlapping, higher-scoring detection removes track 0 in NMS -> suspended; the detection starts id 2
+    out = solver([bl([[0, 0, 50, 50], [1, 1, 51, 51], [200, 200, 260, 260]], [0, -1, 1], [1.5, 0.95, 1.9])])[0]
+    assert pool.get_active_ids() == {0, 1} and out.get_field("ids").tolist() == [0, 1]      # active band wins NMS
+    # too many boxes for the single-workgroup kernel: the multi-kernel path takes over, same semantics
+    n = ops.track_solve_max_boxes() + 10
+    rs = np.random.RandomState(0)
+    xy = rs.uniform(0, 1000, (n, 2))
+    big = bl(np.concatenate((xy, xy + 20), 1).tolist(), [-1] * n, rs.uniform(0.1, 0.5, n).tolist())
+    assert not solver._device_path(big)
+    out = solver([big])[0]
+    assert len(out) > 0 and (out.get_field("ids") < 0).all()
