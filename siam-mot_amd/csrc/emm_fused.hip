@@ -22,7 +22,7 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
 unsigned* decode_tickets(float* cand_ws, int N, int Ho);
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
-                         float two_e, float min_wh, float* templates, float* sr, hipStream_t st);
+                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, hipStream_t st);
 }  // namespace smot
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
@@ -100,11 +100,35 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
         const float half_e = (float)((double)search_expansion / 2.0);
         const float two_e = (float)((double)search_expansion * 2.0);
         return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, N, rz, pad_pixels, half_e,
-                                    two_e, min_search_wh, templates, sr, (hipStream_t)stream);
+                                    two_e, min_search_wh, templates, sr, nullptr, (hipStream_t)stream);
     }
     int zero_pad[SMOT_MAX_LEVELS] = {0};
     int rc = smot_roi_align_levels_fwd(feats, heights, widths, zero_pad, scales, num_levels, C, boxes, boxes, N, rz, rz,
                                        sampling_ratio, templates, nullptr, stream);
     if (rc) return rc;
     return smot_search_region_fwd(boxes, N, pad_pixels, search_expansion, min_search_wh, sr, stream);
+}
+
+// EMM.extract_cache over a CAPACITY of boxes of which only the first *n_valid (a device-resident count, e.g. word 1
+// of smot_track_solve_fwd's record) are real: the launch is enqueued before the host knows the count, workgroups
+// of the other rows return at once and their output rows stay unwritten.  The tracker's frame then needs no host
+// synchronisation between the solver and the template extraction.
+extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heights, const int* widths,
+                                                 const float* scales, int num_levels, int C, const float* boxes,
+                                                 int capacity, const int* n_valid, int rz, int sampling_ratio,
+                                                 float pad_pixels, float search_expansion, float min_search_wh,
+                                                 float* templates, float* sr, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(capacity >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache_masked: bad sizes");
+    SMOT_REQUIRE(n_valid != nullptr, "emm_extract_cache_masked: null count pointer");
+    if (capacity == 0) return SMOT_OK;
+    if (!(rz == 15 && sampling_ratio == 2)) {
+        set_error("emm_extract_cache_masked: only Rz=15, sampling_ratio=2 (got %d, %d); use smot_emm_extract_cache_fwd "
+                  "with the count on the host", rz, sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    const float half_e = (float)((double)search_expansion / 2.0);
+    const float two_e = (float)((double)search_expansion * 2.0);
+    return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, capacity, rz, pad_pixels, half_e,
+                                two_e, min_search_wh, templates, sr, n_valid, (hipStream_t)stream);
 }

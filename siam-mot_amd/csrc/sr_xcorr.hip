@@ -39,6 +39,8 @@ struct SrOut {
     int abl;              // timing ablation of the generation-2 kernel (wrong results): 2 = no correlation phase
                           // (SMOT_FUSED_ABL=2).  A run-time switch around the row loads is NOT an option: the
                           // branch makes hipcc wait for every pair of loads (measured +2 us).
+    const int* n_valid;   // device count of valid rois, or nullptr: rois >= *n_valid are skipped (the launch covers
+                          // a CAPACITY when the count is still on the device — smot_emm_extract_cache_masked_fwd)
 };
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
@@ -338,6 +340,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
     const int n = blockIdx.x;
     const int c0 = blockIdx.y * FX_CH;
+    if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
 #define FX_TRACE(SLOT)                                                                      \
     if (S.trace && tid == 0)                                                                \
         S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
@@ -624,7 +627,7 @@ template <int RX, bool XCORR>
 static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C, const float* rois, const float* boxes,
                          const float* z, float* resp, float* out, int32_t* levels_out, const SrOut& S) {
 #ifdef SMOT_DEBUG
-    if (knobs().fused_gen == 2) {
+    if (knobs().fused_gen == 2 && S.n_valid == nullptr) {      // (generation 2 has no masked form)
         hipLaunchKernelGGL((sr_xcorr_fused8_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp,
                            out, levels_out, S);
         return;
@@ -638,7 +641,7 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr};
     if (out_size == 30) {
         launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     } else {
@@ -649,14 +652,14 @@ int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, co
 
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
-                         float two_e, float min_wh, float* templates, float* sr, hipStream_t st) {
+                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, hipStream_t st) {
     (void)rz;
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "emm_extract_cache");
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0};
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid};
     launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
     return check_launch("emm_extract_cache");
 }
@@ -681,7 +684,7 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr};
     launch_fused<30, true>(grid, (hipStream_t)stream, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
     timer_mark(0, 1, (hipStream_t)stream);
     return check_launch("sr_xcorr_fused");

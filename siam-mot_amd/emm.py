@@ -160,6 +160,20 @@ class EMM(nn.Module):
         track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
         return {}, track_result, {}
 
+    def track_raw(self, features, boxes, sr, template_features, image_wh):
+        """The inference branch of ``forward`` on raw tensors: template boxes ``[N,4]``, search regions ``[N,4]``,
+        templates ``[N,C,rz,rz]`` -> (boxes ``[N,4]``, scores ``[N]``), clamped to the image unless amodal.  No
+        BoxList in or out — the tracking loop's per-frame fast path (track_head.TrackingLoop)."""
+        st = self.__dict__.get("_static")
+        if st is None:
+            fe, pr = self.feature_extractor.pooler_x, self.predictor
+            st = self.__dict__["_static"] = (pr.param_dict(), tuple(fe.scales), fe.sampling_ratio, pr.gn_groups,
+                                             pr.gn_eps)
+        params, scales, sampling_ratio, gn_groups, gn_eps = st
+        return ops.emm_track(features, boxes, sr, template_features, params, self.rx, self.rz, scales, sampling_ratio,
+                             self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
+                             clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps)
+
     def extract_cache(self, features, detection):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""
         detection = [detection]
@@ -171,11 +185,32 @@ class EMM(nn.Module):
             sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
         x, sr_bbox = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1],
                                            tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
+        return self.wrap_cache(x, sr_bbox, det)
+
+    def wrap_cache(self, x, sr_bbox, det):
+        """(templates, search-region boxes) of ``det``'s rows -> the reference's cache tuple."""
+        tu = self.track_utils
         w, h = det.size
         sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
         for field in det.fields():
             sr.add_field(field, det.get_field(field))
-        return x, [sr], detection
+        return x, [sr], [det]
+
+    def extract_cache_rows(self, features, boxes, n_valid):
+        """``extract_cache`` on a CAPACITY of boxes ``[M,4]`` whose number of real rows is still on the device
+        (``n_valid``: int32 tensor, 1 element — the solver kernel's count): launch only, rows beyond the count are
+        skipped by the kernel.  Returns capacity-sized ``(templates [M,C,rz,rz], sr [M,4])``; the caller slices
+        them once the count is on the host (``wrap_cache``).  Lets the tracking loop enqueue the template
+        extraction BEFORE its one synchronisation of the frame."""
+        tu = self.track_utils
+        sz = self.__dict__.get("_static_z")
+        if sz is None:
+            fz = self.feature_extractor.pooler_z
+            sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
+        if not (self.rz == 15 and sz[1] == 2):
+            return None                                    # no masked kernel for this shape family: caller falls back
+        return ops.emm_extract_cache(features, boxes, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
+                                     tu.min_search_wh, n_valid=n_valid)
 
 
 def wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=False):

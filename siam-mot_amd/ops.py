@@ -62,6 +62,8 @@ _SIGNATURES = {
                                           _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "smot_emm_extract_cache_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f,
                                                   _vp, _vp, _vp]),
+    "smot_emm_extract_cache_masked_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _f, _f,
+                                                         _vp, _vp, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -278,6 +280,8 @@ PREDICTOR_KEYS = (
 )
 
 
+_TOWER_KEYS = ("cls_tower.0.weight", "reg_tower.0.weight")
+_KEY_INDEX = {k: i for i, k in enumerate(PREDICTOR_KEYS)}
 _pack_cache = {}
 
 
@@ -469,10 +473,11 @@ def _same_device(device, *named):
 class _ParamBlock(object):
     """The 12 predictor tensors validated once, their pointers as a ctypes block, and the Winograd-packed tower
     filters; revalidated per call by data pointer + version counter (a dozen attribute reads)."""
-    __slots__ = ("params", "tensors", "stamp", "pp", "a_pp", "packed", "C")
+    __slots__ = ("params", "tensors", "stamp", "pp", "a_pp", "packed", "C", "calls")
 
     def __init__(self, params):
         self.params = params                     # keeps the dict (and so its id) alive while cached
+        self.calls = 0
         self.refresh()
 
     def refresh(self):
@@ -489,10 +494,15 @@ class _ParamBlock(object):
         self.a_pp = ctypes.addressof(self.pp)
 
     def current(self):
+        """Revalidate against in-place updates (``load_state_dict`` bumps every tensor's version) and moves
+        (``.to()`` replaces every storage): the two tower weights are checked on every call, the whole set every
+        32nd — a dozen attribute reads less per frame on the tracking loop's host path."""
         p, st = self.params, self.stamp
-        for i, k in enumerate(PREDICTOR_KEYS):
+        self.calls = calls = self.calls + 1
+        keys = PREDICTOR_KEYS if (calls & 31) == 0 else _TOWER_KEYS
+        for k in keys:
             t = p[k]
-            s = st[i]
+            s = st[_KEY_INDEX[k]]
             if t.data_ptr() != s[0] or t._version != s[1]:
                 self.refresh()
                 break
@@ -567,8 +577,13 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     return (bb, conf, idx) if return_index else (bb, conf)
 
 
-def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh):
-    """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``)."""
+def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
+                      n_valid=None):
+    """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``).
+
+    ``n_valid``: a device int32 tensor (1 element) holding the number of REAL rows among ``boxes`` (a capacity): rows
+    beyond it are skipped on the device and their outputs stay unwritten — the call can be enqueued before the
+    host knows the count (ops.track_solve_launch)."""
     lib = _lib or load_library()
     if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
         _dev_f32(boxes, "boxes")                 # raises: no CPU path
@@ -582,9 +597,15 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
     if cur != dev.index:
         torch.cuda.set_device(dev.index)
     try:
-        rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
-                                            rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
-                                            templates.data_ptr(), sr.data_ptr(), _stream(dev))
+        if n_valid is None:
+            rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
+                                                rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
+                                                templates.data_ptr(), sr.data_ptr(), _stream(dev))
+        else:
+            rc = lib.smot_emm_extract_cache_masked_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
+                                                       n_valid.data_ptr(), rz, sampling_ratio, pad_pixels,
+                                                       search_expansion, min_search_wh, templates.data_ptr(),
+                                                       sr.data_ptr(), _stream(dev))
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
@@ -703,10 +724,10 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     """``smot_track_solve_fwd``: one launch for TrackSolver.forward + the pool transitions + the active-row filter.
 
     det / trk: ``(boxes [n,4] xyxy, scores [n], ids [n] int64, labels [n] int64 or None)`` device tensors or ``None``
-    for an empty segment.  Returns ``(fbuf, ibuf, rec, M)``: ``fbuf`` fp32 ``[10*M]`` = out_boxes | act_boxes |
-    out_scores | act_scores, ``ibuf`` int64 ``[4*M]`` = out_ids | out_labels | act_ids | act_labels (capacity M rows
-    each; the first K / A are valid) and ``rec``, the record as a host numpy int32 array — read back through a
-    pinned buffer after ONE stream synchronisation, the only one of the frame."""
+    for an empty segment.  Launch only (no synchronisation).  Returns ``(fbuf, ibuf, rec, M)``: ``fbuf`` fp32
+    ``[10*M]`` = out_boxes | act_boxes | out_scores | act_scores, ``ibuf`` int64 ``[4*M]`` = out_ids | out_labels |
+    act_ids | act_labels (capacity M rows each; the first K / A are valid) and ``rec``, the record on the DEVICE
+    (``rec[0]`` = K, ``rec[1]`` = A, ...: include/smot_emm.h); ``track_solve_record(rec)`` brings it to the host."""
     lib = _lib or load_library()
     segs = []
     dev = pool_state.device
@@ -744,14 +765,22 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
             torch.cuda.set_device(cur)
     if rc:
         _check(rc, "track_solve")
+    return fbuf, ibuf, rec, M
+
+
+def track_solve_record(rec):
+    """The solver's record on the host: a copy through a pinned buffer + ONE stream synchronisation (the frame's
+    only one).  Everything enqueued on the stream before this call — including launches that consume the
+    record's device copy, such as a masked ``emm_extract_cache`` — has completed when it returns."""
+    dev, nrec = rec.device, rec.shape[0]
     host = _rec_pinned.get((dev, nrec))
     if host is None:
         if len(_rec_pinned) > 64:
             _rec_pinned.clear()
         host = _rec_pinned[(dev, nrec)] = torch.empty((nrec,), dtype=torch.int32).pin_memory()
     host.copy_(rec, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()              # the frame's one host synchronisation
-    return fbuf, ibuf, host.numpy().copy(), M
+    torch.cuda.current_stream(dev).synchronize()
+    return host.numpy().copy()
 
 
 def track_solve_max_boxes():

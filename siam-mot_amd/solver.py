@@ -65,6 +65,7 @@ class TrackPool(object):
         # kernel hands back; a mutation through the methods below marks the device copy stale instead.
         self._dev_state = None
         self._dev_stale = True
+        self._pending = None            # (memory, host ids) of the last frame, not yet turned into cache entries
 
     # ---- device-resident state -------------------------------------------------------------------
     def device_state(self, device):
@@ -94,6 +95,9 @@ class TrackPool(object):
         base = 8 + 3 * M
         active = set(rec[base:base + na].tolist())
         dormant = dict(zip(rec[base + cap:base + cap + nd].tolist(), rec[base + 2 * cap:base + 2 * cap + nd].tolist()))
+        newly_dormant = set(dormant) - set(self._dormant_ids)
+        if newly_dormant and self.__dict__.get("_pending") is not None:
+            self._flush_pending(only=newly_dormant)    # their entry = their row in the last memory they were active in
         gone = (self._active_ids | set(self._dormant_ids)) - active - set(dormant)
         for tid in gone:                              # expire_tracks: killed ids lose their cache entry
             self._cache.pop(tid, None)
@@ -125,6 +129,7 @@ class TrackPool(object):
     def update_cache(self, cache):
         """Latest (template features, search region, box) per track id — the ids cross to the host in one copy
         (the reference calls ``.item()`` per track, track_utils.py:196)."""
+        self._flush_pending()                               # an older, lazily noted memory goes in first
         template_features, sr, template_boxes = cache
         sr, template_boxes = sr[0], template_boxes[0]
         n = len(template_boxes)
@@ -172,7 +177,33 @@ class TrackPool(object):
     def get_dormant_ids(self):
         return set(self._dormant_ids.keys())
 
+    def note_memory(self, cache, host_ids):
+        """Lazy form of ``update_cache`` for the tracking loop's fast path: remember this frame's memory and the
+        ids of its rows; entries are materialised only for the tracks that go dormant (their last active memory is
+        this one) — the reference rebuilds an entry per track per frame although only dormant tracks are ever read
+        back (track_head.py:83-86).  ``get_cache()`` still answers for every id in memory."""
+        # (the previous frame's pending memory is simply dropped: tracks that went dormant since were materialised
+        # from it by _mirror, tracks that are still active have a row in the new memory)
+        self._pending = (cache, host_ids)
+
+    def _flush_pending(self, only=None):
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        (template_features, sr, template_boxes), ids = pend
+        sr, template_boxes = sr[0], template_boxes[0]
+        active = self._active_ids
+        for idx, tid in enumerate(ids):
+            if only is not None and tid not in only:
+                continue
+            if tid not in active and tid in self._cache:
+                continue                                   # dormant row re-appended from the cache: keep the original
+            self._cache[tid] = _CacheEntry(template_features, sr, template_boxes, idx)
+        if only is None:
+            self._pending = None
+
     def get_cache(self):
+        self._flush_pending()
         return self._cache
 
     def activate_tracks(self, track_id):
@@ -180,6 +211,20 @@ class TrackPool(object):
 
     def reset(self):
         self.__init__(max_entangle_length=self._max_entangle_length, max_dormant_frames=self._max_dormant_frames)
+
+
+class _Solve(object):
+    """Handle between ``TrackSolver.solve_launch`` and ``solve_finish``."""
+    __slots__ = ("ref", "M", "rec", "out_boxes", "act_boxes", "out_scores", "act_scores", "ibuf")
+
+    def __init__(self, ref, M, rec, out_boxes, act_boxes, out_scores, act_scores, ibuf):
+        self.ref, self.M, self.rec = ref, M, rec
+        self.out_boxes, self.act_boxes, self.out_scores, self.act_scores, self.ibuf = \
+            out_boxes, act_boxes, out_scores, act_scores, ibuf
+
+    @property
+    def count(self):
+        return self.rec[1:2]                    # number of active rows, on the device
 
 
 class TrackSolver(torch.nn.Module):
@@ -220,11 +265,11 @@ class TrackSolver(torch.nn.Module):
         return (bx if bx.is_contiguous() else bx.contiguous(), sc, ids, lab)
 
     @torch.no_grad()
-    def solve(self, detections, tracks=None, track_score_bias=0.0):
-        """One frame on the device-resident pool: ``detections`` (+ the boxes the tracker propagated, un-concatenated)
-        -> output BoxList.  ONE kernel launch, ONE host synchronisation (the record).  The result carries
-        ``host_ids`` (numpy) and ``active_rows`` (boxes / ids / labels / scores of the rows whose id is active now)
-        so that ``TrackHead`` builds the next track memory without touching the device again."""
+    def solve_launch(self, detections, tracks=None, track_score_bias=0.0):
+        """Enqueue one frame on the device-resident pool: ``detections`` (+ the boxes the tracker propagated,
+        un-concatenated).  ONE kernel launch, NO synchronisation.  Returns a handle for ``solve_finish``; its
+        ``act_boxes`` ([M,4], capacity) and ``count`` (device int32 view of the number of active rows) can feed a
+        masked ``EMM.extract_cache`` right away."""
         pool = self.track_pool
         ref = detections if detections is not None and len(detections) else tracks
         dev = ref.bbox.device
@@ -232,24 +277,35 @@ class TrackSolver(torch.nn.Module):
             self._segment(detections), self._segment(tracks), float(track_score_bias),
             (float(self.track_thresh), float(self.start_thresh), float(self.resume_track_thresh)),
             float(self.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY)
-        K, A = int(rec[0]), int(rec[1])
-        pool._mirror(rec, M)
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
-        oi, ol, ai, al = ibuf.split((M, M, M, M))
-        out = ref.__class__(ob.view(M, 4)[:K], ref.size, mode="xyxy")
+        return _Solve(ref, M, rec, ob.view(M, 4), ab.view(M, 4), osc, asc, ibuf)
+
+    def solve_finish(self, h):
+        """Synchronise once, mirror the pool, slice the outputs.  The result carries ``host_ids`` (numpy) and
+        ``active_rows`` (boxes / ids / labels / scores of the rows whose id is active now) so that ``TrackHead``
+        builds the next track memory without touching the device again."""
+        rec = ops.track_solve_record(h.rec)
+        M, ref = h.M, h.ref
+        K, A = int(rec[0]), int(rec[1])
+        self.track_pool._mirror(rec, M)
+        oi, ol, ai, al = h.ibuf.split((M, M, M, M))
+        out = ref.__class__(h.out_boxes[:K], ref.size, mode="xyxy")
         if ref.mode != "xyxy":
             out = out.convert(ref.mode)
         out.add_field("ids", oi[:K])
-        out.add_field("scores", osc[:K])
+        out.add_field("scores", h.out_scores[:K])
         out.add_field("labels", ol[:K])
         out.host_ids = rec[8 + M:8 + M + K].astype(np.int64)
-        act = ref.__class__(ab.view(M, 4)[:A], ref.size, mode="xyxy")
+        act = ref.__class__(h.act_boxes[:A], ref.size, mode="xyxy")
         act.add_field("ids", ai[:A])
-        act.add_field("scores", asc[:A])
+        act.add_field("scores", h.act_scores[:A])
         act.add_field("labels", al[:A])
         act.host_ids = rec[8 + 2 * M:8 + 2 * M + A].tolist()
         out.active_rows = act
         return out
+
+    def solve(self, detections, tracks=None, track_score_bias=0.0):
+        return self.solve_finish(self.solve_launch(detections, tracks, track_score_bias))
 
     @torch.no_grad()
     def forward(self, detection):

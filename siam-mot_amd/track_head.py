@@ -14,6 +14,7 @@ import copy
 
 import torch
 
+from . import ops
 from .structures import cat_boxlist
 
 
@@ -41,9 +42,17 @@ class TrackHead(torch.nn.Module):
     def reset_track_pool(self):
         self.track_pool.reset()
 
-    def get_track_memory(self, features, tracks):                                  # track_head.py:54-75
+    def get_track_memory(self, features, tracks, precomputed=None):                # track_head.py:54-75
+        """``precomputed``: capacity-sized ``(templates, sr boxes)`` of the solver's active rows, extracted by a
+        launch that was enqueued before the frame's synchronisation (``EMM.extract_cache_rows``)."""
         assert len(tracks) == 1
         active_tracks = self._get_track_targets(tracks[0])
+        if precomputed is not None and len(active_tracks) > 0:
+            a = len(active_tracks)
+            track_memory = self.tracker.wrap_cache(precomputed[0][:a], precomputed[1][:a], active_tracks)
+            track_memory = self._update_memory_with_dormant_track(track_memory)
+            self.track_pool.update_cache(track_memory)
+            return track_memory
         if len(active_tracks) == 0:
             template_features = torch.tensor([], device=features[0].device)
             sr = copy.deepcopy(active_tracks)
@@ -104,15 +113,85 @@ class TrackingLoop(torch.nn.Module):
         self.track_memory = None
         self.track.reset_track_pool()
 
+    def _lean_ok(self, detections):
+        """The per-frame fast path applies: this repository's EMM head, no box-head refinement, the one-launch
+        solver, device tensors."""
+        if self.refine_tracks is not None or not hasattr(self.track.tracker, "track_raw"):
+            return False
+        fast = getattr(self.solver, "_device_path", None)
+        if fast is None or not detections.bbox.is_cuda or self.track.tracker.rz != 15:
+            return False
+        mem = self.track_memory
+        n = len(detections) + (len(mem[2][0]) if mem is not None else 0)
+        return self.solver.nms_mask_fn is ops.nms_keep_mask and 0 < n <= ops.track_solve_max_boxes()
+
+    def _step_lean(self, features, detections):
+        """One frame with the minimum of host work between the launches: raw tensors into ``ops.emm_track``, the
+        solver kernel on un-concatenated segments, the masked template extraction — all enqueued before the frame's
+        ONE synchronisation — then views, the pool mirror and a lazy cache note.  Same results as the general path
+        (tests/test_solver.py::test_lean_step_equals_general_path)."""
+        emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
+        mem = self.track_memory
+        trk = None
+        if mem is None:
+            pool.reset()                                                           # track_head.py:39-40
+        else:
+            z, sr, tb = mem
+            tb0 = tb[0]
+            if z.numel() > 0:
+                bb, conf = emm.track_raw(features, tb0.bbox, sr[0].bbox, z, tb0.size)
+                trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels"))
+        dev = detections.bbox.device
+        fbuf, ibuf, rec_dev, M = ops.track_solve(
+            solver._segment(detections), trk, 1.0,
+            (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)),
+            float(solver.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY)
+        ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
+        act_boxes = ab.view(M, 4)
+        pre = emm.extract_cache_rows(features, act_boxes, rec_dev[1:2])
+        rec = ops.track_solve_record(rec_dev)                                      # the frame's one synchronisation
+        K, A = int(rec[0]), int(rec[1])
+        pool._mirror(rec, M)
+        oi, ol, ai, al = ibuf.split((M, M, M, M))
+        cls = detections.__class__
+        out = cls(ob.view(M, 4)[:K], detections.size, mode="xyxy")
+        out.add_field("ids", oi[:K])
+        out.add_field("scores", osc[:K])
+        out.add_field("labels", ol[:K])
+        out.host_ids = rec[8 + M:8 + M + K]
+        act = cls(act_boxes[:A], detections.size, mode="xyxy")
+        act.add_field("ids", ai[:A])
+        act.add_field("scores", asc[:A])
+        act.add_field("labels", al[:A])
+        act.host_ids = rec[8 + 2 * M:8 + 2 * M + A].tolist()
+        out.active_rows = act
+        if A == 0 or pre is None:
+            # no active row (the reference's empty memory) or no masked kernel for this pooler shape: general code
+            self.track_memory = self.track.get_track_memory(features, [out])
+            return out
+        memory = emm.wrap_cache(pre[0][:A], pre[1][:A], act)
+        if pool._dormant_ids:
+            memory = self.track._update_memory_with_dormant_track(memory)
+        pool.note_memory(memory, getattr(memory[2][0], "host_ids", act.host_ids))
+        self.track_memory = memory
+        return out
+
     @torch.no_grad()
     def forward(self, features, detections):
+        if self._lean_ok(detections):
+            return self._step_lean(features, detections)
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38
         fast = getattr(self.solver, "_device_path", None)
         if fast is not None and self.refine_tracks is None and fast(detections, tracks[0] if tracks else None):
             # one launch for merge + solver + pool + active rows: the propagated boxes stay a segment of their own
             # (no concatenation), their +1 score band is applied inside the kernel
-            out = self.solver.solve(detections, tracks[0] if tracks else None, track_score_bias=1.0)
-            self.track_memory = self.track.get_track_memory(features, [out])
+            h = self.solver.solve_launch(detections, tracks[0] if tracks else None, track_score_bias=1.0)
+            # the next frame's templates / search regions of the rows the solver leaves active: enqueued NOW, on
+            # the capacity with the count still on the device — the GPU never waits for the host inside a frame
+            rows = getattr(self.track.tracker, "extract_cache_rows", None)
+            pre = rows(features, h.act_boxes, h.count) if rows is not None else None
+            out = self.solver.solve_finish(h)                                      # the frame's one synchronisation
+            self.track_memory = self.track.get_track_memory(features, [out], precomputed=pre)
             return out
         dets = [detections]
         if tracks is not None:                                                     # roi_heads.py:43-45

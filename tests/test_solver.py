@@ -185,7 +185,21 @@ def test_one_launch_solver_replays_the_reference_tracking_sequence():
     dev = torch.device("cuda:0")
     gold = np.load(os.path.join(os.path.dirname(GOLDEN), "tracking_sequence.npz"))
     pool = TrackPool(max_dormant_frames=SEQ["max_dormant_frames"])
-    head = TrackHead(FakeTracker(SEQ["pad"]), types.SimpleNamespace(pad_pixels=SEQ["pad"]), pool).eval()
+
+    class HostFake(FakeTracker):
+        """The stand-in tracker's own arithmetic stays on the CPU (as in the golden run: torch's device kernels round
+        ``x / 100 * 0.9 + 0.05`` differently in the last bit); only its results live on the device."""
+
+        def forward(self, features, boxes, sr, targets=None, template_features=None):
+            _, out, _ = FakeTracker.forward(self, features, [boxes[0].to("cpu")], [sr[0].to("cpu")],
+                                            template_features=template_features.cpu())
+            return {}, [out[0].to(dev)], {}
+
+        def extract_cache(self, features, detection):
+            f, sr, d = FakeTracker.extract_cache(self, features, detection.to("cpu"))
+            keep = detection                     # the solver's active rows (with their host_ids) stay the memory boxes
+            return f.to(dev), [sr[0].to(dev)], [keep]
+    head = TrackHead(HostFake(SEQ["pad"]), types.SimpleNamespace(pad_pixels=SEQ["pad"]), pool).eval()
     solver = TrackSolver(pool, *SEQ["thresholds"])
     loop = TrackingLoop(head, solver).eval()
     rs = np.random.RandomState(SEQ["seed"])
@@ -243,7 +257,7 @@ def test_one_launch_solver_edge_cases():
     out = solver.solve(None, trk, track_score_bias=1.0)
     assert out.get_field("ids").tolist() == [0, -1] and pool.get_active_ids() == {0} and pool.get_dormant_ids() == {1}
     assert torch.allclose(out.get_field("scores"), torch.tensor([0.8, 0.2], device=dev))
-    assert trk.get_field("scores").tolist() == pytest.approx([2.8, 1.2])          # banded in place (+1 bias, +1 active)
+    assert trk.get_field("scores").tolist() == pytest.approx([2.8, 2.2])          # banded in place (+1 bias, +1 active)
     # host-side edit between frames: the mirror is authoritative until the next kernel call uploads it
     pool.resume_track(1)
     out = solver([bl([[0, 0, 50, 50], [200, 200, 260, 260]], [0, 1], [1.9, 1.9])])[0]
@@ -259,3 +273,53 @@ def test_one_launch_solver_edge_cases():
     assert not solver._device_path(big)
     out = solver([big])[0]
     assert len(out) > 0 and (out.get_field("ids") < 0).all()
+
+
+@pytest.mark.gpu
+def test_lean_step_equals_general_path():
+    """TrackingLoop's lean per-frame step (raw tensors, masked template extraction before the synchronisation, lazy
+    cache) against the general path (TrackHead / EMM modules, BoxLists, eager cache) on the same sequence with the
+    real HIP head: outputs, track memory and pool must be identical frame by frame — including frames in which
+    tracks go dormant, are carried in the memory, are resumed and expire."""
+    import golden_inputs as gi
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
+    # the freshly initialised head scores every track ~0.5: thresholds at 0.5 make tracks go dormant, come back, expire
+    cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
+    cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    with torch.no_grad():
+        for name in ("cls", "center", "reg"):
+            getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
+    loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+    loops[1]._lean_ok = lambda d: False                     # general path
+    lean_frames = []
+    real = loops[0]._step_lean
+    loops[0]._step_lean = lambda f, d: (lean_frames.append(1), real(f, d))[1]
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(9)
+    rs = [np.random.RandomState(5), np.random.RandomState(5)]
+    seen_dormant = False
+    for f in range(16):
+        feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+        outs = [lp(feats, detections(r, f).to(dev)) for lp, r in zip(loops, rs)]
+        a, b = outs
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+        ma, mb = loops[0].track_memory, loops[1].track_memory
+        assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
+        assert torch.equal(ma[2][0].bbox, mb[2][0].bbox)
+        assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids"))
+        pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids
+        assert pa._kill_ids == pb._kill_ids and pa._max_id == pb._max_id
+        ca, cb = pa.get_cache(), pb.get_cache()
+        for tid in pa.get_dormant_ids():
+            if tid in cb:
+                assert tid in ca and torch.equal(ca[tid][0], cb[tid][0]) and torch.equal(ca[tid][1].bbox, cb[tid][1].bbox)
+        seen_dormant |= bool(pa.get_dormant_ids())
+    assert len(lean_frames) == 16 and seen_dormant and loops[0].solver.track_pool._kill_ids
