@@ -150,6 +150,7 @@ constexpr int DEC_MAX_COLS = 4;   // output columns per lane: G <= 1024
 constexpr float DEC_TOL = 4e-6f;  // |fast score - exact score| bound used to nominate cells (scores are <= 1 in
                                   // magnitude: (1-sigma)*p*pen + sigma*window); measured gap: a few 1e-7
 constexpr int DEC_REC = 5;        // u64 words published per band: key, then seven floats (+ pad)
+constexpr int DEC_NOM = 64;       // nominee list per band (more: the whole band is re-scored exactly)
 
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 typedef __attribute__((address_space(1))) unsigned gu32_t;
@@ -165,6 +166,7 @@ struct FinalizeArgs {
     float* conf;
     long long* idx_out;
     unsigned* ticket;       // [N], zero at launch
+    long long* trace;       // phase trace (smot_debug_trace) or nullptr: 8 stamps per workgroup
     int rx, rz;
     float pad, clip_w, clip_h;
 };
@@ -178,6 +180,9 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
     __shared__ unsigned long long wbest[4 * SPLIT];
     __shared__ unsigned wflag;
+    __shared__ unsigned nom[DEC_NOM];     // flat indices of the cells nominated for exact re-scoring
+    __shared__ int nom_cnt;
+    if (threadIdx.x == 0) nom_cnt = 0;
     const int tcol = threadIdx.x & 255, part = threadIdx.x >> 8;
     __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
     __shared__ float dv[4][4][64];     // ranking planes {cls0-cls1, center, l+r, t+b} of the band's 4 source rows
@@ -185,6 +190,10 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
     const int Ho = D.Ho, up = D.up, G = D.G;
     const int nband = gridDim.y;
+#define DC_TRACE(SLOT)                                                                                          \
+    if (F.trace && threadIdx.x == 0)                                                                            \
+        F.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    DC_TRACE(0)
     if (L.logits != nullptr) {
         for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
             const int ch = e / (Ho * Ho);
@@ -235,6 +244,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         dv[3][k][col] = q[6 * hw] + q[4 * hw];
     }
     __syncthreads();
+    DC_TRACE(1)
     const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
     const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
     const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
@@ -283,6 +293,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
             best = (key > best) ? key : best;
         });
     }
+    DC_TRACE(2)
     unsigned long long wg = best;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -298,83 +309,89 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     // nomination threshold in key space: fast score >= best fast score - DEC_TOL (NaN best: only NaN cells)
     const unsigned thr = score_key(key_score((unsigned)(wg >> 32)) - DEC_TOL);
 
+    DC_TRACE(3)
     // ---- exact re-scoring of the nominated cells (the reference's rounding sequence) ----------------------------
-    float ev[7];                          // the seven interpolated logits of this lane's best exact cell
-    unsigned long long ebest = 0ull;
-    auto exact_cell = [&](int X, int Y) {
-        int bx, by;
-        float tx, ty, wx[4], wy[4];
-        cubic_src(X, D.inv_up, &bx, &tx);
-        cubic_src(Y, D.inv_up, &by, &ty);
-        cubic_coeffs(tx, wx);
-        cubic_coeffs(ty, wy);
-        int cols[4], rws[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
-            rws[k] = clampi(by - 1 + k, 0, Ho - 1);
-        }
-        // A rolled loop over the channels (a handful of lanes run this; unrolled, hipcc hoists all 112 LDS reads and
-        // the kernel needs 143 VGPRs — one workgroup per CU instead of two); the selects keep v[] in registers.
-        float v[7];
-#pragma unroll
-        for (int c = 0; c < 7; ++c) v[c] = 0.0f;
-#pragma unroll 1
-        for (int ch = 0; ch < 7; ++ch) {
-            float h[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* q = lg + ch * Ho * Ho + rws[k] * Ho;
-                h[k] = interp4(q[cols[0]], q[cols[1]], q[cols[2]], q[cols[3]], wx);
-            }
-            const float val = interp4(h[0], h[1], h[2], h[3], wy);
-#pragma unroll
-            for (int c = 0; c < 7; ++c) v[c] = (c == ch) ? val : v[c];
-        }
-        const float score = cell_score(v, box_w, box_h, mul_rn(hann[Y], hann[X]), D);
-        const unsigned long long key = make_key(score, (unsigned)(Y * G + X));
-        if (key > ebest) {
-            ebest = key;
-#pragma unroll
-            for (int ch = 0; ch < 7; ++ch) ev[ch] = v[ch];
-        }
-    };
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) ev[ch] = 0.0f;
+    // Nominees go on a workgroup list; every entry is evaluated by a whole WAVE: lane = (channel, source row) does
+    // one horizontal 4-tap, the four lanes of a channel are combined vertically, the seven channel values are
+    // broadcast and all lanes score the cell redundantly.  A lane evaluating its cell alone walked 112 dependent LDS
+    // reads and ~1,000 instructions at one-wave issue rate — up to 17 k cycles with the rest of the workgroup waiting
+    // at the barrier (profiles/r02_decode_trace.md); cooperatively it is a few hundred cycles per nominee.
     const bool have = best != 0ull;
     const bool nominee = have && (unsigned)(best >> 32) >= thr;
     const bool several = have && sk2 != 0u && sk2 >= thr;          // a second cell of this lane is in range too
     if (nominee) {
-        // One nominee (the common case): re-walk just that cell.  Several (rare): re-walk all of this lane's cells;
-        // the fast scores are recomputed bit for bit, every cell in range is re-scored exactly.
         const unsigned idx1 = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
-        const int Y1 = (int)(idx1 / (unsigned)G), X1 = (int)(idx1 - (unsigned)Y1 * (unsigned)G);
+        if (!several) {
+            const int p = atomicAdd(&nom_cnt, 1);
+            if (p < DEC_NOM) nom[p] = idx1;
+        } else {
+            // rare: re-walk this lane's cells (the fast scores are recomputed bit for bit), nominate every one in range
 #pragma unroll 1
-        for (int j = 0; j < DEC_MAX_COLS; ++j) {
-            const int X = tcol + 256 * j;
-            if (X >= G) break;
-            if (!several && X != X1) continue;
-            walk(X, several ? y0p : Y1, several ? y1p : Y1 + 1, [&](float s, int Y) {
-                if (score_key(s) >= thr) exact_cell(X, Y);
-            });
+            for (int j = 0; j < DEC_MAX_COLS; ++j) {
+                const int X = tcol + 256 * j;
+                if (X >= G) break;
+                walk(X, y0p, y1p, [&](float s, int Y) {
+                    if (score_key(s) >= thr) {
+                        const int p = atomicAdd(&nom_cnt, 1);
+                        if (p < DEC_NOM) nom[p] = (unsigned)(Y * G + X);
+                    }
+                });
+            }
         }
     }
-    unsigned long long we = ebest;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(we, m);
-        we = (o > we) ? o : we;
-    }
-    __syncthreads();                      // wbest is reused
-    if ((threadIdx.x & 63) == 0) wbest[wave] = we;
     __syncthreads();
-    we = wbest[0];
+    DC_TRACE(4)
+    float ev[7];                          // the seven interpolated logits of this wave's best exact cell (wave-uniform)
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) ev[ch] = 0.0f;
+    unsigned long long ebest = 0ull;
+    {
+        // more nominees than the list holds (a flat score map): the band's first cells in list order are not
+        // necessarily its best — every cell of the band is then re-scored exactly, a wave per cell in turn
+        const int total = nom_cnt;
+        const bool flood = total > DEC_NOM;
+        const int cells = flood ? (y_end - y_begin) * G : total;
+        const int lane = threadIdx.x & 63;
+        const int ch = lane >> 2, k = lane & 3;
+        for (int e = wave; e < cells; e += 4 * SPLIT) {
+            const unsigned idx = flood ? (unsigned)(y_begin * G + e) : nom[e];
+            const int Y = (int)(idx / (unsigned)G), X = (int)(idx - (unsigned)Y * (unsigned)G);
+            int bx, by;
+            float tx, ty, wx[4], wy[4];
+            cubic_src(X, D.inv_up, &bx, &tx);
+            cubic_src(Y, D.inv_up, &by, &ty);
+            cubic_coeffs(tx, wx);
+            cubic_coeffs(ty, wy);
+            float hk = 0.0f;
+            if (ch < 7) {
+                const float* q = lg + ch * Ho * Ho + clampi(by - 1 + k, 0, Ho - 1) * Ho;
+                hk = interp4(q[clampi(bx - 1, 0, Ho - 1)], q[clampi(bx, 0, Ho - 1)], q[clampi(bx + 1, 0, Ho - 1)],
+                             q[clampi(bx + 2, 0, Ho - 1)], wx);
+            }
+            const int q0 = lane & ~3;
+            const float vch = interp4(__shfl(hk, q0), __shfl(hk, q0 + 1), __shfl(hk, q0 + 2), __shfl(hk, q0 + 3), wy);
+            float v[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) v[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vch), 4 * c));
+            const float score = cell_score(v, box_w, box_h, mul_rn(hann[Y], hann[X]), D);
+            const unsigned long long key = make_key(score, idx);
+            if (key > ebest) {                                     // wave-uniform
+                ebest = key;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) ev[c] = v[c];
+            }
+        }
+    }
+    if ((threadIdx.x & 63) == 0) wbest[wave] = ebest;              // (the first reduction's readers passed a barrier)
+    __syncthreads();
+    unsigned long long we = wbest[0];
 #pragma unroll
     for (int w = 1; w < 4 * SPLIT; ++w) we = (wbest[w] > we) ? wbest[w] : we;
 
+    DC_TRACE(5)
     // ---- publish the band's record (write-through 8-byte stores), take a ticket ---------------------------------
     gu64_t* rec = (gu64_t*)(cand + ((size_t)n * nband + blockIdx.y) * DEC_REC);
-    const bool winner = (we != 0ull) && (ebest == we);             // keys are unique per cell: one lane
+    const bool winner = (we != 0ull) && (ebest == we) && (threadIdx.x & 63) == 0;   // keys are unique per cell: one wave
     if (we == 0ull && threadIdx.x == 0) __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (winner) {
         auto pk = [](float a, float b) {
@@ -394,6 +411,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         wflag = (old == (unsigned)(nband - 1)) ? 1u : 0u;
     }
     __syncthreads();
+    DC_TRACE(6)
     if (wflag == 0u || threadIdx.x >= 64) return;
 
     // ---- last workgroup of the track: arg-max over the bands' exact winners, box, confidence --------------------
@@ -451,6 +469,8 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     const float e0 = expf(sub_rn(v[0], m)), e1 = expf(sub_rn(v[1], m));
     F.conf[n] = div_rn(e1, add_rn(e0, e1));
     if (F.idx_out != nullptr) F.idx_out[n] = (long long)idx;
+    if (F.trace) F.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
+#undef DC_TRACE
 }
 
 #ifdef SMOT_DEBUG
@@ -756,6 +776,7 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     F.pad = pad_pixels;
     F.clip_w = clip_w;
     F.clip_h = clip_h;
+    F.trace = g_trace;
     if (!tickets_zeroed) {
         hipError_t e = hipMemsetAsync(F.ticket, 0, (size_t)N * sizeof(unsigned), st);
         if (e != hipSuccess) {
