@@ -22,6 +22,7 @@
 // aspect ratios) take a workgroup-uniform slow path: per-bin gathers, same arithmetic as roi_align.hip.
 #include "roi_common.h"
 #include "xcorr_patch2.h"
+#include "xcorr_patch1.h"
 #include "knobs.h"
 #include <type_traits>
 
@@ -321,13 +322,14 @@ __device__ __forceinline__ float rl_f(float v, int lane_const) {
 }
 
 template <int RX, int RZ, int G, bool XCORR>
-__global__ void __launch_bounds__(512, 4)      // <= 128 VGPRs: two workgroups (16 waves) per CU
+__global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                        const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
                        int32_t* __restrict__ levels_out, SrOut S) {
     constexpr int HO = XCORR ? RX - RZ + 1 : 16;
     constexpr int NS = RX * G;                   // samples per axis
-    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
+    // LDS image of the one-plane-per-wave correlation (xcorr_patch1.h): row stride 40, one plane per slot
+    constexpr int XS = XP1_XS, XP = 32 * XP1_XS, ZS = XP1_ZS, ZP = RZ * XP1_ZS;
     constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
@@ -339,7 +341,6 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
     const int n = blockIdx.x;
-    const int c0 = blockIdx.y * FX_CH;
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
 #define FX_TRACE(SLOT)                                                                      \
     if (S.trace && tid == 0)                                                                \
@@ -368,9 +369,15 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
     const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
     const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
-
+    // (Measured and dropped, profiles/r02x: one workgroup per (roi, FOUR channels) for rois whose window is wider
+    // than 32 columns — two waves per plane, so that they do not set the makespan — with narrow rois using every
+    // second workgroup: per-workgroup spans became equal (25-32 k cycles instead of 26 k / 48 k) but 608 working
+    // workgroups no longer fit the chip's 512 resident slots (two rounds: 18.7 -> 24 us), and at three workgroups
+    // per CU — 74 VGPRs with the one-plane correlation below — the kernel still took 23.0 us.)
+    constexpr int nplanes = FX_CH;
+    const int c0 = blockIdx.y * FX_CH;
     // template of this wave's plane: issue the loads now, park them in LDS after the tables
-    const bool owns = (c0 + wave < C);                    // channel tails: this wave has no plane
+    const bool owns = (wave < nplanes && c0 + wave < C);  // channel tails / four-plane workgroups: no plane here
     const int plane = n * C + c0 + wave;
     constexpr int NZ = XCORR ? (RZ * RZ + 63) / 64 : 1;
     float zreg[NZ];
@@ -604,13 +611,12 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
 #ifdef SMOT_DEBUG
         if (S.abl == 2) return;                           // timing ablation: measurement library only
 #endif
-        if (wave < 4) {
-            const int plane0 = n * C + c0 + 2 * wave;
-            const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);
-            if (nvalid > 0) {
-                const float* xs2 = sm + wave * (2 * XP + 2 * ZP);
-                xcorr_patch2_compute<RX, RZ, 0>(xs2, xs2 + 2 * XP, lane, resp, plane0, plane0 + nvalid);
-            }
+        // every wave correlates its own plane (2x2 output patches per lane): all eight waves work, and the phase
+        // needs few enough registers for three workgroups per CU
+        if (owns) {
+            const float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
+            const float* zs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;
+            xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane);
         }
     }
     FX_TRACE(4)

@@ -16,7 +16,10 @@ namespace smot {
 constexpr int XP1_XS = 40;
 constexpr int XP1_ZS = 16;
 
-template <int RX, int RZ>
+// LEAN: no software prefetch of the next window / template row (one row buffer instead of two, two live template
+// rows instead of three): ~65 instead of ~90 VGPRs.  For callers that run six waves per SIMD (the fused pooling +
+// correlation kernel at three workgroups per CU), where other waves cover the LDS latency.  Same FMA order.
+template <int RX, int RZ, bool LEAN = false>
 __device__ __forceinline__ void xcorr_patch1_compute(const float* xs, const float* zs, int lane,
                                                      float* __restrict__ out, int plane) {
     constexpr int HO = RX - RZ + 1;
@@ -51,8 +54,10 @@ __device__ __forceinline__ void xcorr_patch1_compute(const float* xs, const floa
     }
 #define SMOT_STEP(T, CUR, NXT)                                                              \
     {                                                                                       \
-        if ((T) + 1 < RZ + 1) SMOT_LOAD_X((T) + 1, NXT)                                     \
-        if ((T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                              \
+        if (!LEAN && (T) + 1 < RZ + 1) SMOT_LOAD_X((T) + 1, NXT)                            \
+        if (!LEAN && (T) + 1 < RZ) SMOT_LOAD_Z((T) + 1)                                     \
+        if (LEAN && (T) > 0) SMOT_LOAD_X((T), CUR)                                          \
+        if (LEAN && (T) > 0 && (T) < RZ) SMOT_LOAD_Z((T))                                   \
         _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                     \
             const int u = (T) - k;                                                          \
             if (u >= 0 && u < RZ) {                                                         \
@@ -70,8 +75,13 @@ __device__ __forceinline__ void xcorr_patch1_compute(const float* xs, const floa
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t2 = 0; t2 < RZ + 1; t2 += 2) {
-        SMOT_STEP(t2, wa, wb)
-        SMOT_STEP(t2 + 1, wb, wa)
+        if (LEAN) {
+            SMOT_STEP(t2, wa, wa)
+            SMOT_STEP(t2 + 1, wa, wa)
+        } else {
+            SMOT_STEP(t2, wa, wb)
+            SMOT_STEP(t2 + 1, wb, wa)
+        }
     }
 #undef SMOT_STEP
 #undef SMOT_LOAD_Z

@@ -23,12 +23,15 @@ for n in [int(a) for a in sys.argv[1:]] or [30]:
         tr = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
         lib.smot_debug_trace(ops._ptr(tr)); f(); torch.cuda.synchronize(); lib.smot_debug_trace(ops._ptr(None))
         t = tr.view(n, 16, 8).cpu().numpy().astype(np.float64)
+        ran = t[:, :, 4] > 0                                   # workgroups that did not return at the split
         d = np.diff(t[:, :, :5], axis=2)
         t0 = t[:, :, 0].min()
-        out = {"tracks": n, "kernel": name, "phase_ticks_mean(tables,z,pool,xcorr)": [round(float(x)) for x in d.reshape(-1, 4).mean(0)],
-               "phase_max": [int(x) for x in d.reshape(-1, 4).max(0)], "span": int(t[:, :, 4].max() - t0),
-               "start_spread": int(t[:, :, 0].max() - t0)}
+        out = {"tracks": n, "kernel": name, "workgroups_working": int(ran.sum()), "workgroups_launched": int(ran.size),
+               "phase_ticks_mean(tables,z,pool,xcorr)": [round(float(x)) for x in d[ran].mean(0)],
+               "phase_max": [int(x) for x in d[ran].max(0)], "span": int(t[:, :, 4].max() - t0),
+               "start_spread": int(t[:, :, 0].max() - t0), "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
+               "total_max": int((t[:, :, 4] - t[:, :, 0])[ran].max())}
         for L in range(4):
-            m = lv == L
-            if m.any(): out["pool_ticks_level%d" % L] = round(float(d[m][:, :, 2].mean()))
+            m = (lv == L)[:, None] & ran
+            if m.any(): out["pool_ticks_level%d" % L] = round(float(d[:, :, 2][m].mean()))
         print(json.dumps(out), flush=True)

@@ -1,9 +1,8 @@
 set -x
-python -m pytest tests/test_hip_parity.py -m gpu -q --no-header --tb=short -x -k "decode or emm or benchmark" 2>&1 | tail -6
-python tools/debug/decode_trace.py 30 100
-python bench.py --no-cpu-baseline --extra-streams 0 > gpurun_out/r02t_bench.log 2>&1; python - <<'PY'
-import json
-for l in open('gpurun_out/r02t_bench.log'):
-    if l.startswith('{'):
-        d=json.loads(l); print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline_tower']['avg_launch_us'], d['parity']['vs_reference_golden'])
-PY
+python -m pytest tests/test_hip_parity.py -m gpu -q --no-header --tb=short -x 2>&1 | tail -3
+python tools/debug/fused_trace.py 30 2>&1 | grep "^{" | cut -c1-400
+export TMPDIR=/tmp
+TAG=r02y
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-parity --extra-streams 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1 )
+python tools/rocpd_stats.py gpurun_out/prof_${TAG}/${TAG}_results.db --md gpurun_out/${TAG}_kernel_stats.md --title "${TAG}: bench.py --steps 300" 2>&1 | tail -1; head -10 gpurun_out/${TAG}_kernel_stats.md | cut -c1-60,150-260
+python bench.py --no-cpu-baseline --extra-streams 0 --tracks 100 --no-parity 2>&1 | tail -1 | cut -c1-200
