@@ -1,0 +1,208 @@
+"""The detector's half of the tracking step: ``_refine_tracks`` and the box head it calls.
+
+``CombinedROIHeads._refine_tracks`` (reference siammot/modelling/roi_heads.py:60-84) sends the boxes the EMM head
+propagated through the box head AS PROPOSALS and averages the two scores; ``RefineTracks`` is that function around any
+box head with the reference's call signature ``box(features, [BoxList]) -> (x, [BoxList], {})`` — the reference's own
+``ROIBoxHead`` or ``TrackBoxHead`` below — and is what ``TrackingLoop(refine_tracks=...)`` expects.
+
+``TrackBoxHead`` restates ``ROIBoxHead`` at inference (siammot/modelling/box_head/box_head.py:10-56) with the pieces the
+reference's yaml files select: [UPSTREAM] ``FPN2MLPFeatureExtractor`` (7x7 ``Pooler`` -> fc6 -> ReLU -> fc7 -> ReLU),
+[UPSTREAM] ``FPNPredictor`` (``cls_score`` / ``bbox_pred``) and the reference's own ``PostProcessor``
+(box_head/inference.py:11-185: soft-max, ``BoxCoder.decode``, track rows keep only their label's probability + 1 so
+that they survive, clip, per-class threshold, NMS on detections only).  The pooler is this repository's HIP ROIAlign
+(``poolers.Pooler``); the four ``Linear`` layers are library GEMMs (hipBLASLt through torch) — plain dense layers, not
+hand kernels, as the north star assigns them.  Parameter names are upstream's (``feature_extractor.fc6.weight`` ...), so
+the ``roi_heads.box.*`` entries of a reference checkpoint load with ``load_state_dict``.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .poolers import Pooler
+from .structures import BoxList, boxlist_nms, cat_boxlist
+
+
+class BoxCoder(object):
+    """[UPSTREAM] maskrcnn_benchmark/modeling/box_coder.py ``decode``: deltas (dx, dy, dw, dh) / weights applied to
+    boxes measured with the legacy +1 width, ``dw`` / ``dh`` clamped at log(1000/16)."""
+
+    def __init__(self, weights=(10.0, 10.0, 5.0, 5.0), bbox_xform_clip=math.log(1000.0 / 16)):
+        self.weights = tuple(float(w) for w in weights)
+        self.bbox_xform_clip = bbox_xform_clip
+
+    def decode(self, rel_codes, boxes):
+        boxes = boxes.to(rel_codes.dtype)
+        widths = boxes[:, 2] - boxes[:, 0] + 1
+        heights = boxes[:, 3] - boxes[:, 1] + 1
+        ctr_x = boxes[:, 0] + 0.5 * widths
+        ctr_y = boxes[:, 1] + 0.5 * heights
+        wx, wy, ww, wh = self.weights
+        dx = rel_codes[:, 0::4] / wx
+        dy = rel_codes[:, 1::4] / wy
+        dw = torch.clamp(rel_codes[:, 2::4] / ww, max=self.bbox_xform_clip)
+        dh = torch.clamp(rel_codes[:, 3::4] / wh, max=self.bbox_xform_clip)
+        pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
+        pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
+        pred_w = torch.exp(dw) * widths[:, None]
+        pred_h = torch.exp(dh) * heights[:, None]
+        out = torch.zeros_like(rel_codes)
+        out[:, 0::4] = pred_ctr_x - 0.5 * pred_w
+        out[:, 1::4] = pred_ctr_y - 0.5 * pred_h
+        out[:, 2::4] = pred_ctr_x + 0.5 * pred_w - 1
+        out[:, 3::4] = pred_ctr_y + 0.5 * pred_h - 1
+        return out
+
+
+class FPN2MLPFeatureExtractor(nn.Module):
+    """[UPSTREAM] roi_box_feature_extractors.py ``FPN2MLPFeatureExtractor`` (no GroupNorm variant, as in the yamls)."""
+
+    def __init__(self, in_channels, resolution, scales, sampling_ratio, representation_size, pooler=None):
+        super(FPN2MLPFeatureExtractor, self).__init__()
+        self.pooler = pooler if pooler is not None else Pooler((resolution, resolution), scales, sampling_ratio)
+        self.fc6 = nn.Linear(in_channels * resolution * resolution, representation_size)
+        self.fc7 = nn.Linear(representation_size, representation_size)
+        self.out_channels = representation_size
+
+    def forward(self, x, proposals):
+        x = self.pooler(x, proposals)
+        x = x.reshape(x.size(0), -1)
+        x = torch.relu(self.fc6(x))
+        return torch.relu(self.fc7(x))
+
+
+class FPNPredictor(nn.Module):
+    """[UPSTREAM] roi_box_predictors.py ``FPNPredictor``."""
+
+    def __init__(self, representation_size, num_classes, cls_agnostic_bbox_reg=False):
+        super(FPNPredictor, self).__init__()
+        self.cls_score = nn.Linear(representation_size, num_classes)
+        self.bbox_pred = nn.Linear(representation_size, (2 if cls_agnostic_bbox_reg else num_classes) * 4)
+
+    def forward(self, x):
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+class PostProcessor(nn.Module):
+    """box_head/inference.py:11-185.  ``nms_fn(BoxList, thresh) -> BoxList`` defaults to the HIP NMS."""
+
+    def __init__(self, score_thresh=0.05, nms=0.5, box_coder=None, cls_agnostic_bbox_reg=False,
+                 amodal_inference=False, nms_fn=None):
+        super(PostProcessor, self).__init__()
+        self.score_thresh = score_thresh
+        self.nms = nms
+        self.box_coder = box_coder if box_coder is not None else BoxCoder()
+        self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+        self.amodal_inference = amodal_inference
+        self.nms_fn = nms_fn if nms_fn is not None else boxlist_nms
+
+    def forward(self, x, boxes):
+        class_logits, box_regression = x
+        if len(boxes) != 1:
+            raise RuntimeError("PostProcessor: one image per call")
+        box = boxes[0]
+        prob = torch.softmax(class_logits, -1)
+        device = class_logits.device
+        if self.cls_agnostic_bbox_reg:
+            box_regression = box_regression[:, -4:]
+        proposals = self.box_coder.decode(box_regression.view(len(box), -1), box.bbox)
+        if self.cls_agnostic_bbox_reg:
+            proposals = proposals.repeat(1, prob.shape[1])
+        num_classes = prob.shape[1]
+        if box.has_field("ids"):                                                   # inference.py:85-90
+            ids = box.get_field("ids")
+        else:
+            ids = torch.full((len(box),), -1, dtype=torch.int64, device=device)
+        if box.has_field("labels"):                                                # inference.py:93-104: tracks
+            labels = box.get_field("labels")
+            is_track = ids >= 0
+            keep = torch.zeros_like(prob)
+            keep.scatter_(1, labels.view(-1, 1), 1.0)
+            # a track row keeps only its own label's probability, moved to the (1, 2] band
+            prob = torch.where(is_track[:, None], (prob + 1.0) * keep, prob)
+        boxlist = BoxList(proposals.reshape(-1, 4), box.size, mode="xyxy")
+        boxlist.add_field("scores", prob.reshape(-1))
+        if not self.amodal_inference:
+            boxlist = boxlist.clip_to_image(remove_empty=False)
+        return [self.filter_results(boxlist, ids, num_classes)]
+
+    def filter_results(self, boxlist, ids, num_classes):                           # inference.py:137-185
+        boxes = boxlist.bbox.reshape(-1, num_classes * 4)
+        scores = boxlist.get_field("scores").reshape(-1, num_classes)
+        device = scores.device
+        result = []
+        inds_all = scores > self.score_thresh
+        for j in range(1, num_classes):
+            inds = inds_all[:, j].nonzero().squeeze(1)
+            scores_j, boxes_j, ids_j = scores[inds, j], boxes[inds, j * 4:(j + 1) * 4], ids[inds]
+            det_idx = ids_j < 0
+            det = BoxList(boxes_j[det_idx], boxlist.size, mode="xyxy")
+            det.add_field("scores", scores_j[det_idx])
+            det.add_field("ids", ids_j[det_idx])
+            if len(det) > 0:
+                det = self.nms_fn(det, self.nms)
+            trk_idx = ids_j >= 0
+            if bool(trk_idx.any()):
+                trk = BoxList(boxes_j[trk_idx], boxlist.size, mode="xyxy")
+                trk.add_field("scores", scores_j[trk_idx])
+                trk.add_field("ids", ids_j[trk_idx])
+                det = cat_boxlist([det, trk])
+            det.add_field("labels", torch.full((len(det),), j, dtype=torch.int64, device=device))
+            result.append(det)
+        return cat_boxlist(result)
+
+
+class TrackBoxHead(nn.Module):
+    """``ROIBoxHead`` at inference: ``forward(features, [proposals]) -> (x, [BoxList], {})``."""
+
+    def __init__(self, cfg, in_channels, pooler=None, nms_fn=None):
+        super(TrackBoxHead, self).__init__()
+        head = cfg.MODEL.ROI_BOX_HEAD
+        agnostic = bool(getattr(cfg.MODEL, "CLS_AGNOSTIC_BBOX_REG", False))
+        self.feature_extractor = FPN2MLPFeatureExtractor(in_channels, head.POOLER_RESOLUTION, head.POOLER_SCALES,
+                                                         head.POOLER_SAMPLING_RATIO, head.MLP_HEAD_DIM, pooler)
+        self.predictor = FPNPredictor(head.MLP_HEAD_DIM, head.NUM_CLASSES, agnostic)
+        rh = cfg.MODEL.ROI_HEADS
+        self.post_processor = PostProcessor(rh.SCORE_THRESH, rh.NMS, BoxCoder(rh.BBOX_REG_WEIGHTS), agnostic,
+                                            bool(cfg.INPUT.AMODAL), nms_fn)
+
+    def forward(self, features, proposals, targets=None):
+        if self.training:
+            raise NotImplementedError("siammot_amd.TrackBoxHead is an inference path (box_head.py:39-43,52-61)")
+        x = self.feature_extractor(features, proposals)
+        return x, self.post_processor(self.predictor(x), proposals), {}
+
+
+class RefineTracks(object):
+    """roi_heads.py:60-84 as a callable: ``refine(features, [tracks]) -> [tracks]``.
+
+    The propagated boxes come back from the box head with its regressed box and ``score = (p_label + 1 + track_conf
+    + 1) / 2`` in the (1, 2] band (``tracktor``: the box head's score alone).  Like the reference, the matching
+    scores are taken in the order the tracks went in and the detection scores in the order the box head returns them
+    (grouped by label) — identical orders for the single-class models the reference ships."""
+
+    def __init__(self, box_head, tracktor=False):
+        self.box = box_head
+        self.tracktor = bool(tracktor)
+
+    def __call__(self, features, tracks):
+        if len(tracks[0]) == 0:
+            return tracks
+        track_scores = tracks[0].get_field("scores") + 1.0
+        _, refined, _ = self.box(features, tracks)
+        r = refined[0]
+        det_scores = r.get_field("scores")
+        scores = det_scores if self.tracktor else (det_scores + track_scores) / 2.0
+        out = r.__class__(r.bbox, r.size, mode=r.mode)
+        out.add_field("scores", scores)
+        out.add_field("ids", r.get_field("ids"))
+        out.add_field("labels", r.get_field("labels"))
+        return [out]
+
+
+def build_refine_tracks(cfg, in_channels, box_head=None):
+    """The ``refine_tracks`` callable of ``build_tracking_loop`` from a config: the given box head (e.g. the reference's
+    ``ROIBoxHead`` with its trained weights) or a fresh ``TrackBoxHead``."""
+    if box_head is None:
+        box_head = TrackBoxHead(cfg, in_channels).eval()
+    return RefineTracks(box_head, bool(getattr(cfg.MODEL.TRACK_HEAD, "TRACKTOR", False)))

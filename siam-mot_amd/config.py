@@ -49,4 +49,11 @@ def get_default_cfg(conv_body="DLA-34-FPN", channels=128):
     th.EMM = CfgNode(USE_CENTERNESS=True, POS_RATIO=0.25, HN_RATIO=0.25, TRACK_LOSS_WEIGHT=1.0,
                      CLS_POS_REGION=0.8, COSINE_WINDOW_WEIGHT=0.4)
     cfg.MODEL.TRACK_HEAD = th
+    # the box head the tracker calls back into (_refine_tracks, roi_heads.py:60-84): DLA_34_FPN_EMM.yaml:25-33;
+    # thresholds / regression weights are [UPSTREAM] maskrcnn_benchmark defaults (the reference's yamls keep them)
+    cfg.MODEL.CLS_AGNOSTIC_BBOX_REG = False
+    cfg.MODEL.ROI_HEADS = CfgNode(USE_FPN=True, SCORE_THRESH=0.05, NMS=0.5, DETECTIONS_PER_IMG=100,
+                                  BBOX_REG_WEIGHTS=(10.0, 10.0, 5.0, 5.0))
+    cfg.MODEL.ROI_BOX_HEAD = CfgNode(POOLER_RESOLUTION=7, POOLER_SCALES=(0.25, 0.125, 0.0625, 0.03125),
+                                     POOLER_SAMPLING_RATIO=2, MLP_HEAD_DIM=1024, NUM_CLASSES=2)
     return cfg

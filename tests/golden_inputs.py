@@ -120,3 +120,44 @@ def decode_case_inputs(name):
     reg = (np.abs(rs.standard_normal((n, 4, ho, ho))) * 0.5 * side).astype(F32)
     sr = np_search_region(boxes, c["pad_pixels"], c["search_expansion"])
     return dict(cls=cls, center=center, reg=reg, boxes=boxes, sr=sr)
+
+
+# ---- box head / _refine_tracks (second half) ---------------------
+REFINE_CASE = dict(image_wh=(512, 384), channels=32, resolution=7, scales=(0.25, 0.125, 0.0625, 0.03125),
+                   sampling_ratio=2, mlp_dim=64, num_classes=3, score_thresh=0.05, nms=0.5,
+                   reg_weights=(10.0, 10.0, 5.0, 5.0), seed=31)
+
+
+def refine_case_inputs():
+    """FPN maps, a box head's weights (upstream parameter names) and two proposal sets: seven propagated tracks
+    (ids >= 0, labels in {1, 2}, matching scores) and sixteen proposals of which seven carry an id."""
+    c = REFINE_CASE
+    rs = np.random.RandomState(c["seed"])
+    feats = [rs.standard_normal(s).astype(F32) for s in feature_shapes(c["image_wh"], c["channels"])[:4]]
+    d_in = c["channels"] * c["resolution"] ** 2
+    params = {
+        "feature_extractor.fc6.weight": (rs.standard_normal((c["mlp_dim"], d_in)) / np.sqrt(d_in)).astype(F32),
+        "feature_extractor.fc6.bias": (0.1 * rs.standard_normal(c["mlp_dim"])).astype(F32),
+        "feature_extractor.fc7.weight": (rs.standard_normal((c["mlp_dim"], c["mlp_dim"])) / 8.0).astype(F32),
+        "feature_extractor.fc7.bias": (0.1 * rs.standard_normal(c["mlp_dim"])).astype(F32),
+        "predictor.cls_score.weight": (rs.standard_normal((c["num_classes"], c["mlp_dim"])) / 2.0).astype(F32),
+        "predictor.cls_score.bias": np.zeros(c["num_classes"], F32),
+        "predictor.bbox_pred.weight": (rs.standard_normal((4 * c["num_classes"], c["mlp_dim"])) / 4.0).astype(F32),
+        "predictor.bbox_pred.bias": np.zeros(4 * c["num_classes"], F32),
+    }
+    W, H = c["image_wh"]
+    wh = np.exp(rs.uniform(np.log(12), np.log(260), (16, 2)))
+    xy = rs.uniform(0, 1, (16, 2)) * np.array([W - 40.0, H - 40.0]) - 10.0
+    boxes = np.concatenate((xy, xy + wh), 1).astype(F32)
+    boxes[3] = [W - 30.0, H - 25.0, W + 40.0, H + 30.0]           # sticks out of the image: clipped by the head
+    track_boxes = boxes[:7]
+    track_ids = np.array([4, 0, 9, 2, 11, 5, 7], np.int64)
+    track_labels = np.array([1, 2, 1, 1, 2, 1, 2], np.int64)
+    track_scores = rs.uniform(0.3, 1.0, 7).astype(F32)
+    mixed_boxes = boxes[rs.permutation(16)]
+    order = rs.permutation(16)
+    mixed_ids = np.full(16, -1, np.int64)
+    for k, row in enumerate(order[:7]):
+        mixed_ids[row] = track_ids[k]
+    return dict(features=feats, params=params, track_boxes=track_boxes, track_ids=track_ids,
+                track_labels=track_labels, track_scores=track_scores, mixed_boxes=mixed_boxes, mixed_ids=mixed_ids)

@@ -1,0 +1,169 @@
+"""SURVEY.md §8(f) rank 1, second half: ``_refine_tracks`` and the box head it calls, against
+``tests/golden/refine_tracks.npz`` — outputs of the reference's OWN ``CombinedROIHeads._refine_tracks`` /
+``ROIBoxHead`` / ``PostProcessor`` (oracle/gen_golden_refine.py)."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import box_head_oracle as BO
+from oracle import solver_oracle as SO
+from siammot_amd.box_refine import BoxCoder, RefineTracks, TrackBoxHead, build_refine_tracks
+from siammot_amd.structures import BoxList
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "refine_tracks.npz")
+
+
+def _cfg():
+    c = gi.REFINE_CASE
+    ns = types.SimpleNamespace
+    return ns(INPUT=ns(AMODAL=False),
+              MODEL=ns(CLS_AGNOSTIC_BBOX_REG=False,
+                       ROI_HEADS=ns(BBOX_REG_WEIGHTS=c["reg_weights"], SCORE_THRESH=c["score_thresh"], NMS=c["nms"]),
+                       ROI_BOX_HEAD=ns(POOLER_RESOLUTION=c["resolution"], POOLER_SCALES=c["scales"],
+                                       POOLER_SAMPLING_RATIO=c["sampling_ratio"], MLP_HEAD_DIM=c["mlp_dim"],
+                                       NUM_CLASSES=c["num_classes"]),
+                       TRACK_HEAD=ns(TRACKTOR=False)))
+
+
+def _cpu_nms(boxlist, thresh):
+    keep = SO.nms_indices(boxlist.bbox.numpy(), boxlist.get_field("scores").numpy(), thresh)
+    return boxlist[torch.from_numpy(keep)]
+
+
+def _proposals(boxes, ids, dev, labels=None, scores=None):
+    bl = BoxList(torch.from_numpy(boxes.copy()).to(dev), gi.REFINE_CASE["image_wh"], mode="xyxy")
+    bl.add_field("ids", torch.from_numpy(ids.copy()).to(dev))
+    if labels is not None:
+        bl.add_field("labels", torch.from_numpy(labels.copy()).to(dev))
+    if scores is not None:
+        bl.add_field("scores", torch.from_numpy(scores.copy()).to(dev))
+    return bl
+
+
+def _check(head, dev, tol):
+    c, inp, g = gi.REFINE_CASE, gi.refine_case_inputs(), np.load(GOLD)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in inp["params"].items()}, strict=True)
+    head = head.to(dev).eval()
+    feats = [torch.from_numpy(f).to(dev) for f in inp["features"]]
+    with torch.no_grad():
+        refine = RefineTracks(head)
+        r = refine(feats, [_proposals(inp["track_boxes"], inp["track_ids"], dev, inp["track_labels"],
+                                      inp["track_scores"])])[0]
+        x, res, losses = head(feats, [_proposals(inp["mixed_boxes"], inp["mixed_ids"], dev)])
+    assert losses == {}
+    assert r.get_field("ids").cpu().numpy().tolist() == g["refine_ids"].tolist()
+    assert r.get_field("labels").cpu().numpy().tolist() == g["refine_labels"].tolist()      # regrouped by label
+    np.testing.assert_allclose(r.bbox.cpu().numpy(), g["refine_bbox"], rtol=0, atol=tol * 100)
+    np.testing.assert_allclose(r.get_field("scores").cpu().numpy(), g["refine_scores"], rtol=0, atol=tol)
+    sc = r.get_field("scores").cpu().numpy()
+    assert (sc > 1.0).all() and (sc <= 2.0).all()                  # the band TrackSolver reads as "track"
+    m = res[0]
+    assert m.get_field("ids").cpu().numpy().tolist() == g["mixed_ids"].tolist()
+    assert m.get_field("labels").cpu().numpy().tolist() == g["mixed_labels"].tolist()
+    np.testing.assert_allclose(m.bbox.cpu().numpy(), g["mixed_bbox"], rtol=0, atol=tol * 100)
+    np.testing.assert_allclose(m.get_field("scores").cpu().numpy(), g["mixed_scores"], rtol=0, atol=tol)
+    np.testing.assert_allclose(x[:, ::9].cpu().numpy(), g["mixed_x_sub"], rtol=0, atol=tol * 10)
+    assert int((g["mixed_ids"] >= 0).sum()) > 7 and len(g["mixed_ids"]) < 32      # id rows kept per class, dets pruned
+
+
+def test_box_head_host_logic_matches_reference_golden():
+    """Everything above the pooler and the NMS kernel (MLP, soft-max, BoxCoder, the track branch of the post-processor,
+    per-class filtering, ``_refine_tracks`` score averaging and regrouping) with the oracle's pooler / numpy NMS
+    injected: no GPU, no HIP library."""
+    c = gi.REFINE_CASE
+    head = TrackBoxHead(_cfg(), c["channels"], pooler=BO.OraclePooler(c["resolution"], c["scales"], c["sampling_ratio"]),
+                        nms_fn=_cpu_nms)
+    _check(head, "cpu", 2e-6)
+
+
+def test_box_head_parameter_names_are_upstreams():
+    c = gi.REFINE_CASE
+    head = TrackBoxHead(_cfg(), c["channels"], pooler=torch.nn.Identity())
+    assert sorted(head.state_dict().keys()) == sorted(gi.refine_case_inputs()["params"].keys())
+    with pytest.raises(NotImplementedError):
+        head.train()(None, None)
+
+
+def test_box_coder_matches_the_loopwise_restatement():
+    rs = np.random.RandomState(5)
+    boxes = torch.from_numpy(np.abs(rs.standard_normal((40, 4))).cumsum(1).astype(np.float32) * 30)
+    codes = torch.from_numpy(rs.standard_normal((40, 12)).astype(np.float32) * 4)
+    codes[0, 2] = 100.0                                              # clamp at log(1000/16)
+    a = BoxCoder((10.0, 10.0, 5.0, 5.0)).decode(codes, boxes)
+    b = BO.BoxCoder((10.0, 10.0, 5.0, 5.0)).decode(codes, boxes)
+    assert torch.equal(a, b)
+
+
+def test_refine_tracks_empty_and_tracktor():
+    empty = BoxList(torch.zeros(0, 4), (10, 10))
+    empty.add_field("scores", torch.zeros(0))
+    assert RefineTracks(None)(None, [empty])[0] is empty
+
+    def box(features, tracks):
+        t = tracks[0]
+        out = BoxList(t.bbox + 1.0, t.size)
+        out.add_field("scores", torch.full((len(t),), 1.25))
+        out.add_field("ids", t.get_field("ids"))
+        out.add_field("labels", t.get_field("labels"))
+        return None, [out], {}
+    t = _proposals(np.zeros((2, 4), np.float32), np.array([3, 4]), "cpu", np.array([1, 1]),
+                   np.array([0.5, 0.9], np.float32))
+    assert RefineTracks(box, tracktor=True)(None, [t])[0].get_field("scores").tolist() == [1.25, 1.25]
+    assert RefineTracks(box)(None, [t])[0].get_field("scores").tolist() == pytest.approx([1.375, 1.575])
+    cfg = _cfg()
+    assert isinstance(build_refine_tracks(cfg, 32, box_head=box), RefineTracks)
+
+
+@pytest.mark.gpu
+def test_box_head_on_the_hip_pooler_and_nms_matches_reference_golden():
+    """The product configuration: HIP ROIAlign 7x7 + hipBLASLt linears + HIP NMS on the device."""
+    c = gi.REFINE_CASE
+    _check(TrackBoxHead(_cfg(), c["channels"]), "cuda", 2e-5)
+
+
+@pytest.mark.gpu
+def test_tracking_loop_with_refine_tracks_runs_the_reference_order():
+    """TrackingLoop(refine_tracks=RefineTracks(box head)): the propagated boxes go through the box head as proposals
+    (roi_heads.py:43-45), come back with scores in the (1, 2] band, and the tracks keep their ids over frames."""
+    import bench
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    cfg = get_default_cfg(channels=bench.CHANNELS)
+    cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM = 64
+    image_wh = (bench.NET_HW[1], bench.NET_HW[0])
+    torch.manual_seed(0)
+    head = TrackBoxHead(cfg, bench.CHANNELS).to("cuda").eval()
+    with torch.no_grad():
+        head.predictor.bbox_pred.weight.mul_(0.02)                 # small regressions: tracks stay on their objects
+        head.predictor.cls_score.bias.copy_(torch.tensor([-4.0, 4.0]))
+    calls = []
+    refine = RefineTracks(head)
+
+    def counted(features, tracks):
+        out = refine(features, tracks)
+        calls.append((len(tracks[0]), float(out[0].get_field("scores").min()), float(out[0].get_field("scores").max())))
+        return out
+    loop = build_tracking_loop(cfg, "cuda", refine_tracks=counted)
+    boxes = torch.tensor([[100.0 + 150 * i, 80.0 + 60 * (i % 3), 160.0 + 150 * i, 220.0 + 60 * (i % 3)] for i in range(7)])
+    bench.init_predictor(loop.track.tracker.predictor, boxes)
+    with torch.no_grad():
+        for name in ("cls", "center", "reg"):                      # a response dominated by the cosine window
+            getattr(loop.track.tracker.predictor, name).weight.mul_(0.02)
+    loop.track.tracker.to("cuda")
+    feats = [bench.synthetic_features(100 + k, "cuda") for k in range(2)]
+    ids_seen = []
+    for f in range(4):
+        det = BoxList(boxes.clone().to("cuda"), image_wh)
+        det.add_field("scores", torch.full((7,), 0.99, device="cuda"))
+        det.add_field("labels", torch.ones(7, dtype=torch.int64, device="cuda"))
+        det.add_field("ids", torch.full((7,), -1, dtype=torch.int64, device="cuda"))
+        out = loop(feats[f % 2], det)
+        ids_seen.append(sorted(i for i in out.get_field("ids").tolist() if i >= 0))
+    assert ids_seen[0] == list(range(7))
+    assert len(calls) == 3 and all(n == 7 for n, _, _ in calls)     # every later frame refined the 7 propagated boxes
+    assert all(lo > 1.0 and hi <= 2.0 for _, lo, hi in calls)
+    assert ids_seen[-1] == list(range(7))                           # the refined tracks win the NMS against detections
