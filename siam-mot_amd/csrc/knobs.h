@@ -26,6 +26,7 @@ struct Knobs {
     int xcorr_variant = 0;   // SMOT_XCORR_VARIANT : XcorrVariant (wave|patch|pk|one|mfma|fill|compute)
     int decode_two_pass = 0; // SMOT_DECODE_2PASS  : band kernel + separate finalize launch (round-1 structure)
     int fused_gen = 0;       // SMOT_FUSED_GEN     : 0 = current fused pooling kernel, 2 = round-1 kernel
+    int tower_oct = 0;       // SMOT_TOWER_OCT     : 16-channel tiles per Winograd workgroup (0 = default, 1 or 2)
     // timing ablations: WRONG results, measurement builds only
     int fused_abl = 0;       // SMOT_FUSED_ABL
     int wino_abl = 0;        // SMOT_WINO_ABL

@@ -18,11 +18,14 @@ struct TowerParams {
 };
 
 __device__ __forceinline__ float group16_sum(float v) {
-    // sum over the 16 lanes that share lane>>4
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    // sum over the 16 lanes that share lane>>4 (= one DPP row): four row rotations, no LDS crossbar round trips
+    // (__shfl_xor compiles to ds_bpermute: four dependent ~100-cycle trips per sum)
+#define SMOT_ROR(N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (N), 0xf, 0xf, false))
+    v += SMOT_ROR(8);
+    v += SMOT_ROR(4);
+    v += SMOT_ROR(2);
+    v += SMOT_ROR(1);
+#undef SMOT_ROR
     return v;
 }
 

@@ -12,9 +12,12 @@
 //     M_xi[oc][tile] = sum_ic U_xi[oc][ic] * V_xi[ic][tile]   -> 16 GEMMs of 16 x 64 x C per workgroup.
 // Transform constants are 0, +-1, +-1/2: the result differs from the direct fp32 sum only in rounding order.
 //
-//   workgroup = (track, 16 output channels) x all 64 2x2 tiles; 4 waves; XCD-aware block order: the 16
+//   workgroup = (track, OCT x 16 output channels) x all 64 2x2 tiles; 4*OCT waves; XCD-aware block order: the
 //               workgroups of a track share an XCD (one L2 fetch of the track's response map).
-//   wave w    = xi row i = w (4 xi) x 4 N-tiles of 16 tiles  -> 16 accumulator tiles (64 AGPRs).
+//   OCT = 1   : wave w = xi row i = w (4 xi) x 4 N-tiles of 16 tiles -> 16 accumulator tiles.
+//   OCT = 2   : wave w = xi row i = w%4 x the N-tile pair h = w/4 x TWO 16-channel tiles -> 16 accumulator tiles
+//               again, but every B operand a lane builds now feeds two MFMAs: half the operand-transform VALU
+//               work, LDS reads and raw staging per MFMA, one zero fill and one response fetch per 32 channels.
 //   A operand = U, transformed ONCE per parameter set by tower_pack_kernel into the exact per-lane order the
 //               waves consume (one coalesced 16-byte load per lane and 4-channel k-step, straight to VGPRs).
 //   B operand = V, built in registers: a lane owns one input channel of the k-step and two horizontally
@@ -40,8 +43,12 @@ constexpr int W_X_FLOATS = 4 * 2 * 16 * W_XOC;   // 8704
 constexpr int W_PL_OFF = W_X_FLOATS;             // head planes [16][336]
 constexpr int W_HW_OFF = W_PL_OFF + 16 * T_PLANE;   // head taps [16*9][4]
 constexpr int W_ST_OFF = W_HW_OFF + 16 * 36;        // channel sums [16], [16]
-constexpr int W_SMEM_FLOATS = (W_ST_OFF + 32 > W_RING * W_BUF) ? W_ST_OFF + 32 : W_RING * W_BUF;   // epilogue overlays the ring
-static_assert(W_SMEM_FLOATS * 4 <= 64 * 1024, "two workgroups per CU, no opt-in needed");
+constexpr int W_EPI_FLOATS = W_ST_OFF + 32;         // epilogue image of ONE 16-channel tile
+constexpr int w_smem_floats(int oct) {              // the epilogue images (one per tile) overlay the ring
+    return (oct * W_EPI_FLOATS > W_RING * W_BUF) ? oct * W_EPI_FLOATS : W_RING * W_BUF;
+}
+static_assert(w_smem_floats(1) * 4 <= 64 * 1024, "OCT = 1: two workgroups per CU, no opt-in needed");
+static_assert(w_smem_floats(2) * 4 <= 160 * 1024, "OCT = 2: one workgroup per CU");
 
 // packed[tile][k = ic/4][wave][lane][q] = (G g G^T)[i = wave][j = q] of g = W[oc = 16*tile + lane%16][ic = 4k + lane/16]
 // (oc counts cls_tower channels first, then reg_tower).  One thread per (oc, ic).
@@ -76,11 +83,14 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 // ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
 // loads inside the loop, 3 = no LDS reads / operand transform, 4 = no MFMAs, 5 = MFMAs + barriers only,
 // 6 = MFMAs only.  Instantiated in the measurement library only (knobs.h: SMOT_WINO_ABL).
-template <int ABL>
-__global__ void __launch_bounds__(256, 2)
+template <int ABL, int OCT>
+__global__ void __launch_bounds__(256 * OCT, OCT == 1 ? 2 : 1)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
                   int cpg, float eps, float* __restrict__ part, unsigned* __restrict__ zero_words,
                   long long* __restrict__ trace) {
+    constexpr int NT = 256 * OCT;             // threads
+    constexpr int NP = 2 / OCT;               // tile-row halves (pairs of N-tiles) per wave
+    constexpr int RAW4 = 512 / NT;            // float4 per thread and stage of raw response
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
 #define W_TRACE(SLOT) \
@@ -92,89 +102,125 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xi = wave & 3;                  // xi row of this wave
+    const int nh = wave >> 2;                 // OCT = 2: which pair of N-tiles (0 for OCT = 1)
     const int tiles_per_tower = C >> 4;
     const int tiles = 2 * tiles_per_tower;
-    // consecutive workgroup ids go round-robin over the 8 XCDs: give all tiles of a track the same XCD
+    const int wg_per_track = tiles / OCT;
+    // consecutive workgroup ids go round-robin over the 8 XCDs: give all workgroups of a track the same XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int n = (slot / tiles) * 8 + xcd;
-    const int tile = slot % tiles;
+    const int n = (slot / wg_per_track) * 8 + xcd;
+    const int tile0 = (slot % wg_per_track) * OCT;      // first 16-channel tile (OCT = 2: tile0, tile0 + 1: same tower)
     if (n >= N) return;
-    if (zero_words != nullptr && tile == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
+    if (zero_words != nullptr && tile0 == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
     // (Workgroups b and b + 256 share a CU — HW_ID trace in tools/debug/tower_bench.py.  Delaying the second
     // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
     // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
-    const int tower = tile / tiles_per_tower;
-    const int oc0 = (tile - tower * tiles_per_tower) * 16;
     const float* __restrict__ in = resp + (size_t)n * C * 256;
     const int nk = C >> 2;
     const int nstages = C / W_STAGE_IC;
-
-    {   // zero the stage buffers once: the halos stay zero for the whole main loop (a halo-only fill was measured
-        // slower: its scattered ds_write_b32 and index arithmetic cost more than 14 ds_write_b128 per thread)
-        float4* z = reinterpret_cast<float4*>(sm);
-        for (int e = tid; e < W_RING * W_BUF / 4; e += 256) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    // head taps of this tile's channels, fetched now, used in the epilogue: hw[(ocl*9+tap)*4 + o]
-    float hwreg[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int idx = tid + 256 * j;
-        float v = 0.0f;
-        if (idx < 16 * 36) {
-            const int o = idx / (16 * 9);
-            const int rem = idx - o * (16 * 9);
-            const size_t src = (size_t)oc0 * 9 + rem;
-            if (tower == 1) {
-                v = P.reg_w[(size_t)o * C * 9 + src];
-            } else if (o < 2) {
-                v = P.cls_w[(size_t)o * C * 9 + src];
-            } else if (o == 2) {
-                v = P.center_w[src];
-            }
-        }
-        hwreg[j] = v;
-    }
+    // epilogue roles: thread (sub, ltid) works on tile tile0 + sub exactly as a 256-thread workgroup would
+    const int sub = tid >> 8, ltid = tid & 255;
+    const int etile = tile0 + sub;
+    const int tower = etile / tiles_per_tower;
+    const int oc0 = (etile - tower * tiles_per_tower) * 16;
 
     // ---- staging: ring of four 8-channel stages of raw response planes --------------------------------
-    float4 prs[2][2];                         // two stages in flight in registers
-    auto load_raw = [&](int st, float4* pr) {
+    // Global addresses are buffer resource + per-thread byte offset (set once) + wave-uniform SGPR offset: no
+    // vector instruction is spent on addressing inside the loop (every VALU instruction occupies the fp32 matrix
+    // pipe on gfx950 — profiles/r02_ubench_mfma_valu_overlap.jsonl).
+    auto make_rsrc = [](const float* base) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 0x7fffffff, 0x00020000);
+    };
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const auto rs_in = make_rsrc(in);
+    const auto rs_a = make_rsrc(packed);
+    float4 prs[2][RAW4];                      // two stages in flight in registers
+    unsigned raw_voff[RAW4];
+    int raw_lds[RAW4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int f = tid + 256 * j;
-            pr[j] = *reinterpret_cast<const float4*>(in + (size_t)(W_STAGE_IC * st + (f >> 6)) * 256 + (f & 63) * 4);
+    for (int j = 0; j < RAW4; ++j) {
+        const int f = tid + NT * j;
+        const int f4 = f & 63;
+        raw_voff[j] = (unsigned)((f >> 6) * 256 + f4 * 4) * 4u;
+        raw_lds[j] = (f >> 6) * W_PLANE + ((f4 >> 2) + 1) * W_ROW + 1 + (f4 & 3) * 4;
+    }
+    auto load_raw = [&](int st, float4* pr) {
+        const int soff = __builtin_amdgcn_readfirstlane(st * (W_STAGE_IC * 256 * 4));
+#pragma unroll
+        for (int j = 0; j < RAW4; ++j) {
+            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, raw_voff[j], soff, 0));
+            pr[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
         }
     };
     auto store_raw = [&](float* buf, const float4* pr) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int f = tid + 256 * j;
-            const int f4 = f & 63;
-            float* d = buf + (f >> 6) * W_PLANE + ((f4 >> 2) + 1) * W_ROW + 1 + (f4 & 3) * 4;
+        for (int j = 0; j < RAW4; ++j) {
+            float* d = buf + raw_lds[j];
             d[0] = pr[j].x;
             d[1] = pr[j].y;
             d[2] = pr[j].z;
             d[3] = pr[j].w;
         }
     };
-    const float* __restrict__ ua = packed + (((size_t)tile * nk) * 4 + wave) * 256 + lane * 4;   // + k*1024
-    f32x4 aset[2][2];                         // A operands: the stage in use and the next one
-    auto load_a = [&](int st, f32x4* dst) {
-        dst[0] = *reinterpret_cast<const f32x4*>(ua + (size_t)(2 * st) * 1024);
-        dst[1] = *reinterpret_cast<const f32x4*>(ua + (size_t)(2 * st + 1) * 1024);
+    // A operands: packed[tile][k][xi][lane][4]
+    const unsigned a_voff = (unsigned)lane * 16u;
+    const int a_base = __builtin_amdgcn_readfirstlane((int)((((size_t)tile0 * nk) * 4 + xi) * 1024));     // bytes
+    const int a_tile = nk * 4096;                                                                          // bytes
+    f32x4 aset[2][2][OCT];                    // A operands: [the stage in use / the next one][k-step][tile]
+    auto load_a = [&](int st, f32x4 (*dst)[OCT]) {
+#pragma unroll
+        for (int o = 0; o < OCT; ++o)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int soff = __builtin_amdgcn_readfirstlane(a_base + o * a_tile + (2 * st + k) * 4096);
+                dst[k][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff, soff, 0));
+            }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[OCT][4][2 * NP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int o = 0; o < OCT; ++o)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 2 * NP; ++t) acc[o][q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     load_raw(0, prs[0]);
     load_raw(1, prs[1]);
     load_a(0, aset[0]);
     if (ABL == 2 || ABL >= 5) {
-        aset[1][0] = aset[0][0]; aset[1][1] = aset[0][1];
+#pragma unroll
+        for (int o = 0; o < OCT; ++o) {
+            aset[1][0][o] = aset[0][0][o];
+            aset[1][1][o] = aset[0][1][o];
+        }
     }
+    // (first global loads are in flight: their latency covers the fill and the weight fetch)
+    {   // zero the stage buffers once: the halos stay zero for the whole main loop (a halo-only fill was measured
+        // slower: its scattered ds_write_b32 and index arithmetic cost more than 14 ds_write_b128 per thread)
+        float4* z = reinterpret_cast<float4*>(sm);
+        for (int e = tid; e < W_RING * W_BUF / 4; e += NT) z[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // Head taps of this tile's channels, fetched now, used in the epilogue — kept in NINE registers per lane: the
+    // 4x4x1 matrix instruction can broadcast the A operand of ONE of its 16 blocks to all blocks (CBSZ = 4, ABID =
+    // block), so block b of register r holds the four head weights (lane % 4 = output) of tap r*16 + b, and the
+    // epilogue's 144 instructions name their tap through ABID.  No LDS image of the taps, no LDS read per tap.
+    float hwv[9];
+    {
+        const int o = lane & 3, blk = lane >> 2;
+        const float* wsrc = (tower == 1) ? P.reg_w + (size_t)o * C * 9
+                                         : (o < 2 ? P.cls_w + (size_t)o * C * 9 : P.center_w);
+        const bool live = (tower == 1) || (o < 3);
+        wsrc += (size_t)oc0 * 9 + blk;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) hwv[r] = live ? wsrc[r * 16] : 0.0f;
+    }
+
     __syncthreads();                       // zero fill complete before interior writes
     store_raw(sm, prs[0]);
     store_raw(sm + W_BUF, prs[1]);
@@ -183,8 +229,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     __syncthreads();
 
     // rows of the 4x4 patch this wave's xi-row combines:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
-    const int row_a = (wave == 0) ? 0 : ((wave == 2) ? 2 : 1);
-    const int row_b = (wave == 2) ? 1 : ((wave == 3) ? 3 : 2);
+    const int row_a = (xi == 0) ? 0 : ((xi == 2) ? 2 : 1);
+    const int row_b = (xi == 2) ? 1 : ((xi == 3) ? 3 : 2);
     const int kq = lane >> 4, xl = lane & 15;
     // Lane (kq, xl) supplies input channel kq of the k-step and, for N-tile t, the 2x2-output tile
     //     ty = xl/4 + 4*(t/2),  tx = 2*(xl%4) + (t%2):
@@ -192,8 +238,10 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // ds_read_b64, both naturally aligned: haloed column 4*(xl%4)) serves both.  Banks: row stride 24 and
     // plane stride 448 put the four (plane, tile-row) classes of every 16-lane b128 group on disjoint
     // 16-bank windows; the b64 halves of planes 0/1 collide 2-way (4 instead of 2 LDS cycles).
-    const int patch0 = kq * W_PLANE + (2 * (xl >> 2)) * W_ROW + 4 * (xl & 3);
-    const int ia = patch0 + row_a * W_ROW, ib = patch0 + row_b * W_ROW;
+    // OCT = 1: the wave walks p = 0, 1;  OCT = 2: the wave owns p = nh.
+    const int patch0 = kq * W_PLANE + (2 * (xl >> 2) + (OCT == 2 ? 8 * nh : 0)) * W_ROW + 4 * (xl & 3);
+    int ia = patch0 + row_a * W_ROW, ib = patch0 + row_b * W_ROW;
+    asm volatile("" : "+v"(ia), "+v"(ib));   // two base registers; every (stage, k-step, pair) offset is an immediate
 
     // Main loop.  Stage = 8 input channels = 2 k-steps; ring of four stage buffers; one barrier per stage.
     // At the start of stage s: store the raw planes of stage s+2 (fetched two stages ago), fetch stage s+4 and
@@ -206,28 +254,24 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // Everything is branch-free (prefetch indices are clamped; the tail re-fetches the last stage): with guards
     // the waitcnt pass drains vmcnt at the top of every stage; the fences keep hipcc from sinking the prefetch
     // loads to their first use.
-    float rd[2][6][2];
-    float bop[4][4];
+    float rd[NP][6][2];
+    float bop[4][2 * NP];
     if (ABL >= 3) {
 #pragma unroll
-        for (int e = 0; e < 24; ++e) {
-            (&bop[0][0])[e & 15] = (float)(lane + e);
+        for (int e = 0; e < 12 * NP; ++e) {
+            (&bop[0][0])[e % (8 * NP)] = (float)(lane + e);
             (&rd[0][0][0])[e] = (float)(lane - e);
         }
     }
 #define W_READ(BUFI, Q, RD)                                                                      \
     if (ABL != 3 && ABL < 5) {                                                                   \
-        /* one laundered base per k-step so the pair offsets fold into the ds_read immediates */ \
-        int oa = ia + (BUFI) * W_BUF + (Q) * 4 * W_PLANE;                                        \
-        int ob = ib + (BUFI) * W_BUF + (Q) * 4 * W_PLANE;                                        \
-        asm volatile("" : "+v"(oa), "+v"(ob));                                                   \
-        __builtin_assume((oa & 3) == 0);                                                         \
-        __builtin_assume((ob & 3) == 0);                                                         \
-        _Pragma("unroll") for (int p = 0; p < 2; ++p) {          /* tile rows ty and ty + 4 */    \
-            const float4 a4 = *reinterpret_cast<const float4*>(sm + oa + p * 8 * W_ROW);         \
-            const float2 a2 = *reinterpret_cast<const float2*>(sm + oa + p * 8 * W_ROW + 4);     \
-            const float4 b4 = *reinterpret_cast<const float4*>(sm + ob + p * 8 * W_ROW);         \
-            const float2 b2 = *reinterpret_cast<const float2*>(sm + ob + p * 8 * W_ROW + 4);     \
+        const float* oa = sm + ia + ((BUFI) * W_BUF + (Q) * 4 * W_PLANE);                        \
+        const float* ob = sm + ib + ((BUFI) * W_BUF + (Q) * 4 * W_PLANE);                        \
+        _Pragma("unroll") for (int p = 0; p < NP; ++p) {         /* tile rows ty and ty + 4 */    \
+            const float4 a4 = *reinterpret_cast<const float4*>(oa + p * 8 * W_ROW);              \
+            const float2 a2 = *reinterpret_cast<const float2*>(oa + p * 8 * W_ROW + 4);          \
+            const float4 b4 = *reinterpret_cast<const float4*>(ob + p * 8 * W_ROW);              \
+            const float2 b2 = *reinterpret_cast<const float2*>(ob + p * 8 * W_ROW + 4);          \
             RD[p][0][0] = a4.x; RD[p][0][1] = b4.x;                                              \
             RD[p][1][0] = a4.y; RD[p][1][1] = b4.y;                                              \
             RD[p][2][0] = a4.z; RD[p][2][1] = b4.z;                                              \
@@ -237,7 +281,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         }                                                                                        \
     }
 #define W_XFORM(RD, BOP)                                                                         \
-    if (ABL != 3 && ABL < 5) _Pragma("unroll") for (int p = 0; p < 2; ++p) {                     \
+    if (ABL != 3 && ABL < 5) _Pragma("unroll") for (int p = 0; p < NP; ++p) {                    \
         /* six columns of the row combination d_a +- d_b, shared by the tile pair */             \
         float w[6];                                                                              \
         _Pragma("unroll") for (int c = 0; c < 6; ++c)                                            \
@@ -252,12 +296,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         BOP[3][2 * p + 1] = w[3] - w[5];                                                         \
     }
 #define W_MFMA(AV, BOP)                                                                          \
-    if (ABL != 4) _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                \
-        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[0], BOP[0][t], acc[0][t], 0, 0, 0);   \
-        acc[1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[1], BOP[1][t], acc[1][t], 0, 0, 0);   \
-        acc[2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[2], BOP[2][t], acc[2][t], 0, 0, 0);   \
-        acc[3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[3], BOP[3][t], acc[3][t], 0, 0, 0);   \
-    }
+    if (ABL != 4) _Pragma("unroll") for (int t = 0; t < 2 * NP; ++t)                             \
+        _Pragma("unroll") for (int o = 0; o < OCT; ++o) {                                        \
+            acc[o][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[o][0], BOP[0][t], acc[o][0][t], 0, 0, 0);   \
+            acc[o][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[o][1], BOP[1][t], acc[o][1][t], 0, 0, 0);   \
+            acc[o][2][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[o][2], BOP[2][t], acc[o][2][t], 0, 0, 0);   \
+            acc[o][3][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[o][3], BOP[3][t], acc[o][3][t], 0, 0, 0);   \
+        }
 #define W_FENCE __builtin_amdgcn_sched_barrier(0);
 #define W_STAGE(J)                                                                               \
     {                                                                                            \
@@ -288,7 +333,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         W_STAGE(3)                                                                               \
     }
     W_TRACE(1)
-    if (wave == 1) {             // the xi-row 1 combination adds its two patch rows, the others subtract
+    if (xi == 1) {               // the xi-row 1 combination adds its two patch rows, the others subtract
         constexpr bool PLUS = true;
         W_LOOP
     } else {
@@ -305,42 +350,35 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     W_TRACE(2)
 
     // ---- output transform --------------------------------------------------------------------------
-    // acc[q][t][r] = M_(i=wave, j=q)[oc = 4*kq + r][tile = 16t + xl].  Column half (j) in registers,
-    // row half (i) across the four waves through the exchange image X[i][b][oc][tile].
-    float* X = sm;
-    float* planes = sm + W_PL_OFF;
-    float* hw = sm + W_HW_OFF;
-    float* chs = sm + W_ST_OFF;            // [16] channel sums, [16] channel squared deviations
+    // acc[o][q][t][r] = M_(i=xi, j=q)[oc = 4*kq + r of tile o][tile = 16*(t + 2*NP*nh) + xl].  Column half (j) in
+    // registers, row half (i) across the four xi-waves through the exchange image X[i][b][oc][tile] of tile o.
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int o = 0; o < OCT; ++o)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p0 = (acc[0][t][r] + acc[1][t][r]) + acc[2][t][r];
-            const float p1 = (acc[1][t][r] - acc[2][t][r]) - acc[3][t][r];
-            float* dst = X + ((wave * 2) * 16 + (kq * 4 + r)) * W_XOC + 16 * t + xl;
-            dst[0] = p0;
-            dst[16 * W_XOC] = p1;
-        }
-    for (int e = tid; e < 16 * 68; e += 256) {          // halo of the head planes (interiors are written below)
+        for (int t = 0; t < 2 * NP; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p0 = (acc[o][0][t][r] + acc[o][1][t][r]) + acc[o][2][t][r];
+                const float p1 = (acc[o][1][t][r] - acc[o][2][t][r]) - acc[o][3][t][r];
+                float* dst = sm + o * W_EPI_FLOATS + ((xi * 2) * 16 + (kq * 4 + r)) * W_XOC +
+                             16 * (t + (OCT == 2 ? 2 * nh : 0)) + xl;
+                dst[0] = p0;
+                dst[16 * W_XOC] = p1;
+            }
+    float* X = sm + sub * W_EPI_FLOATS;
+    float* planes = X + W_PL_OFF;
+    float* chs = X + W_ST_OFF;             // [16] channel sums, [16] channel squared deviations
+    for (int e = ltid; e < 16 * 68; e += 256) {         // halo of the head planes (interiors are written below)
         const int pl = e / 68, c = e - pl * 68;
         const int row = c < 18 ? 0 : (c < 36 ? 17 : 1 + ((c - 36) >> 1));
         const int col = c < 18 ? c : (c < 36 ? c - 18 : (((c - 36) & 1) ? 17 : 0));
         planes[pl * T_PLANE + row * 18 + col] = 0.0f;
     }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < 16 * 36) {
-            const int o = idx / (16 * 9);
-            const int rem = idx - o * (16 * 9);
-            hw[rem * 4 + o] = hwreg[j];
-        }
-    }
     __syncthreads();
 
     W_TRACE(3)
-    // thread = (output channel ocl = tid/16, tiles 4*x16 + t): 4 tiles x 2x2 outputs, one ds_read_b128 per (i, b)
-    const int ocl = tid >> 4, x16 = tid & 15;
+    // thread = (output channel ocl = ltid/16, tiles 4*x16 + t): 4 tiles x 2x2 outputs, one ds_read_b128 per (i, b)
+    const int ocl = ltid >> 4, x16 = ltid & 15;
     float y[4][2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -362,11 +400,17 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #pragma unroll
     for (int t = 0; t < 4; ++t) s += (y[t][0][0] + y[t][0][1]) + (y[t][1][0] + y[t][1][1]);
     s = group16_sum(s);
-    if (x16 == 0) chs[ocl] = s;
-    __syncthreads();
+    float mean = 0.0f, var = 0.0f;
     const int g0 = (ocl / cpg) * cpg;
-    float mean = 0.0f;
-    for (int ch = g0; ch < g0 + cpg; ++ch) mean += chs[ch];
+    if (cpg == 4) {
+        // a group = 4 channels = the four 16-lane rows of THIS wave: no LDS, no barrier; rows are added in channel
+        // order, as the general path below does
+        mean = (((0.0f + __shfl(s, 0)) + __shfl(s, 16)) + __shfl(s, 32)) + __shfl(s, 48);
+    } else {
+        if (x16 == 0) chs[ocl] = s;
+        __syncthreads();
+        for (int ch = g0; ch < g0 + cpg; ++ch) mean += chs[ch];
+    }
     mean *= inv_cnt;
     float sq = 0.0f;
 #pragma unroll
@@ -379,10 +423,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
                 sq += d * d;
             }
     sq = group16_sum(sq);
-    if (x16 == 0) chs[16 + ocl] = sq;
-    __syncthreads();
-    float var = 0.0f;
-    for (int ch = g0; ch < g0 + cpg; ++ch) var += chs[16 + ch];
+    if (cpg == 4) {
+        var = (((0.0f + __shfl(sq, 0)) + __shfl(sq, 16)) + __shfl(sq, 32)) + __shfl(sq, 48);
+    } else {
+        if (x16 == 0) chs[16 + ocl] = sq;
+        __syncthreads();
+        for (int ch = g0; ch < g0 + cpg; ++ch) var += chs[16 + ch];
+    }
     const float rstd = 1.0f / sqrtf(var * inv_cnt + eps);
     const float ga = P.gamma[tower][oc0 + ocl], be = P.beta[tower][oc0 + ocl];
     {
@@ -405,24 +452,26 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     W_TRACE(4)
     // ---- fused partial heads: this tile's 16 channels x 9 taps -> 4 head outputs per position ---------
     // v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products per instruction, block = 4 neighbouring
-    // positions: A = the 4 head weights of one (channel, tap) (lane%4 = output), B = the lane's own activation,
-    // D[output][position] accumulates in 4 VGPRs per lane — the layout the stores below need.  256 MACs per
-    // 8-cycle instruction: twice the v_fmac rate with no padding waste, and half the instructions
-    // (2 LDS reads + 1 MFMA instead of 2 LDS reads + 4 FMAs per tap).  One fmaf chain per output, as before.
+    // positions: A = the 4 head weights of one (channel, tap) — broadcast from block ABID of a weight register
+    // (see hwv above) — B = the lane's own activation, D[output][position] accumulates in 4 VGPRs per lane, the
+    // layout the stores below need.  256 MACs per 8-cycle instruction, one LDS read (the activation) per tap, all
+    // 144 offsets immediates.  One fmaf chain per output in (channel, tap) order, as in predictor.hip.
     {
-        const int py = tid >> 4, px = tid & 15;
+        const int py = ltid >> 4, px = ltid & 15;
         f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
         const float* pl0 = planes + py * 18 + px;
-        const float* hwl = hw + (lane & 3);
-#pragma unroll 4
-        for (int cl = 0; cl < 16; ++cl) {
-            const float* pl = pl0 + cl * T_PLANE;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-                hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwl[(cl * 9 + tap) * 4], pl[(tap / 3) * 18 + (tap % 3)], hacc, 0,
-                                                          0, 0);
-        }
-        float* __restrict__ dst = part + ((size_t)n * tiles + tile) * 4 * 256 + tid;
+#define W_HEAD(ID)                                                                                          \
+    hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16], pl0[((ID) / 9) * T_PLANE + (((ID) % 9) / 3) * 18 + ((ID) % 9) % 3], \
+                                              hacc, 4, (ID) % 16, 0);
+#define W_HEAD16(R)                                                                                         \
+    W_HEAD((R) * 16 + 0) W_HEAD((R) * 16 + 1) W_HEAD((R) * 16 + 2) W_HEAD((R) * 16 + 3) W_HEAD((R) * 16 + 4)   \
+    W_HEAD((R) * 16 + 5) W_HEAD((R) * 16 + 6) W_HEAD((R) * 16 + 7) W_HEAD((R) * 16 + 8) W_HEAD((R) * 16 + 9)   \
+    W_HEAD((R) * 16 + 10) W_HEAD((R) * 16 + 11) W_HEAD((R) * 16 + 12) W_HEAD((R) * 16 + 13)                  \
+    W_HEAD((R) * 16 + 14) W_HEAD((R) * 16 + 15)
+        W_HEAD16(0) W_HEAD16(1) W_HEAD16(2) W_HEAD16(3) W_HEAD16(4) W_HEAD16(5) W_HEAD16(6) W_HEAD16(7) W_HEAD16(8)
+#undef W_HEAD16
+#undef W_HEAD
+        float* __restrict__ dst = part + ((size_t)n * tiles + etile) * 4 * 256 + ltid;
         dst[0 * 256] = hacc[0];
         dst[1 * 256] = hacc[1];
         dst[2 * 256] = hacc[2];
@@ -434,24 +483,55 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
                       float* part, unsigned* zero_words, hipStream_t st) {
-    const size_t smem = (size_t)W_SMEM_FLOATS * sizeof(float);     // 58,752 B: two workgroups per CU
     const int tiles = 2 * (C / 16);
-    const int grid = ((N + 7) / 8) * 8 * tiles;
-#define W_LAUNCH(A)                                                                                             \
-    hipLaunchKernelGGL(tower_wino_kernel<A>, dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, eps, part, \
-                       zero_words, g_trace)
+    // Two 16-channel tiles per workgroup (8 waves, 115 KB of LDS: one workgroup per CU) while that launch is a single
+    // dispatch round of the 256 CUs; beyond that the one-tile form (two independent workgroups per CU, finer
+    // rounds) is ahead — 100.2 vs 103.9 us at 100 tracks.  SMOT_TOWER_OCT = 1 / 2 forces a form in the measurement
+    // library.
+    int oct = ((N + 7) / 8) * 8 * (tiles / 2) <= 256 ? 2 : 1;
+    if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+    const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
+    const int grid = ((N + 7) / 8) * 8 * (tiles / oct);
+    if (oct == 2) {
+        static bool opted_in = false;          // > 64 KiB of dynamic LDS needs the attribute (once per process)
+        if (!opted_in) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            {
+                set_error("predictor towers (winograd): cannot opt in to %zu B of LDS", smem);
+                return SMOT_ERR_BAD_ARG;
+            }
+            opted_in = true;
+        }
+    }
+#define W_LAUNCH(A, O)                                                                                            \
+    hipLaunchKernelGGL((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, \
+                       part, zero_words, g_trace)
 #ifdef SMOT_DEBUG
-    switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only
-        case 1: W_LAUNCH(1); break;
-        case 2: W_LAUNCH(2); break;
-        case 3: W_LAUNCH(3); break;
-        case 4: W_LAUNCH(4); break;
-        case 5: W_LAUNCH(5); break;
-        case 6: W_LAUNCH(6); break;
-        default: W_LAUNCH(0); break;
+    if (oct == 1) {
+        switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only
+            case 1: W_LAUNCH(1, 1); break;
+            case 2: W_LAUNCH(2, 1); break;
+            case 3: W_LAUNCH(3, 1); break;
+            case 4: W_LAUNCH(4, 1); break;
+            case 5: W_LAUNCH(5, 1); break;
+            case 6: W_LAUNCH(6, 1); break;
+            default: W_LAUNCH(0, 1); break;
+        }
+    } else {
+        switch (knobs().wino_abl) {
+            case 3: W_LAUNCH(3, 2); break;
+            case 4: W_LAUNCH(4, 2); break;
+            case 6: W_LAUNCH(6, 2); break;
+            default: W_LAUNCH(0, 2); break;
+        }
     }
 #else
-    W_LAUNCH(0);
+    if (oct == 2) {
+        W_LAUNCH(0, 2);
+    } else {
+        W_LAUNCH(0, 1);
+    }
 #endif
 #undef W_LAUNCH
     return check_launch("predictor towers (winograd)");

@@ -270,6 +270,24 @@ def test_predictor_vs_oracle(ops, n, c, ho, winograd):
     assert float(((logits - ref32).abs() / scale.float()).max()) < 2e-4
 
 
+def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
+    """The Winograd tower with two 16-channel tiles per workgroup (the default: every B operand feeds two MFMAs)
+    against the one-tile form kept in the measurement library: the same accumulation order per output, so the logits
+    must be bit-identical — C in {32, 96, 128, 256}, odd track counts included."""
+    rs = np.random.RandomState(77)
+    boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+    for n, c in ((1, 32), (5, 96), (30, 128), (3, 256), (11, 128)):
+        params = {k: _d(v) for k, v in gi.predictor_params(rs, c, boxes).items()}
+        resp = _d((rs.standard_normal((n, c, 16, 16)) * 15.0).astype(np.float32))
+        two = ops.emm_predictor(resp, params)
+        with ops.debug_library(SMOT_TOWER_OCT=1):
+            one = ops.emm_predictor(resp, params)
+        with ops.debug_library(SMOT_TOWER_OCT=2):
+            two_dbg = ops.emm_predictor(resp, params)
+        assert torch.equal(two, one), "n=%d C=%d: max diff %g" % (n, c, float((two - one).abs().max()))
+        assert torch.equal(two, two_dbg)
+
+
 def test_tower_pack_cache_follows_the_weights(ops):
     """The packed (Winograd-transformed) filters are a cache keyed on the weight tensors: an in-place update
     (load_state_dict) or a replacement must be picked up, otherwise stale filters would be used silently."""

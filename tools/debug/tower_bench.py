@@ -9,10 +9,11 @@ rs = np.random.RandomState(0)
 boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
 P = {k: torch.from_numpy(v).to(dev) for k, v in gi.predictor_params(rs, 128, boxes).items()}
 ABLS = os.environ.get("ABLS", "0").split(",")
+OCTS = [int(o) for o in os.environ.get("OCTS", "1,2").split(",")]       # 16-channel tiles per workgroup
 for n in (30, 100):
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
-    for abl in ABLS:
-      with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl)):
+    for abl, oct_ in [(a, o) for a in ABLS for o in (OCTS if a != "direct" else [0])]:
+      with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl), SMOT_TOWER_OCT=oct_):
         f = lambda: ops.emm_predictor(resp, P, winograd=(abl != "direct"))
         for _ in range(200): f()
         torch.cuda.synchronize()
@@ -22,12 +23,12 @@ for n in (30, 100):
             for _ in range(300): f()
             ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
             ts.append(ms / cnt * 1e3)
-        print(json.dumps({"tracks": n, "variant": abl, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
+        print(json.dumps({"tracks": n, "variant": abl, "tiles_per_wg": oct_, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
 # phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
-lib = ops.load_library()
-for n in (30, 100):
+for n, oct_ in [(n, o) for n in (30, 100) for o in OCTS]:
+  with ops.debug_library(SMOT_TOWER_OCT=oct_) as lib:
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
-    grid = (n + 7) // 8 * 8 * 16
+    grid = (n + 7) // 8 * 8 * 16 // oct_
     tr = torch.zeros(grid * 8, dtype=torch.int64, device=dev)
     lib.smot_debug_trace(ops._ptr(tr))
     ops.emm_predictor(resp, P); torch.cuda.synchronize()
@@ -37,11 +38,11 @@ for n in (30, 100):
     t = t[t[:, 5] != 0]
     t0 = t[:, 0].min()
     d = np.diff(t[:, :6], axis=1)
-    print(json.dumps({"tracks": n, "blocks": len(t), "phase_ticks_mean": [round(float(x), 1) for x in d.mean(0)],
+    print(json.dumps({"tracks": n, "tiles_per_wg": oct_, "blocks": len(t), "phase_ticks_mean": [round(float(x), 1) for x in d.mean(0)],
                       "phase_ticks_max": [int(x) for x in d.max(0)], "block_total_mean": round(float((t[:, 5] - t[:, 0]).mean()), 1),
                       "kernel_span_ticks": int(t[:, 5].max() - t0), "start_spread": int(t[:, 0].max() - t0)}), flush=True)
 
-    if n == 30:
+    if n == 30 and oct_ == OCTS[-1]:
         tt = tr.view(grid, 8).cpu().numpy()
         hw, xcc = tt[:, 6], tt[:, 7]
         cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; xc = xcc & 0xF
