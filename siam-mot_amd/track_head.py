@@ -3,12 +3,15 @@
 Mirrors ``TrackHead`` (reference siammot/modelling/track_head/track_head.py:8-126, inference branch) and the
 tracking part of ``CombinedROIHeads.forward`` / ``SiamMOT.forward`` (modelling/roi_heads.py:22-52, rcnn.py:34-62).
 The reference classes work unchanged with the HIP ``EMM`` module; this restatement exists so that
-the whole tracker — head, solver, pool — can run from this repository with a handful of host synchronisations per
-frame (the reference writes one boolean per track into a device tensor, track_head.py:103-108).
+the whole tracker — head, solver, pool — can run from this repository with ONE host synchronisation per frame (the
+reference writes one boolean per track into a device tensor, track_head.py:103-108).
 
 ``TrackingLoop`` is the detector-agnostic frame step: FPN features + this frame's detections in, tracked boxes out.
-The box-head refinement of the propagated boxes (``_refine_tracks``, roi_heads.py:60-84) belongs to the detector and
-is an optional callable.
+Per frame it enqueues the head (3 launches), the one-launch solver and the masked template extraction of the rows the
+solver leaves active, then synchronises once on the solver's record (``_step_lean``; the general path covers other
+solvers, CPU tensors and a ``refine_tracks`` callable).  The box-head refinement of the propagated boxes
+(``_refine_tracks``, roi_heads.py:60-84) belongs to the detector: ``siammot_amd.box_refine.RefineTracks`` wraps any
+box head with the reference's call signature.
 """
 import copy
 
