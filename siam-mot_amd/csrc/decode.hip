@@ -85,6 +85,26 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// Wave-wide maxima without LDS-crossbar round trips: four DPP row rotations leave every lane with its 16-lane row's
+// maximum, four v_readlane + scalar max make it wave-uniform.  (The __shfl_xor butterfly is twelve dependent
+// ds_bpermute trips for a 64-bit key: ~1.2 k cycles per reduction.)  All 64 lanes must be active.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#define SMOT_ROR(N) (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (N), 0xf, 0xf, false)
+    v = max(v, SMOT_ROR(8));
+    v = max(v, SMOT_ROR(4));
+    v = max(v, SMOT_ROR(2));
+    v = max(v, SMOT_ROR(1));
+#undef SMOT_ROR
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {   // lexicographic: score, then ~index
+    const unsigned hi = wave_max_u32((unsigned)(k >> 32));
+    const unsigned lo = wave_max_u32(((unsigned)(k >> 32) == hi) ? (unsigned)k : 0u);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 struct DecodeParams {
     int Ho, up, G;
     float inv_up;
@@ -294,20 +314,16 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         });
     }
     DC_TRACE(2)
-    unsigned long long wg = best;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(wg, m);
-        wg = (o > wg) ? o : wg;
-    }
+    // only the best fast SCORE of the band is needed here (the nomination threshold): a 32-bit maximum
+    const unsigned ws = wave_max_u32((unsigned)(best >> 32));
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) wbest[wave] = wg;
+    if ((threadIdx.x & 63) == 0) wbest[wave] = ws;
     __syncthreads();
-    wg = wbest[0];
+    unsigned wgs = wbest[0];
 #pragma unroll
-    for (int w = 1; w < 4 * SPLIT; ++w) wg = (wbest[w] > wg) ? wbest[w] : wg;
+    for (int w = 1; w < 4 * SPLIT; ++w) wgs = max(wgs, wbest[w]);
     // nomination threshold in key space: fast score >= best fast score - DEC_TOL (NaN best: only NaN cells)
-    const unsigned thr = score_key(key_score((unsigned)(wg >> 32)) - DEC_TOL);
+    const unsigned thr = score_key(key_score(wgs) - DEC_TOL);
 
     DC_TRACE(3)
     // ---- exact re-scoring of the nominated cells (the reference's rounding sequence) ----------------------------
@@ -426,12 +442,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
             bband = b;
         }
     }
-    unsigned long long top = bk;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(top, m);
-        top = (o > top) ? o : top;
-    }
+    const unsigned long long top = wave_max_u64(bk);
     if (lane == 0) __hip_atomic_store((gu32_t*)(F.ticket + n), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (top == 0ull || bk != top) return;          // keys are unique per cell index: exactly one lane continues
     const gu64_t* wr = recs + (size_t)bband * DEC_REC;
