@@ -21,7 +21,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
 LIB_DEBUG = os.path.join(CSRC, "libsmot_emm_debug.so")
 DEBUG_ONLY_SOURCES = ["xcorr_variants.hip"]
-SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "preprocess.hip",
+SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "tower_conv.hip", "preprocess.hip",
            "emm_fused.hip", "track_solver.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of

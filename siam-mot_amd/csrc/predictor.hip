@@ -400,7 +400,7 @@ struct HeadsParams {
 // kernel arguments and loop counters, so they are fetched with scalar loads and used as the SGPR
 // operand of v_fmac — no LDS traffic, no VGPRs, no per-lane global loads for weights.
 constexpr int H_IC = 16;
-constexpr int H_MAXPOS = 4;     // positions per thread for Ho*Ho up to 1024
+constexpr int H_MAXPOS = 4;     // position chunks of 256 (grid z) for Ho*Ho up to 1024
 
 template <int NPOS>
 __global__ void __launch_bounds__(256)
@@ -418,10 +418,11 @@ heads_kernel(const float* __restrict__ tower_ws, HeadsParams H, int C, int Ho, f
     const float* __restrict__ w3 = reg_side ? H.reg_w + 3 * C9 : H.center_w;
     const float* __restrict__ in = tower_ws + ((size_t)n * 2 * C + (reg_side ? C : 0)) * HW;
 
+    const int pos0 = blockIdx.z * 256 * NPOS;          // grid z = position chunk (maps larger than 256 cells)
     int off[NPOS];
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
-        const int pos = min((int)threadIdx.x + p * 256, HW - 1);
+        const int pos = min(pos0 + (int)threadIdx.x + p * 256, HW - 1);
         const int y = pos / Ho, x = pos - y * Ho;
         off[p] = y * PW + x;
     }
@@ -471,7 +472,7 @@ heads_kernel(const float* __restrict__ tower_ws, HeadsParams H, int C, int Ho, f
     bias[3] = reg_side ? H.reg_b[3] : 0.0f;
 #pragma unroll
     for (int p = 0; p < NPOS; ++p) {
-        const int pos = threadIdx.x + p * 256;
+        const int pos = pos0 + threadIdx.x + p * 256;
         if (pos < HW) {
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
@@ -598,13 +599,16 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
 #undef SMOT_COMBINE
         return check_launch("predictor heads combine");
     }
-    {
+    // the reference's second shape family (Ho = 29) has a matrix-core kernel of its own; anything else: scalar
+    int rc = launch_tower_conv(resp, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits, st);
+    if (rc == SMOT_OK) return SMOT_OK;
+    if (rc == SMOT_ERR_UNSUPPORTED) {
         const size_t smem = (size_t)cpg * Ho * Ho * sizeof(float);
         SMOT_REQUIRE(smem <= 64 * 1024, "predictor: GroupNorm group too large for the generic tower kernel");
         hipLaunchKernelGGL(tower_generic_kernel, dim3(N * 2 * gn_groups), dim3(256), smem, st, resp, T, C, Ho, cpg,
                            gn_eps, tower_ws);
+        rc = check_launch("predictor towers");
     }
-    int rc = check_launch("predictor towers");
     if (rc) return rc;
 
     HeadsParams H;
@@ -616,13 +620,10 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
     H.reg_b = reg_b;
     const size_t hsmem = (size_t)H_IC * (Ho + 2) * (Ho + 2) * sizeof(float);
     SMOT_REQUIRE(hsmem <= 64 * 1024, "predictor: Ho=%d too large for the heads kernel", Ho);
-    if (Ho * Ho <= 256) {
-        hipLaunchKernelGGL(heads_kernel<1>, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H, C, Ho,
-                           logits);
-    } else {
-        hipLaunchKernelGGL(heads_kernel<H_MAXPOS>, dim3(N, 2), dim3(256), hsmem, st, (const float*)tower_ws, H, C,
-                           Ho, logits);
-    }
+    // one position per thread, position chunks of 256 on grid z: 4x the workgroups of the former 4-positions-per-
+    // thread form for a 29x29 map (60 workgroups left three quarters of the chip idle: 177 us)
+    hipLaunchKernelGGL(heads_kernel<1>, dim3(N, 2, (Ho * Ho + 255) / 256), dim3(256), hsmem, st,
+                       (const float*)tower_ws, H, C, Ho, logits);
     return check_launch("predictor heads");
 }
 }  // namespace smot

@@ -37,4 +37,10 @@ constexpr int T_PLANE = 336;                      // 18*18 = 324 padded to 336
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
                       float* part, unsigned* zero_words, hipStream_t st);
 
+// tower_conv.hip: towers + heads of a response map other than 16x16 on the matrix cores (instantiated for Ho = 29,
+// the reference's second yaml family): logits complete on return; SMOT_ERR_UNSUPPORTED when no instantiation fits
+int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int Ho, int cpg, float eps,
+                      const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws, float* logits,
+                      hipStream_t st);
+
 }  // namespace smot

@@ -249,10 +249,12 @@ def test_xcorr_rejects_bad_inputs(ops):
 # K3: predictor
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("winograd", [True, False])
-@pytest.mark.parametrize("n,c,ho", [(3, 64, 16), (2, 128, 16), (1, 256, 16), (2, 32, 29), (2, 96, 16), (9, 128, 16)])
+@pytest.mark.parametrize("n,c,ho", [(3, 64, 16), (2, 128, 16), (1, 256, 16), (2, 32, 29), (2, 96, 16), (9, 128, 16),
+                                    (2, 128, 29), (3, 64, 29), (1, 96, 29), (2, 32, 21)])
 def test_predictor_vs_oracle(ops, n, c, ho, winograd):
     """Matrix-core towers (Ho=16, C in {64,128,256}: Winograd F(2x2,3x3) with the packed filters, or the direct
-    kernel) and the generic kernel (Ho=29; C=96 -> 3 ch/group).  Same tolerance for both tower kernels."""
+    kernel; Ho=29, the reference's second yaml family: direct implicit GEMM, tower_conv.hip) and the scalar generic
+    kernel (C=96 -> 3 channels per group; Ho=21).  Same tolerance for all tower kernels."""
     rs = np.random.RandomState(100 + c + ho)
     boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
     params = gi.predictor_params(rs, c, boxes)
