@@ -26,6 +26,8 @@ struct Knobs {
     int xcorr_variant = 0;   // SMOT_XCORR_VARIANT : XcorrVariant (wave|patch|pk|one|mfma|fill|compute)
     int decode_two_pass = 0; // SMOT_DECODE_2PASS  : band kernel + separate finalize launch (round-1 structure)
     int fused_gen = 0;       // SMOT_FUSED_GEN     : 0 = current fused pooling kernel, 2 = round-1 kernel
+    int fused_order = 0;     // SMOT_FUSED_ORDER   : workgroup -> roi assignment of the pooling kernels (0 = default,
+                             //                      1..3 = cost-sorted forms, 4 = grid order; sr_xcorr.hip fx_assign)
     int tower_oct = 0;       // SMOT_TOWER_OCT     : 16-channel tiles per Winograd workgroup (0 = default, 1 or 2)
     // timing ablations: WRONG results, measurement builds only
     int fused_abl = 0;       // SMOT_FUSED_ABL

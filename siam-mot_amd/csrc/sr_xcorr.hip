@@ -42,6 +42,8 @@ struct SrOut {
                           // branch makes hipcc wait for every pair of loads (measured +2 us).
     const int* n_valid;   // device count of valid rois, or nullptr: rois >= *n_valid are skipped (the launch covers
                           // a CAPACITY when the count is still on the device — smot_emm_extract_cache_masked_fwd)
+    int order;            // workgroup -> (roi, channel group) assignment: 0 = grid order, 1..3 = cost-sorted forms
+                          // (fx_assign below; the measurement library can select any, SMOT_FUSED_ORDER)
 };
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
@@ -321,6 +323,134 @@ __device__ __forceinline__ float rl_f(float v, int lane_const) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
 }
 
+// Which (roi, channel group) a workgroup takes.  The grid is (rois, channel groups) and the hardware dispatches
+// workgroups in linear order (x fastest), L and L + 256 onto the same CU while the launch fits the chip; a roi whose
+// window is wider than 32 columns costs about twice a narrow one (two row blocks per plane), so the order in which
+// rois appear in the caller's tensor decided how evenly the CUs were loaded (tools/debug/pairing_probe.py: the same 30
+// boxes, 18.9 us in the benchmark's size-cycling order, 17.6 us sorted by width; 49.2 vs 42.5 us at 100).  Every
+// workgroup therefore ranks the rois by a cost class itself — lane = roi, three ballots per 64 rois, all wave-uniform
+// — and takes its item from the cost-sorted list; results do not depend on the assignment (it is a bijection).
+//   order 1: item i = L of the list sorted by (class descending, roi, channel group)
+//   order 2: the first 256 workgroups take the list from the front, the next 256 from the back (expensive with cheap
+//            on a CU), the rest the middle in descending order
+//   order 3: grid position x -> the roi of rank x (channel group = grid y, as in grid order)
+// Rois at or past *n_valid keep their own index (they return at once).  More than 256 rois: grid order.
+// Returns true when the roi's box and FPN level are handed back as well (read out of the lane that ranked it: the
+// workgroup's own roi loads — a second dependent memory round trip — are then not needed).
+__device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __restrict__ sr,
+                                          const float* __restrict__ boxes, const int* __restrict__ n_valid, int order,
+                                          int lane, int* n_out, int* cg_out, float4* roi_out, int* lvl_out) {
+    const int NT = gridDim.x, ny = gridDim.y;
+    int n = blockIdx.x, cg = blockIdx.y;
+    *n_out = n;
+    *cg_out = cg;
+    if (order == 0 || NT > 256 || NT < 2) return false;
+    const int nv = (n_valid != nullptr) ? min(*n_valid, NT) : NT;
+    const int T = NT * ny, L = blockIdx.y * NT + blockIdx.x;
+    constexpr int SLOTS = 256;                       // CUs: one workgroup each per dispatch round
+    int i = L;
+    if (order == 2) {
+        const int r = L / SLOTS, q = L - r * SLOTS;
+        if (r == 1) {
+            i = T - 1 - q;
+        } else if (r >= 2) {
+            i = SLOTS + (L - 2 * SLOTS);
+        }
+    }
+    int k;
+    if (order == 3) {
+        k = blockIdx.x;
+    } else {
+        k = i / ny;
+        cg = i - k * ny;
+    }
+    *cg_out = cg;
+    if (k >= nv) {
+        *n_out = k;
+        return false;
+    }
+    unsigned long long mask[4][3];
+    int cnt[3] = {0, 0, 0};
+    float rbx[4], rby[4], rbz[4], rbw[4];
+    int rl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int cls = -1;
+        const int t = lane + 64 * p;
+        rbx[p] = rby[p] = rbz[p] = rbw[p] = 0.0f;
+        rl[p] = 0;
+        if (64 * p < nv && t < nv) {
+            int lvl = 0;
+            if (P.num_levels > 1) lvl = map_level(boxes + (size_t)t * 4, P.k_min, P.k_max);
+            float scale = P.scale[0];
+#pragma unroll
+            for (int l = 1; l < SMOT_MAX_LEVELS; ++l) scale = (lvl == l) ? P.scale[l] : scale;
+            const float4 b4 = *reinterpret_cast<const float4*>(sr + (size_t)t * 4);
+            rbx[p] = b4.x;
+            rby[p] = b4.y;
+            rbz[p] = b4.z;
+            rbw[p] = b4.w;
+            rl[p] = lvl;
+            const float ww = (b4.z - b4.x) * scale;                                         // window width in cells
+            cls = ww <= 30.0f ? 0 : (ww <= 62.0f ? 1 : 2);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mask[p][c] = __ballot(cls == c);
+            cnt[c] += __popcll(mask[p][c]);
+        }
+    }
+    int m = k, csel = 2;
+    if (m >= cnt[2]) {
+        m -= cnt[2];
+        csel = 1;
+        if (m >= cnt[1]) {
+            m -= cnt[1];
+            csel = 0;
+        }
+    }
+    int psel = 0;
+    bool done = false;
+    unsigned long long msel = 0ull;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const unsigned long long mk = csel == 2 ? mask[p][2] : (csel == 1 ? mask[p][1] : mask[p][0]);
+        const int pc = __popcll(mk);
+        if (!done) {
+            if (m < pc) {
+                psel = p;
+                msel = mk;
+                done = true;
+            } else {
+                m -= pc;
+            }
+        }
+    }
+    const unsigned long long below = msel & ((1ull << lane) - 1ull);
+    const bool hit = ((msel >> lane) & 1ull) != 0ull && __popcll(below) == m;
+    const unsigned long long b = __ballot(hit);
+    if (b == 0ull) return false;                                  // (cannot happen: k < nv)
+    const int ln = __ffsll((long long)b) - 1;
+    *n_out = ln + 64 * psel;
+    float sx = rbx[0], sy = rby[0], sz = rbz[0], sw = rbw[0];
+    int lsel = rl[0];
+#pragma unroll
+    for (int p = 1; p < 4; ++p)
+        if (psel == p) {                                         // wave-uniform
+            sx = rbx[p];
+            sy = rby[p];
+            sz = rbz[p];
+            sw = rbw[p];
+            lsel = rl[p];
+        }
+    roi_out->x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), ln));
+    roi_out->y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sy), ln));
+    roi_out->z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sz), ln));
+    roi_out->w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sw), ln));
+    *lvl_out = __builtin_amdgcn_readlane(lsel, ln);
+    return true;
+}
+
 template <int RX, int RZ, int G, bool XCORR>
 __global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
@@ -340,19 +470,34 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
-    const int n = blockIdx.x;
+    const long long t_start = S.trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
+    int n_assigned, cg_assigned, lvl_assigned = 0;
+    float4 roi_assigned = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool have_roi =
+        fx_assign(P, sr, boxes, S.n_valid, S.order, lane, &n_assigned, &cg_assigned, &roi_assigned, &lvl_assigned);
+    const int n = __builtin_amdgcn_readfirstlane(n_assigned);
+    const int cgrp = __builtin_amdgcn_readfirstlane(cg_assigned);
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
+    // (trace rows are indexed by the item, not by the workgroup that happened to take it)
 #define FX_TRACE(SLOT)                                                                      \
     if (S.trace && tid == 0)                                                                \
-        S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
-    FX_TRACE(0)
+        S.trace[((size_t)n * gridDim.y + cgrp) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    if (S.trace && tid == 0) S.trace[((size_t)n * gridDim.y + cgrp) * 8 + 0] = t_start;
 
-    const float* roi = sr + (size_t)n * 4;
-    int lvl = 0;
-    if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
+    float roi0 = roi_assigned.x, roi1 = roi_assigned.y, roi2 = roi_assigned.z, roi3 = roi_assigned.w;
+    int lvl = lvl_assigned;
+    if (!have_roi) {                             // workgroup-uniform
+        roi0 = sr[(size_t)n * 4 + 0];
+        roi1 = sr[(size_t)n * 4 + 1];
+        roi2 = sr[(size_t)n * 4 + 2];
+        roi3 = sr[(size_t)n * 4 + 3];
+        lvl = 0;
+        if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
+    }
+    const float roi[4] = {roi0, roi1, roi2, roi3};
     lvl = __builtin_amdgcn_readfirstlane(lvl);
-    if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
-    if (!XCORR && S.sr != nullptr && blockIdx.y == 0 && tid == 0) {
+    if (levels_out != nullptr && cgrp == 0 && tid == 0) levels_out[n] = lvl;
+    if (!XCORR && S.sr != nullptr && cgrp == 0 && tid == 0) {
         const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
         const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
         const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
@@ -375,7 +520,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // workgroups no longer fit the chip's 512 resident slots (two rounds: 18.7 -> 24 us), and at three workgroups
     // per CU — 74 VGPRs with the one-plane correlation below — the kernel still took 23.0 us.)
     constexpr int nplanes = FX_CH;
-    const int c0 = blockIdx.y * FX_CH;
+    const int c0 = cgrp * FX_CH;
     // template of this wave's plane: issue the loads now, park them in LDS after the tables
     const bool owns = (wave < nplanes && c0 + wave < C);  // channel tails / four-plane workgroups: no plane here
     const int plane = n * C + c0 + wave;
@@ -629,6 +774,11 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
 // Launch the pooling(+correlation) kernel: generation 3 in the product library; the measurement library can
 // select generation 2 (SMOT_FUSED_GEN=2) for A/B runs.
 namespace smot {
+constexpr int FX_ORDER_DEFAULT = 1;
+static inline int fused_order() {          // SMOT_FUSED_ORDER: 0 = default, 1..3 = a form of fx_assign, 4 = grid order
+    const int k = knobs().fused_order;
+    return k == 0 ? FX_ORDER_DEFAULT : (k == 4 ? 0 : k);
+}
 template <int RX, bool XCORR>
 static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C, const float* rois, const float* boxes,
                          const float* z, float* resp, float* out, int32_t* levels_out, const SrOut& S) {
@@ -647,7 +797,7 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order()};
     if (out_size == 30) {
         launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     } else {
@@ -665,7 +815,7 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid};
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order()};
     launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
     return check_launch("emm_extract_cache");
 }
@@ -690,7 +840,7 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (rc) return rc;
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, (hipStream_t)stream);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order()};
     launch_fused<30, true>(grid, (hipStream_t)stream, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
     timer_mark(0, 1, (hipStream_t)stream);
     return check_launch("sr_xcorr_fused");

@@ -879,6 +879,37 @@ def test_fused_pooling_generation3_is_bitwise_generation2(ops, n):
     assert torch.equal(r3, r2), "responses: max diff %g" % float((r3 - r2).abs().max())
 
 
+@pytest.mark.parametrize("n", [1, 2, 30, 65, 100, 130, 260])
+def test_cost_sorted_workgroup_assignment_is_a_bijection(ops, n):
+    """The pooling kernels rank the rois by window width and hand the expensive ones out first (sr_xcorr.hip
+    fx_assign): which workgroup takes which (roi, channel group) must not change a single bit — against grid order
+    (measurement library, SMOT_FUSED_ORDER=4), for roi counts below / at / above one and two 64-roi ranking passes and
+    above the 256-roi limit of the ranking, random box sizes (all three width classes), and the masked launch."""
+    rs = np.random.RandomState(900 + n)
+    g = torch.Generator().manual_seed(n)
+    C = 16
+    feats = tuple(torch.randn((1, C, 704 // s, 1280 // s), generator=g).to(DEV) for s in (4, 8, 16, 32))
+    wh = np.exp(rs.uniform(np.log(20), np.log(500), (n, 1))) * np.array([[1.0, 1.7]])
+    xy = rs.uniform(0, 1, (n, 2)) * np.maximum(np.array([1280.0, 704.0]) - wh, 1.0)
+    boxes = _d(np.concatenate((xy, xy + wh), 1).astype(np.float32))
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    sr = ops.search_region(boxes, 512, 1.0, 0)
+
+    def run():
+        z = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)
+        r = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512)
+        cz, csr = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0)
+        nv = torch.tensor([max(n - 3, 0)], dtype=torch.int32, device=DEV)
+        mz, msr = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0, n_valid=nv)
+        return z, r, cz, csr, mz[:max(n - 3, 0)], msr[:max(n - 3, 0)]
+    sorted_ = run()
+    with ops.debug_library(SMOT_FUSED_ORDER=4):
+        grid = run()
+    for a, b in zip(sorted_, grid):
+        assert torch.equal(a, b)
+    assert torch.equal(sorted_[2], sorted_[0]) and torch.equal(sorted_[4], sorted_[0][:max(n - 3, 0)])
+
+
 def test_fused_pooling_odd_channel_counts_and_wide_windows(ops):
     """Channel counts that leave plane pairs / workgroups half empty (C = 5, 9, 12), and windows wider than a wave
     (chunked path): against the oracle, and the fused response against the stand-alone composition."""
