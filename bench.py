@@ -276,13 +276,17 @@ def tracking_loop_throughput(n, dev, feats, steps=300):
                     "the device; one host synchronisation per frame"}
 
 
-def tower_roofline(n, total_ms, launches, bracket_us):
+TIMER_NOTE = ("kernel start/stop events on the launch stream (hipExtLaunchKernel: the dispatch's own begin/end "
+              "timestamps, the quantity rocprofv3 reports), every %d-th step of the timed region" % TIMER_STRIDE)
+
+
+def tower_roofline(n, total_ms, launches):
     algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
-    sec = total_ms * 1e-3 / launches                     # raw event span (includes part of the bracket's own span)
+    sec = total_ms * 1e-3 / launches
     return {
-        "bound": "mfma", "kernel": "tower_wino_kernel<0> (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)",
-        "flops_per_launch": algo, "avg_launch_us": sec * 1e6, "event_bracket_overhead_us": bracket_us,
+        "bound": "mfma", "kernel": "tower_wino_kernel<0,2> (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)",
+        "flops_per_launch": algo, "avg_launch_us": sec * 1e6,
         "achieved": algo / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": algo / sec / 1e12 / 157.3,
         "executed_mfma_flops_per_launch": executed, "executed_frac_of_peak": executed / sec / 1e12 / 157.3,
         "launches_timed": launches,
@@ -531,11 +535,9 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, dev)
     backend = torch.distributed.get_backend() if parallel.is_distributed() else "none"
     dist_world = torch.distributed.get_world_size() if parallel.is_distributed() else 1
-    # A bracketed span = kernel + part of the bracket's own span.  The span of an EMPTY bracket on the same stream
-    # (two hipEventRecords back to back, ~4.6 us on MI355X) is reported next to the spans as an upper bound of that
-    # share; `achieved` uses the RAW spans (conservative: rocprofv3 durations in profiles/ are 2-3 us shorter, and
-    # raw minus empty-bracket is 2 us shorter still than rocprofv3).
-    bracket_us = 0.0 if args.no_kernel_timer else ops.kernel_timer_bracket_overhead(200)
+    # The timed launches carry a start/stop event pair of their own (hipExtLaunchKernel): the elapsed time between
+    # the two is the kernel's duration as rocprofv3 sees it.  (Round 1 bracketed the launch with two hipEventRecord
+    # markers instead: that span ran 2.5-3.5 us above the kernel's duration.)
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
     if rank != 0:
@@ -613,7 +615,7 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": fused_bytes,
-            "avg_launch_us": xcorr_avg_s * 1e6, "event_bracket_overhead_us": bracket_us, "launches_timed": xcorr_launches,
+            "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer": TIMER_NOTE,
             "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },
@@ -621,7 +623,7 @@ def main():
         # the direct convolution the reference computes; the kernel runs it as Winograd F(2x2,3x3) on the fp32
         # matrix cores, i.e. it EXECUTES 2.25x fewer multiply-adds (reported separately, with the matrix-pipe
         # fraction they amount to).
-        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches, bracket_us),
+        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
         "parity": parity,
         "cache_warm_loop": warm,
         "multi_stream": multi,

@@ -101,30 +101,42 @@ extern "C" void smot_debug_trace(long long* buf) { smot::g_trace = buf; }
 
 extern "C" const char* smot_last_error(void) { return smot::g_err; }
 
-// ---- instrumentation: HIP events recorded on the launch stream around selected kernels --------------
+// ---- instrumentation: kernel start / stop events of selected launches --------------------------------
 // slot 0: cross-correlation (stand-alone or fused with the search-region pooling); slot 1: tower MFMA.
 namespace smot {
 struct EventTimer {
     hipEvent_t* ev = nullptr;
     int capacity = 0;
     int used = 0;
-    int stride = 1;       // bracket every stride-th launch only (an event pair costs ~3 us of stream time)
+    int stride = 1;       // time every stride-th launch only
     int seen = 0;         // launches seen since _begin
-    bool open = false;    // the current launch is being bracketed
+    bool open = false;    // the current region is sampled
+    bool taken = false;   // ... and a launch has picked the event pair up
 };
 static EventTimer g_timers[2];
+static EventTimer* g_pending = nullptr;     // the sampled region waiting for its launch (one stream of launches)
 
-void timer_mark(int slot, int end, hipStream_t st) {
+void timer_mark(int slot, int end, hipStream_t) {
     EventTimer& t = g_timers[slot];
     if (t.ev == nullptr) return;
     if (!end) {
         t.open = (t.seen++ % t.stride == 0) && (t.used + 2 <= t.capacity);
-        if (t.open) (void)hipEventRecord(t.ev[t.used], st);
+        t.taken = false;
+        g_pending = t.open ? &t : nullptr;
     } else if (t.open) {
-        (void)hipEventRecord(t.ev[t.used + 1], st);
-        t.used += 2;
+        if (t.taken) t.used += 2;           // a region whose kernels did not go through SMOT_LAUNCH leaves no sample
         t.open = false;
+        g_pending = nullptr;
     }
+}
+
+bool timer_take(hipEvent_t* start, hipEvent_t* stop) {
+    EventTimer* t = g_pending;
+    if (t == nullptr || t->taken) return false;
+    *start = t->ev[t->used];
+    *stop = t->ev[t->used + 1];
+    t->taken = true;
+    return true;
 }
 }  // namespace smot
 

@@ -565,7 +565,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
             if (rcw) return rcw;
             if (zeroed) *zeroed = (zero_words != nullptr);
         } else if (!narrow) {
-            hipLaunchKernelGGL((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+            SMOT_LAUNCH((tower_mfma_kernel<2, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
 #ifdef SMOT_DEBUG
         } else if (abl == 1) {
             hipLaunchKernelGGL((tower_mfma_kernel<1, 1>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
@@ -573,7 +573,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
             hipLaunchKernelGGL((tower_mfma_kernel<1, 2>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
 #endif
         } else {
-            hipLaunchKernelGGL((tower_mfma_kernel<1, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
+            SMOT_LAUNCH((tower_mfma_kernel<1, 0>), tg, dim3(256), smem, st, resp, T, C, cpg, gn_eps, tower_ws);
         }
         timer_mark(1, 1, st);
         int rc = check_launch("predictor towers");

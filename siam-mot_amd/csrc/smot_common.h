@@ -1,6 +1,7 @@
 // Shared helpers for libsmot_emm.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -11,7 +12,12 @@ namespace smot {
 
 void set_error(const char* fmt, ...);
 extern long long* g_trace;                           // common.hip: phase-trace buffer (smot_debug_trace), or nullptr
-void timer_mark(int slot, int end, hipStream_t st);   // common.hip: event bracket for bench.py (no-op when idle)
+// common.hip — kernel timer for bench.py (no-op when idle).  timer_mark(slot, 0) opens a timed region: if this launch
+// is sampled, the NEXT SMOT_LAUNCH in the region is issued through hipExtLaunchKernel with a start / stop event
+// pair, i.e. the events carry the kernel's own begin / end timestamps (what rocprofv3 reports), not the span of
+// two marker packets around it (which ran 2.5-3.5 us longer).  timer_mark(slot, 1) closes the region.
+void timer_mark(int slot, int end, hipStream_t st);
+bool timer_take(hipEvent_t* start, hipEvent_t* stop);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
@@ -21,6 +27,16 @@ inline int check_launch(const char* what) {
     }
     return SMOT_OK;
 }
+
+#define SMOT_LAUNCH(KERNEL, GRID, BLOCK, SMEM, STREAM, ...)                                                       \
+    do {                                                                                                         \
+        hipEvent_t smot_e0_, smot_e1_;                                                                           \
+        if (smot::timer_take(&smot_e0_, &smot_e1_)) {                                                            \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, smot_e0_, smot_e1_, 0, __VA_ARGS__);        \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, __VA_ARGS__);                                  \
+        }                                                                                                        \
+    } while (0)
 
 #define SMOT_REQUIRE(cond, ...)            \
     do {                                   \

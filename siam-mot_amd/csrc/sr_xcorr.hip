@@ -789,8 +789,8 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
         return;
     }
 #endif
-    hipLaunchKernelGGL((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,
-                       levels_out, S);
+    SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,
+                levels_out, S);
 }
 
 // Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).

@@ -505,8 +505,8 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
         }
     }
 #define W_LAUNCH(A, O)                                                                                            \
-    hipLaunchKernelGGL((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, \
-                       part, zero_words, g_trace)
+    SMOT_LAUNCH((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, part, \
+                zero_words, g_trace)
 #ifdef SMOT_DEBUG
     if (oct == 1) {
         switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only

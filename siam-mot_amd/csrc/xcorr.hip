@@ -139,11 +139,11 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
             hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 2>), g2, b64, 0, st, x, z, out, planes);
         } else if (!launch_xcorr_variant(var, x, z, out, planes, st))
 #endif
-            hipLaunchKernelGGL((xcorr_dw_patch2_kernel<30, 15, 0>), g2, b64, 0, st, x, z, out, planes);
+            SMOT_LAUNCH((xcorr_dw_patch2_kernel<30, 15, 0>), g2, b64, 0, st, x, z, out, planes);
     } else {
         const size_t smem = (size_t)(Rx * Rx + Rz * Rz) * sizeof(float);
         SMOT_REQUIRE(smem <= 160 * 1024, "xcorr: plane too large for LDS (Rx=%d Rz=%d)", Rx, Rz);
-        hipLaunchKernelGGL(xcorr_dw_generic_kernel, dim3(planes), dim3(256), smem, st, x, z, out, Rx, Rz);
+        SMOT_LAUNCH(xcorr_dw_generic_kernel, dim3(planes), dim3(256), smem, st, x, z, out, Rx, Rz);
     }
     timer_mark(0, 1, st);
     return check_launch("xcorr_dw");
