@@ -473,8 +473,15 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const long long t_start = S.trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
     int n_assigned, cg_assigned, lvl_assigned = 0;
     float4 roi_assigned = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool have_roi =
-        fx_assign(P, sr, boxes, S.n_valid, S.order, lane, &n_assigned, &cg_assigned, &roi_assigned, &lvl_assigned);
+    // The ranking costs ~3 k cycles per box tensor at the head of every workgroup: one vector-memory round trip on
+    // lines that all 256 CUs request at the same moment (the workgroup's own roi used to arrive through the scalar
+    // cache in half that).  The 30x30 kernels earn it back (fused: 18.7 -> 17.4 us at 30 rois, 49 -> 42 us at 100);
+    // the small template pooler does not (7.1 -> 7.3 us) and keeps grid order.  Measured and dropped: ranking in wave
+    // 0 only with an LDS broadcast (same time: the cost is latency, not VALU contention); ranking from the search
+    // regions alone with the level estimated (one tensor fewer, but the workgroup's exact level then costs a
+    // dependent scalar load: 17.8 -> 18.4 us).
+    const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, lane, &n_assigned, &cg_assigned,
+                                    &roi_assigned, &lvl_assigned);
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
     const int cgrp = __builtin_amdgcn_readfirstlane(cg_assigned);
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
@@ -483,6 +490,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     if (S.trace && tid == 0)                                                                \
         S.trace[((size_t)n * gridDim.y + cgrp) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
     if (S.trace && tid == 0) S.trace[((size_t)n * gridDim.y + cgrp) * 8 + 0] = t_start;
+    FX_TRACE(5)                                   // after the assignment
 
     float roi0 = roi_assigned.x, roi1 = roi_assigned.y, roi2 = roi_assigned.z, roi3 = roi_assigned.w;
     int lvl = lvl_assigned;

@@ -898,10 +898,11 @@ def test_cost_sorted_workgroup_assignment_is_a_bijection(ops, n):
     def run():
         z = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2)
         r = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512)
+        x = ops.roi_align_levels(feats, sr, boxes, 30, scales, 2, [128, 64, 32, 16])
         cz, csr = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0)
         nv = torch.tensor([max(n - 3, 0)], dtype=torch.int32, device=DEV)
         mz, msr = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0, n_valid=nv)
-        return z, r, cz, csr, mz[:max(n - 3, 0)], msr[:max(n - 3, 0)]
+        return z, r, cz, csr, mz[:max(n - 3, 0)], msr[:max(n - 3, 0)], x
     sorted_ = run()
     with ops.debug_library(SMOT_FUSED_ORDER=4):
         grid = run()

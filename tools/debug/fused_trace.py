@@ -30,7 +30,8 @@ for n in [int(a) for a in sys.argv[1:]] or [30]:
                "phase_ticks_mean(tables,z,pool,xcorr)": [round(float(x)) for x in d[ran].mean(0)],
                "phase_max": [int(x) for x in d[ran].max(0)], "span": int(t[:, :, 4].max() - t0),
                "start_spread": int(t[:, :, 0].max() - t0), "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
-               "total_max": int((t[:, :, 4] - t[:, :, 0])[ran].max())}
+               "total_max": int((t[:, :, 4] - t[:, :, 0])[ran].max()),
+               "assignment_ticks_mean": round(float((t[:, :, 5] - t[:, :, 0])[ran].mean()))}
         for L in range(4):
             m = (lv == L)[:, None] & ran
             if m.any(): out["pool_ticks_level%d" % L] = round(float(d[:, :, 2][m].mean()))

@@ -1,9 +1,8 @@
 set -x
-python -m pytest tests -m gpu -q --no-header --tb=short -x -k "timer or bench or host" 2>&1 | tail -3
-python bench.py --no-cpu-baseline --extra-streams 0 2>&1 | tail -1 > gpurun_out/q_bench.json; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/q_bench.json').read())
-print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['frac'], d['roofline']['launches_timed'], d['roofline']['xcorr_op']['avg_launch_us'], d['roofline']['xcorr_op']['frac'], d['roofline_tower']['avg_launch_us'], d['roofline_tower']['frac'])
-PY
-python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-300
-ABLS=0 OCTS=2 python tools/debug/tower_bench.py 2>&1 | grep "^{" | head -2 | cut -c1-200
+python -m pytest tests/test_hip_parity.py -m gpu -q --no-header --tb=short -x -k "fused or pool or emm or roi or levels or assignment" 2>&1 | tail -3
+python tools/debug/fused_trace.py 30 2>&1 | grep "^{" | cut -c1-600
+export TMPDIR=/tmp
+TAG=r02x2
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG} -o ${TAG} -- python $GRAFT_REPO_ROOT/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-parity --extra-streams 0 > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_bench.log 2>&1 )
+python tools/rocpd_stats.py gpurun_out/prof_${TAG}/${TAG}_results.db --md gpurun_out/${TAG}_kernel_stats.md --title "${TAG}: bench.py --steps 300" 2>&1 | tail -1; head -9 gpurun_out/${TAG}_kernel_stats.md | cut -c1-60,150-260
+python bench.py --no-cpu-baseline --extra-streams 0 --tracks 100 --no-parity 2>&1 | tail -1 | cut -c1-200
