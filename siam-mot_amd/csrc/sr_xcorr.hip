@@ -479,7 +479,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // the small template pooler does not (7.1 -> 7.3 us) and keeps grid order.  Measured and dropped: ranking in wave
     // 0 only with an LDS broadcast (same time: the cost is latency, not VALU contention); ranking from the search
     // regions alone with the level estimated (one tensor fewer, but the workgroup's exact level then costs a
-    // dependent scalar load: 17.8 -> 18.4 us).
+    // dependent scalar load: 17.8 -> 18.4 us); the boxes through the scalar cache (sixteen s_load_dwordx4 per wave,
+    // parked in LDS for the lanes: 106 SGPRs cost the kernel its occupancy target, 18.4 us).
     const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, lane, &n_assigned, &cg_assigned,
                                     &roi_assigned, &lvl_assigned);
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
