@@ -600,8 +600,11 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         return check_launch("predictor heads combine");
     }
     // the reference's second shape family (Ho = 29) has a matrix-core kernel of its own; anything else: scalar
-    int rc = launch_tower_conv(resp, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits, st);
-    if (rc == SMOT_OK) return SMOT_OK;
+    int rc = launch_tower_conv(resp, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits, zero_words, st);
+    if (rc == SMOT_OK) {
+        if (zeroed) *zeroed = (zero_words != nullptr);
+        return SMOT_OK;
+    }
     if (rc == SMOT_ERR_UNSUPPORTED) {
         const size_t smem = (size_t)cpg * Ho * Ho * sizeof(float);
         SMOT_REQUIRE(smem <= 64 * 1024, "predictor: GroupNorm group too large for the generic tower kernel");

@@ -41,6 +41,6 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 // the reference's second yaml family): logits complete on return; SMOT_ERR_UNSUPPORTED when no instantiation fits
 int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int Ho, int cpg, float eps,
                       const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws, float* logits,
-                      hipStream_t st);
+                      unsigned* zero_words, hipStream_t st);
 
 }  // namespace smot

@@ -50,7 +50,7 @@ struct ConvGeom {
 template <int HO>
 __global__ void __launch_bounds__(256, 2)
 tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
-                       float* __restrict__ part) {
+                       float* __restrict__ part, unsigned* __restrict__ zero_words) {
     using G = ConvGeom<HO>;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -62,6 +62,7 @@ tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int
     const int tower = rem / tiles_per_tower;
     const int oc0 = (rem - tower * tiles_per_tower) * 16;
     const int nchunks = C / G_IC;
+    if (zero_words != nullptr && rem == 0 && tid == 0) zero_words[n] = 0u;   // the decode kernel's ticket of this track
 
     auto make_rsrc = [](const float* base) {
         const unsigned long long a = reinterpret_cast<unsigned long long>(base);
@@ -302,7 +303,7 @@ heads_combine_hw_kernel(const float* __restrict__ part, int tpt, int HW, const f
 // tower_generic_kernel + heads_kernel).
 int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int Ho, int cpg, float eps,
                       const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws, float* logits,
-                      hipStream_t st) {
+                      unsigned* zero_words, hipStream_t st) {
     if (Ho != 29 || C % 16 != 0 || cpg > 16 || 16 % cpg != 0) return SMOT_ERR_UNSUPPORTED;
     using G = ConvGeom<29>;
     const size_t smem = (size_t)G::SMEM_FLOATS * sizeof(float);
@@ -316,7 +317,7 @@ int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int
         opted_in = true;
     }
     hipLaunchKernelGGL(tower_conv_mfma_kernel<29>, dim3(N * 2 * (C / 16)), dim3(256), smem, st, resp, P, C, cpg, eps,
-                       tower_ws);
+                       tower_ws, zero_words);
     int rc = check_launch("predictor towers (conv, Ho=29)");
     if (rc) return rc;
     hipLaunchKernelGGL(heads_combine_hw_kernel, dim3(N, 7, (G::HW + 255) / 256), dim3(256), 0, st,

@@ -28,7 +28,7 @@ namespace smot {
 // (output row k, template row t-k) pairs; template rows come from LDS as broadcast ds_read_b128 and
 // live in VGPRs; reads of step t+1 are issued before the FMAs of step t; same FMA order per output.
 template <int RX, int RZ, int MODE>
-__global__ void __launch_bounds__(64, 4)       // <= 128 VGPRs: four waves per SIMD
+__global__ void __launch_bounds__(64, 3)       // <= 168 VGPRs: three waves per SIMD (at four the kernel spilled 5 registers)
 xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
                        float* __restrict__ out, int planes) {
     constexpr int HO = RX - RZ + 1;
@@ -93,6 +93,59 @@ xcorr_dw_patch2_kernel(const float* __restrict__ x, const float* __restrict__ z,
     xcorr_patch2_compute<RX, RZ, MODE>(xs, zs, lane, out, plane0, planes);
 }
 
+// Small templates (the reference's second yaml family: 35x35 search region, 7x7 template -> 29x29): one workgroup
+// per plane, thread = (output row, group of four output columns).  The template's RZ*RZ taps live in registers; a
+// window row is read once per thread as 4 + RZ - 1 contiguous floats (LDS rows padded to a multiple of four floats,
+// zero filled) and feeds 4 * RZ FMAs — 0.4 LDS reads per FMA instead of the generic kernel's two.  Taps accumulate
+// u-major / v-minor in one fmaf chain per output: the generic kernel's (and the oracle's) order, bit for bit.
+template <int RX, int RZ>
+__global__ void __launch_bounds__(256)
+xcorr_dw_rowpatch_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out) {
+    constexpr int HO = RX - RZ + 1;
+    constexpr int NQ = (HO + 3) / 4;                     // column groups per output row
+    constexpr int XS = ((4 * NQ + RZ - 1 + 3) / 4) * 4;  // padded LDS row (floats)
+    constexpr int SEG = 4 + RZ - 1;                      // floats a thread needs of a window row
+    static_assert(HO * NQ <= 256 && XS >= RX, "one workgroup of 256 threads per plane");
+    __shared__ __attribute__((aligned(16))) float xs[RX * XS];
+    __shared__ float zs[RZ * RZ];
+    const size_t plane = blockIdx.x;
+    const float* xg = x + plane * RX * RX;
+    const float* zg = z + plane * RZ * RZ;
+    for (int e = threadIdx.x; e < RX * XS; e += 256) {
+        const int r = e / XS, c = e - r * XS;
+        xs[e] = (c < RX) ? xg[r * RX + c] : 0.0f;
+    }
+    for (int e = threadIdx.x; e < RZ * RZ; e += 256) zs[e] = zg[e];
+    __syncthreads();
+    const int i = threadIdx.x / NQ, jq = threadIdx.x - i * NQ;
+    if (i >= HO) return;
+    float tap[RZ * RZ];
+#pragma unroll
+    for (int t = 0; t < RZ * RZ; ++t) tap[t] = zs[t];
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int u = 0; u < RZ; ++u) {
+        const float* row = xs + (i + u) * XS + 4 * jq;
+        float seg[((SEG + 3) / 4) * 4];
+#pragma unroll
+        for (int q = 0; q < (SEG + 3) / 4; ++q) {
+            const float4 v4 = *reinterpret_cast<const float4*>(row + 4 * q);
+            seg[4 * q + 0] = v4.x;
+            seg[4 * q + 1] = v4.y;
+            seg[4 * q + 2] = v4.z;
+            seg[4 * q + 3] = v4.w;
+        }
+#pragma unroll
+        for (int v = 0; v < RZ; ++v)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = fmaf(seg[o + v], tap[u * RZ + v], acc[o]);
+    }
+    float* dst = out + plane * HO * HO + i * HO + 4 * jq;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+        if (4 * jq + o < HO) dst[o] = acc[o];
+}
+
 // Any (Rx, Rz): one workgroup per plane, plane and template in LDS, one thread per output.
 __global__ void __launch_bounds__(256)
 xcorr_dw_generic_kernel(const float* __restrict__ x, const float* __restrict__ z,
@@ -140,6 +193,8 @@ extern "C" int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int
         } else if (!launch_xcorr_variant(var, x, z, out, planes, st))
 #endif
             SMOT_LAUNCH((xcorr_dw_patch2_kernel<30, 15, 0>), g2, b64, 0, st, x, z, out, planes);
+    } else if (Rx == 35 && Rz == 7) {
+        SMOT_LAUNCH((xcorr_dw_rowpatch_kernel<35, 7>), dim3(planes), dim3(256), 0, st, x, z, out);
     } else {
         const size_t smem = (size_t)(Rx * Rx + Rz * Rz) * sizeof(float);
         SMOT_REQUIRE(smem <= 160 * 1024, "xcorr: plane too large for LDS (Rx=%d Rz=%d)", Rx, Rz);
