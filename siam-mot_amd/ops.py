@@ -783,6 +783,33 @@ def track_solve_record(rec):
     return host.numpy().copy()
 
 
+_rec_events = {}
+
+
+def track_solve_record_begin(rec):
+    """Enqueue the record's copy to a pinned buffer and an event behind it; ``track_solve_record_wait`` blocks on that
+    event only.  Launches enqueued in between (the masked template extraction) run while the host is already woken
+    up and doing its bookkeeping — they are off the frame's critical path."""
+    dev, nrec = rec.device, rec.shape[0]
+    host = _rec_pinned.get((dev, nrec))
+    if host is None:
+        if len(_rec_pinned) > 64:
+            _rec_pinned.clear()
+        host = _rec_pinned[(dev, nrec)] = torch.empty((nrec,), dtype=torch.int32).pin_memory()
+    ev = _rec_events.get(dev)
+    if ev is None:
+        ev = _rec_events[dev] = torch.cuda.Event()
+    host.copy_(rec, non_blocking=True)
+    ev.record(torch.cuda.current_stream(dev))
+    return host, ev
+
+
+def track_solve_record_wait(handle):
+    host, ev = handle
+    ev.synchronize()
+    return host.numpy().copy()
+
+
 def track_solve_max_boxes():
     return (_lib or load_library()).smot_track_solve_max_boxes()
 

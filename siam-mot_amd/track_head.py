@@ -130,8 +130,9 @@ class TrackingLoop(torch.nn.Module):
 
     def _step_lean(self, features, detections):
         """One frame with the minimum of host work between the launches: raw tensors into ``ops.emm_track``, the
-        solver kernel on un-concatenated segments, the masked template extraction — all enqueued before the frame's
-        ONE synchronisation — then views, the pool mirror and a lazy cache note.  Same results as the general path
+        solver kernel on un-concatenated segments, the record's copy, the masked template extraction — all enqueued
+        before the frame's ONE synchronisation, which waits for the record only (the extraction is still running
+        when the host continues) — then views, the pool mirror and a lazy cache note.  Same results as the general path
         (tests/test_solver.py::test_lean_step_equals_general_path)."""
         emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
         mem = self.track_memory
@@ -149,10 +150,11 @@ class TrackingLoop(torch.nn.Module):
             solver._segment(detections), trk, 1.0,
             (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)),
             float(solver.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY)
+        pending = ops.track_solve_record_begin(rec_dev)         # record -> pinned memory, an event behind the copy
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
         act_boxes = ab.view(M, 4)
-        pre = emm.extract_cache_rows(features, act_boxes, rec_dev[1:2])
-        rec = ops.track_solve_record(rec_dev)                                      # the frame's one synchronisation
+        pre = emm.extract_cache_rows(features, act_boxes, rec_dev[1:2])            # runs while the host wakes up
+        rec = ops.track_solve_record_wait(pending)                                 # the frame's one synchronisation
         K, A = int(rec[0]), int(rec[1])
         pool._mirror(rec, M)
         oi, ol, ai, al = ibuf.split((M, M, M, M))
