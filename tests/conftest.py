@@ -32,3 +32,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _seeded_torch():
+    """This PyTorch build seeds its default generator differently in every process (``torch.initial_seed()`` is
+    not a constant): a module initialised inside a test would get other weights on every run, and tests that watch a
+    randomly initialised tracker evolve (tracks going dormant, expiring) would be order- and run-dependent.  Every
+    test starts from the same generator state."""
+    import torch
+    torch.manual_seed(20260925)
+    yield
