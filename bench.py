@@ -541,6 +541,7 @@ def main():
     xcorr_avg_s = xcorr_total_ms * 1e-3 / max(xcorr_launches, 1)
 
     if rank != 0:
+        parallel.shutdown()           # every collective of this rank is behind it
         return
     parity = None
     if not args.no_parity:
@@ -632,6 +633,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)
     print(json.dumps(out))
+    sys.stdout.flush()
+    parallel.shutdown()
 
 
 if __name__ == "__main__":

@@ -76,3 +76,10 @@ def max_over_ranks(value, device=None):
 def barrier():
     if is_distributed():
         dist.barrier()
+
+
+def shutdown():
+    """Tear the process group down (each rank for itself, after its last collective): no complaint from the RCCL
+    watchdog at interpreter exit when ranks finish at different times."""
+    if is_distributed():
+        dist.destroy_process_group()
