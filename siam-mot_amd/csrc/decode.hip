@@ -384,8 +384,10 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
                 hk = interp4(q[clampi(bx - 1, 0, Ho - 1)], q[clampi(bx, 0, Ho - 1)], q[clampi(bx + 1, 0, Ho - 1)],
                              q[clampi(bx + 2, 0, Ho - 1)], wx);
             }
-            const int q0 = lane & ~3;
-            const float vch = interp4(__shfl(hk, q0), __shfl(hk, q0 + 1), __shfl(hk, q0 + 2), __shfl(hk, q0 + 3), wy);
+            // the four source rows of a channel sit in the four lanes of a quad: DPP quad broadcasts, no LDS crossbar
+#define DC_QUAD(K) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(hk), (K) * 0x55, 0xf, 0xf, false))
+            const float vch = interp4(DC_QUAD(0), DC_QUAD(1), DC_QUAD(2), DC_QUAD(3), wy);
+#undef DC_QUAD
             float v[7];
 #pragma unroll
             for (int c = 0; c < 7; ++c) v[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vch), 4 * c));

@@ -12,15 +12,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None, device=None):
+def init_distributed(backend=None, device=None, force=False):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world_size, local_rank).  No-op for a single process.  ``device`` (the rank's GPU, already made
     current by the caller) is handed to the RCCL process group so that its communicator binds to that device
-    eagerly instead of guessing at the first collective."""
+    eagerly instead of guessing at the first collective.  ``force``: create the process group for a world of one as
+    well (RCCL self-check on a one-GPU box: tests/test_distributed.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # SMOT_DIST_BACKEND=gloo: smoke-test the multi-rank path on a box with fewer GPUs than ranks
             backend = os.environ.get("SMOT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

@@ -142,3 +142,36 @@ def test_bench_refuses_more_ranks_than_gpus_without_the_flag():
                           "--prewarm-ms", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300,
                          cwd=ROOT, env=env)
     assert res.returncode != 0 and "only 1 GPU(s) visible" in (res.stderr + res.stdout)
+
+
+@pytest.mark.gpu
+def test_rccl_process_group_runs_its_collectives_in_a_world_of_one():
+    """The collectives the N-GPU path uses — one flat broadcast, a MAX all-reduce of the elapsed time, barriers — on
+    the REAL backend (nccl = RCCL on ROCm) with the communicator bound to the device, in a world of one rank: what a
+    one-GPU box can execute of the RCCL path (library load, communicator creation, kernels, teardown).  Fresh
+    interpreter: a process group is process-global."""
+    import subprocess
+    code = (
+        "import os, sys, socket, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from siammot_amd import parallel\n"
+        "import torch.distributed as dist\n"
+        "s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')\n"
+        "torch.cuda.set_device(0)\n"
+        "dev = torch.device('cuda', 0)\n"
+        "rank, world, local = parallel.init_distributed(backend='nccl', device=dev, force=True)\n"
+        "assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1\n"
+        "flat = torch.arange(303495, dtype=torch.float32, device=dev)            # the head's parameter count\n"
+        "dist.broadcast(flat, src=0)\n"
+        "t = torch.tensor([1.25], dtype=torch.float64, device=dev)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "dist.barrier()\n"
+        "torch.cuda.synchronize()\n"
+        "assert float(t.item()) == 1.25 and float(flat[-1].item()) == 303494.0\n"
+        "dist.destroy_process_group()\n"
+        "print('RCCL-OK')\n" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SMOT_DIST_BACKEND")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode == 0 and "RCCL-OK" in res.stdout, (res.stdout + res.stderr)[-3000:]
