@@ -484,11 +484,21 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
                       float* part, unsigned* zero_words, hipStream_t st) {
     const int tiles = 2 * (C / 16);
-    // Two 16-channel tiles per workgroup (8 waves, 115 KB of LDS: one workgroup per CU) while that launch is a single
-    // dispatch round of the 256 CUs; beyond that the one-tile form (two independent workgroups per CU, finer
-    // rounds) is ahead — 100.2 vs 103.9 us at 100 tracks.  SMOT_TOWER_OCT = 1 / 2 forces a form in the measurement
-    // library.
-    int oct = ((N + 7) / 8) * 8 * (tiles / 2) <= 256 ? 2 : 1;
+    // One or two 16-channel tiles per workgroup, whichever the dispatch-round arithmetic favours (kernel durations by
+    // start/stop events at C = 128, profiles/r02_tower_forms_by_tracks.jsonl):
+    //   one tile  : 16 workgroups per track, 2 per CU -> rounds of 512; 27 us per full round, ~15 us for a last round
+    //               that leaves every workgroup a CU of its own (<= 256), and 20 us when the WHOLE launch does;
+    //   two tiles : 8 workgroups per track, 115 KB of LDS -> 1 per CU, rounds of 256; 24.5 us per full round, 22.5 us
+    //               for a partial one.
+    // e.g. <= 16 tracks: one tile (20 vs 25.5 us); 17..32: two (25.8 vs 28.6); 33..48: one (43 vs 48); 64: two (49 vs
+    // 54); 100: equal.  The constants scale with C alike, so the comparison holds for other channel counts.
+    // SMOT_TOWER_OCT = 1 / 2 forces a form in the measurement library.
+    const int np8 = ((N + 7) / 8) * 8;
+    const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
+    const float c1 = (w1 <= 256) ? 20.0f
+                                 : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
+    const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
+    int oct = (c2 < c1) ? 2 : 1;
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
     const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
     const int grid = ((N + 7) / 8) * 8 * (tiles / oct);

@@ -10,7 +10,7 @@ boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
 P = {k: torch.from_numpy(v).to(dev) for k, v in gi.predictor_params(rs, 128, boxes).items()}
 ABLS = os.environ.get("ABLS", "0").split(",")
 OCTS = [int(o) for o in os.environ.get("OCTS", "1,2").split(",")]       # 16-channel tiles per workgroup
-for n in (30, 100):
+for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     for abl, oct_ in [(a, o) for a in ABLS for o in (OCTS if a != "direct" else [0])]:
       with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl), SMOT_TOWER_OCT=oct_):
@@ -25,7 +25,7 @@ for n in (30, 100):
             ts.append(ms / cnt * 1e3)
         print(json.dumps({"tracks": n, "variant": abl, "tiles_per_wg": oct_, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
 # phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
-for n, oct_ in [(n, o) for n in (30, 100) for o in OCTS]:
+for n, oct_ in [(n, o) for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")] for o in OCTS]:
   with ops.debug_library(SMOT_TOWER_OCT=oct_) as lib:
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     grid = (n + 7) // 8 * 8 * 16 // oct_
