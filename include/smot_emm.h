@@ -223,26 +223,26 @@ int smot_preprocess_fwd(const unsigned char* frame, int H, int W,
 
 /*
  * Instrumentation (bench.py roofline leg): between _begin and _end every smot_xcorr_dw_fwd and
- * smot_sr_xcorr_fused_fwd launch — direct or inside smot_emm_track_fwd — is bracketed by a pair of HIP events recorded on its launch
- * stream (events are created in _begin, outside any timed region; at most max_launches pairs).
- * _end synchronises them and returns the summed kernel spans and the number of launches timed.
- * Not thread-safe; one timing session at a time.
+ * smot_sr_xcorr_fused_fwd launch — direct or inside smot_emm_track_fwd — is issued through hipExtLaunchKernel with a
+ * start / stop event pair of its own (events are created in _begin, outside any timed region; at most max_launches
+ * pairs): the elapsed time between the two is the kernel's duration as rocprofv3 reports it (round 1 recorded two
+ * marker events AROUND the launch: that span ran 2.5-3.5 us longer).  _end synchronises the events and returns the
+ * summed kernel durations and the number of launches timed.  Not thread-safe; one timing session at a time.
  */
 int smot_xcorr_timer_begin(int max_launches);
 int smot_xcorr_timer_end(double* total_ms, int* launches);
-/* Same mechanism per slot, bracketing every `stride`-th launch only (an event pair costs ~3 us of stream time:
- * at stride 1 the instrumentation itself slows a 80 us frame pair by 17 %): 0 = the cross-correlation kernels
- * (what the two calls above use, stride 1),
- * 1 = the tower MFMA kernel of smot_emm_predictor_fwd / smot_emm_track_fwd. */
-/* Phase trace: while buf != NULL every workgroup of the Winograd tower kernel and of the fused pooling /
- * correlation kernel writes s_memtime stamps to buf[workgroup*8 + 0..7] (device memory, 8 int64 per workgroup of
- * the launch grid; tower: start, main loop begin/end, output exchange done, GroupNorm done, end; fused: start,
- * tables done, templates staged, pooling done, end).  NULL switches it off. */
+/* Same mechanism per slot, timing every `stride`-th launch only: 0 = the cross-correlation kernels (what the two
+ * calls above use, stride 1), 1 = the tower kernel of smot_emm_predictor_fwd / smot_emm_track_fwd. */
+/* Phase trace: while buf != NULL every workgroup of the tower kernels, of the pooling / correlation kernels, of the
+ * decode and of the solver kernel writes s_memtime stamps to buf[item*8 + 0..7] (device memory, 8 int64 per
+ * workgroup of the launch grid; tower: start, main loop begin/end, output exchange done, GroupNorm done, end;
+ * pooling: start, tables done, templates staged, pooling done, end, after the workgroup assignment).  NULL switches
+ * it off. */
 void smot_debug_trace(long long* buf);
 int smot_kernel_timer_begin(int slot, int max_launches, int stride);
 int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
-/* Median span (microseconds) of `reps` EMPTY event brackets on `stream`: the part of a bracketed kernel span that
- * is the instrumentation's own (bench.py reports spans with and without it). */
+/* Median span (microseconds) of `reps` EMPTY marker-event brackets on `stream` (kept for tools that still time with
+ * markers; bench.py no longer needs it). */
 int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* median_us);
 
 /*
