@@ -471,6 +471,16 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
     const long long t_start = S.trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
+#ifdef SMOT_DEBUG
+    // experiment (measurement library, SMOT_FUSED_ABL = 100 + k): workgroups of the second dispatch wave start 512*k
+    // cycles late, so that the two workgroups of a CU pool (LDS crossbar) and correlate (VALU) in anti-phase.
+    // Measured: 17.0 us at no delay, 17.05-17.2 us for delays of 2 k .. 8 k cycles, 18.0 at 16 k — the late workgroup
+    // catches up exactly: a CU's time is the SUM of its workgroups' instruction issue (1,500 vector instructions per
+    // wave, 900 of them the correlation's FMAs), not a chain of latencies that a phase shift could overlap.
+    if (S.abl >= 100 && (int)(blockIdx.y * gridDim.x + blockIdx.x) >= 256) {
+        for (int d = 0; d < S.abl - 100; ++d) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     int n_assigned, cg_assigned, lvl_assigned = 0;
     float4 roi_assigned = make_float4(0.f, 0.f, 0.f, 0.f);
     // The ranking costs ~3 k cycles per box tensor at the head of every workgroup: one vector-memory round trip on

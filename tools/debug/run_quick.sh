@@ -1,27 +1,25 @@
 # scratch: one GPU-box session for the kernel under work (edit freely; tools/gpu_round.sh is the full round)
 set -x
 python - <<'PY'
-import sys, json, torch, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import sys, json, torch
+sys.path.insert(0, '.')
 import siammot_amd.ops as ops, bench
-import golden_inputs as gi
-dev = 'cuda'
-for n in (16, 30, 40):
-    rs = np.random.RandomState(1)
-    boxes = bench.synthetic_boxes(n, (1280, 704)).to(dev)
-    sr = ops.search_region(boxes, 512, 1.0, 0)
-    logits = torch.randn(n, 7, 16, 16, device=dev) * 2
-    for split in (1, 2, 4):
-        with ops.debug_library(SMOT_DECODE_SPLIT=split):
-            f = lambda: ops.emm_decode(logits, sr, boxes, 30, 15, 512, clip_wh=(1280, 704))
-            for _ in range(50): f()
-            torch.cuda.synchronize()
-            ts = []
-            for rep in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(200): f()
-                e1.record(); torch.cuda.synchronize()
-                ts.append(e0.elapsed_time(e1) / 200 * 1e3)
-        print(json.dumps({"tracks": n, "decode_split": split, "us_per_call_back_to_back": round(min(ts), 2)}), flush=True)
+dev = torch.device('cuda:0')
+scales = (0.25, 0.125, 0.0625, 0.03125)
+feats = [bench.synthetic_features(k, dev) for k in range(4)]
+boxes = bench.synthetic_boxes(30, (1280, 704)).to(dev)
+sr = ops.search_region(boxes, 512, 1.0, 0)
+z = ops.roi_align_levels(feats[0], boxes, boxes, 15, scales, 2)
+for k in (0, 4, 8, 12, 16, 20, 24, 32):
+    with ops.debug_library(SMOT_FUSED_ABL=(100 + k) if k else 0):
+        f = lambda i: ops.sr_xcorr_fused(feats[i % 4], boxes, sr, z, 30, 15, scales, 2, 512)
+        for i in range(50): f(i)
+        torch.cuda.synchronize()
+        best = 1e9
+        for rep in range(5):
+            ops.kernel_timer_begin(ops.TIMER_XCORR, 300)
+            for i in range(300): f(i)
+            ms, cnt = ops.kernel_timer_end(ops.TIMER_XCORR)
+            best = min(best, ms / cnt * 1e3)
+    print(json.dumps({"second_wave_delay_cycles": 512 * k, "fused_kernel_us": round(best, 2)}), flush=True)
 PY
