@@ -1,5 +1,7 @@
 // Error reporting + ABI version for libsmot_emm.so.
 #include "smot_common.h"
+#include <mutex>
+#include <vector>
 #include "knobs.h"
 #include <stdlib.h>
 #include <string.h>
@@ -96,6 +98,28 @@ extern "C" int smot_debug_set_knob(const char* name, const char* value) {
 
 namespace smot {
 long long* g_trace = nullptr;
+
+int ensure_lds_optin(const void* kernel, size_t bytes, const char* what) {
+    struct Seen {
+        const void* fn;
+        int device;
+        size_t bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Seen> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Seen& e : seen)
+        if (e.fn == kernel && e.device == dev && e.bytes >= bytes) return SMOT_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: cannot opt in to %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
+        return (int)e;
+    }
+    seen.push_back({kernel, dev, bytes});
+    return SMOT_OK;
+}
 }
 extern "C" void smot_debug_trace(long long* buf) { smot::g_trace = buf; }
 

@@ -541,20 +541,9 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
 #else
         const void* fn = narrow ? (const void*)tower_mfma_kernel<1, 0> : (const void*)tower_mfma_kernel<2, 0>;
 #endif
-        static const void* attr_done[4] = {nullptr, nullptr, nullptr, nullptr};   // one opt-in per kernel
-        bool seen = false;
-        for (const void* d : attr_done) seen = seen || (d == fn);
-        if (!seen && !wino) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) {
-                set_error("predictor: hipFuncSetAttribute: %s", hipGetErrorString(e));
-                return (int)e;
-            }
-            for (const void*& d : attr_done)
-                if (d == nullptr) {
-                    d = fn;
-                    break;
-                }
+        if (!wino) {
+            const int rco = ensure_lds_optin(fn, smem, "predictor towers");
+            if (rco) return rco;
         }
         // tower_ws holds the per-tile partial head sums [N][2*tiles_per_tower][4][256] (<= N*2C*256 floats)
         const dim3 tg(N * 2 * tiles_per_tower);

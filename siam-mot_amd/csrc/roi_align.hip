@@ -252,16 +252,8 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH(G)                                                                                        \
     {                                                                                                    \
-        static bool attr_done = false;                                                                   \
-        if (!attr_done) { /* > 64 KiB of dynamic LDS needs the opt-in */                                 \
-            hipError_t e = hipFuncSetAttribute((const void*)roi_align_levels_kernel<G>,                  \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);   \
-            if (e != hipSuccess) {                                                                       \
-                set_error("roi_align: hipFuncSetAttribute: %s", hipGetErrorString(e));                   \
-                return (int)e;                                                                           \
-            }                                                                                            \
-            attr_done = true;                                                                            \
-        }                                                                                                \
+        const int rco = ensure_lds_optin((const void*)roi_align_levels_kernel<G>, 96 * 1024, "roi_align");   \
+        if (rco) return rco;                                                                             \
         hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois, level_boxes, \
                            out_h, out_w, ch_per_block, out, levels_out);                                 \
     }

@@ -18,6 +18,8 @@ extern long long* g_trace;                           // common.hip: phase-trace 
 // two marker packets around it (which ran 2.5-3.5 us longer).  timer_mark(slot, 1) closes the region.
 void timer_mark(int slot, int end, hipStream_t st);
 bool timer_take(hipEvent_t* start, hipEvent_t* stop);
+// common.hip — kernels that use more than 64 KiB of dynamic LDS opt in once per (device, kernel); thread-safe.
+int ensure_lds_optin(const void* kernel, size_t bytes, const char* what);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -307,15 +307,9 @@ int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int
     if (Ho != 29 || C % 16 != 0 || cpg > 16 || 16 % cpg != 0) return SMOT_ERR_UNSUPPORTED;
     using G = ConvGeom<29>;
     const size_t smem = (size_t)G::SMEM_FLOATS * sizeof(float);
-    static bool opted_in = false;              // > 64 KiB of dynamic LDS needs the attribute (once per process)
-    if (!opted_in) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_conv_mfma_kernel<29>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-            set_error("predictor towers (conv, Ho=29): cannot opt in to %zu B of LDS", smem);
-            return SMOT_ERR_BAD_ARG;
-        }
-        opted_in = true;
-    }
+    const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_conv_mfma_kernel<29>), smem,
+                                     "predictor towers (conv, Ho=29)");
+    if (rco) return rco;
     hipLaunchKernelGGL(tower_conv_mfma_kernel<29>, dim3(N * 2 * (C / 16)), dim3(256), smem, st, resp, P, C, cpg, eps,
                        tower_ws, zero_words);
     int rc = check_launch("predictor towers (conv, Ho=29)");

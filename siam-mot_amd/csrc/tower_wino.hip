@@ -502,17 +502,10 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
     const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
     const int grid = ((N + 7) / 8) * 8 * (tiles / oct);
-    if (oct == 2) {
-        static bool opted_in = false;          // > 64 KiB of dynamic LDS needs the attribute (once per process)
-        if (!opted_in) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            {
-                set_error("predictor towers (winograd): cannot opt in to %zu B of LDS", smem);
-                return SMOT_ERR_BAD_ARG;
-            }
-            opted_in = true;
-        }
+    if (oct == 2) {                            // 115 KB of dynamic LDS
+        const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>), smem,
+                                         "predictor towers (winograd)");
+        if (rco) return rco;
     }
 #define W_LAUNCH(A, O)                                                                                            \
     SMOT_LAUNCH((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, part, \

@@ -1,25 +1,3 @@
 # scratch: one GPU-box session for the kernel under work (edit freely; tools/gpu_round.sh is the full round)
 set -x
-python - <<'PY'
-import sys, json, torch
-sys.path.insert(0, '.')
-import siammot_amd.ops as ops, bench
-dev = torch.device('cuda:0')
-scales = (0.25, 0.125, 0.0625, 0.03125)
-feats = [bench.synthetic_features(k, dev) for k in range(4)]
-boxes = bench.synthetic_boxes(30, (1280, 704)).to(dev)
-sr = ops.search_region(boxes, 512, 1.0, 0)
-z = ops.roi_align_levels(feats[0], boxes, boxes, 15, scales, 2)
-for k in (0, 4, 8, 12, 16, 20, 24, 32):
-    with ops.debug_library(SMOT_FUSED_ABL=(100 + k) if k else 0):
-        f = lambda i: ops.sr_xcorr_fused(feats[i % 4], boxes, sr, z, 30, 15, scales, 2, 512)
-        for i in range(50): f(i)
-        torch.cuda.synchronize()
-        best = 1e9
-        for rep in range(5):
-            ops.kernel_timer_begin(ops.TIMER_XCORR, 300)
-            for i in range(300): f(i)
-            ms, cnt = ops.kernel_timer_end(ops.TIMER_XCORR)
-            best = min(best, ms / cnt * 1e3)
-    print(json.dumps({"second_wave_delay_cycles": 512 * k, "fused_kernel_us": round(best, 2)}), flush=True)
-PY
+for s in 2 3 4; do python bench.py --no-cpu-baseline --no-parity --extra-streams $s --steps 500 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['multi_stream'])"; done
