@@ -435,25 +435,28 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     // ---- last workgroup of the track: arg-max over the bands' exact winners, box, confidence --------------------
     const int lane = threadIdx.x;
     const gu64_t* recs = (const gu64_t*)(cand + (size_t)n * nband * DEC_REC);
-    unsigned long long bk = 0ull;
-    int bband = 0;
+    // every lane fetches the WHOLE record of its band(s) — key and the winner's eight values — in one round trip: the
+    // lane that holds the winning key then has the values in registers (no second dependent fetch at the kernel's end)
+    unsigned long long bk = 0ull, bw[4] = {0ull, 0ull, 0ull, 0ull};
     for (int b = lane; b < nband; b += 64) {
-        const unsigned long long k = __hip_atomic_load(recs + (size_t)b * DEC_REC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k > bk) {
-            bk = k;
-            bband = b;
+        const gu64_t* r = recs + (size_t)b * DEC_REC;
+        unsigned long long w[DEC_REC];
+#pragma unroll
+        for (int q = 0; q < DEC_REC; ++q) w[q] = __hip_atomic_load(r + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w[0] > bk) {
+            bk = w[0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw[q] = w[1 + q];
         }
     }
     const unsigned long long top = wave_max_u64(bk);
     if (lane == 0) __hip_atomic_store((gu32_t*)(F.ticket + n), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (top == 0ull || bk != top) return;          // keys are unique per cell index: exactly one lane continues
-    const gu64_t* wr = recs + (size_t)bband * DEC_REC;
     float v[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const unsigned long long w2 = __hip_atomic_load(wr + 1 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v[2 * q] = __uint_as_float((unsigned)w2);
-        v[2 * q + 1] = __uint_as_float((unsigned)(w2 >> 32));
+        v[2 * q] = __uint_as_float((unsigned)bw[q]);
+        v[2 * q + 1] = __uint_as_float((unsigned)(bw[q] >> 32));
     }
     const unsigned idx = 0xFFFFFFFFu - (unsigned)(top & 0xFFFFFFFFull);
     const int Y = (int)(idx / (unsigned)G), X = (int)(idx - (unsigned)Y * (unsigned)G);
