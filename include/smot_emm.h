@@ -306,15 +306,21 @@ int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heig
  *                  trk_score_bias is added to the propagated scores first (the +1 of roi_heads.py:67 when no box
  *                  head refines them; 0 if they are already in the (1,2] band).
  *   pool_state     device int32 [8 + 3*pool_capacity], PERSISTENT between frames: word 0 max_id (-1 for a fresh
- *                  pool), word 1 frame_idx, word 2 n_active, word 3 n_dormant, words 4-7 reserved (0); then the
+ *                  pool), word 1 frame_idx, word 2 n_active, word 3 n_dormant, word 4 the number of act_* rows the
+ *                  last call wrote (A: a device-resident count, e.g. the n_valid of
+ *                  smot_emm_extract_cache_masked_fwd), words 5-7 reserved (0); then the
  *                  active ids [pool_capacity], the dormant ids [pool_capacity] and the frame each dormant id was
  *                  last active in [pool_capacity].  Read and rewritten by every call.
  *   out_*          kept rows in ascending original order (boxes [M,4], scores back in [0,1], ids with new ids
  *                  started and inactive ones set to -1, labels); M = n_det + n_trk rows of capacity each.
  *   act_*          the rows of the output whose id is active after the update (the next frame's track targets).
- *   record         device int32 [8 + 3*M + 3*pool_capacity]: K (kept), A (active rows), max_id, frame_idx,
+ *   record         int32 [8 + 3*M + 3*pool_capacity], DEVICE memory or device-accessible pinned HOST memory (the
+ *                  kernel's stores then land in host memory directly and the caller needs no copy, only an event
+ *                  behind this launch): K (kept), A (active rows), max_id, frame_idx,
  *                  n_active, n_dormant, table overflow flag, M; kept original row [M]; kept id [M]; active-row id
- *                  [M]; snapshot of the three pool tables.  The only thing the host has to read back.
+ *                  [M]; snapshot of the three pool tables.  The only thing the host has to read back.  frame_idx
+ *                  (word 3, always >= 1) is stored last, behind a system-scope fence: a host polling a pinned
+ *                  record it zeroed before the launch finds the record complete once word 3 is non-zero.
  * At most smot_track_solve_max_boxes() boxes / ids per call (one workgroup); more -> SMOT_ERR_UNSUPPORTED.
  */
 int smot_track_solve_max_boxes(void);

@@ -720,14 +720,34 @@ def nms(boxes, scores, thresh):
 _rec_pinned = {}
 
 
-def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity):
+_rec_host_ring = {}
+
+
+def _host_record(dev, pool_capacity):
+    """A pinned, device-accessible int32 buffer large enough for any record (two per device, alternating: the host
+    has copied the previous frame's record out before the next launch can overwrite it)."""
+    n = 8 + 3 * track_solve_max_boxes() + 3 * pool_capacity
+    ring = _rec_host_ring.get((dev, n))
+    if ring is None:
+        ring = _rec_host_ring[(dev, n)] = [[torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)], 0]
+    ring[1] ^= 1
+    rec = ring[0][ring[1]]
+    rec[3] = 0                        # the kernel stores the frame index (>= 1) here last: the host's completion flag
+    return rec
+
+
+def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity,
+                host_record=False):
     """``smot_track_solve_fwd``: one launch for TrackSolver.forward + the pool transitions + the active-row filter.
 
     det / trk: ``(boxes [n,4] xyxy, scores [n], ids [n] int64, labels [n] int64 or None)`` device tensors or ``None``
     for an empty segment.  Launch only (no synchronisation).  Returns ``(fbuf, ibuf, rec, M)``: ``fbuf`` fp32
     ``[10*M]`` = out_boxes | act_boxes | out_scores | act_scores, ``ibuf`` int64 ``[4*M]`` = out_ids | out_labels |
     act_ids | act_labels (capacity M rows each; the first K / A are valid) and ``rec``, the record on the DEVICE
-    (``rec[0]`` = K, ``rec[1]`` = A, ...: include/smot_emm.h); ``track_solve_record(rec)`` brings it to the host."""
+    (``rec[0]`` = K, ``rec[1]`` = A, ...: include/smot_emm.h); ``track_solve_record(rec)`` brings it to the host.
+    ``host_record=True``: the kernel writes the record straight into pinned host memory (``rec`` is then that host
+    tensor; read it after an event behind this launch — no copy command; the count of active rows for device-side
+    consumers is ``pool_state[4:5]``)."""
     lib = _lib or load_library()
     segs = []
     dev = pool_state.device
@@ -748,7 +768,7 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     nrec = 8 + 3 * M + 3 * pool_capacity
     fbuf = torch.empty((10 * max(M, 1),), dtype=_F32, device=dev)
     ibuf = torch.empty((4 * max(M, 1),), dtype=torch.int64, device=dev)
-    rec = torch.empty((nrec,), dtype=torch.int32, device=dev)
+    rec = _host_record(dev, pool_capacity) if host_record else torch.empty((nrec,), dtype=torch.int32, device=dev)
     fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
     cur = torch.cuda.current_device()
     if cur != dev.index:
@@ -808,6 +828,28 @@ def track_solve_record_wait(handle):
     host, ev = handle
     ev.synchronize()
     return host.numpy().copy()
+
+
+def wait_host_record(rec, event, spins=20000):
+    """Block until the solver kernel has completed a pinned-memory record: poll its completion word (stored last,
+    behind a system-scope fence), falling back to the event behind the launch if it does not show up (a kernel
+    fault would otherwise spin for ever).  Polling sees the record ~10 us earlier than an event wake-up."""
+    flag = rec.numpy()
+    for _ in range(spins):
+        if flag[3] != 0:
+            return
+    event.synchronize()
+    if flag[3] == 0:
+        raise RuntimeError("siammot_amd.track_solve: the solver kernel finished without completing its record")
+
+
+def stream_event(dev):
+    """An event recorded on ``dev``'s current stream now (one reusable event per device)."""
+    ev = _rec_events.get(dev)
+    if ev is None:
+        ev = _rec_events[dev] = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return ev
 
 
 def track_solve_max_boxes():

@@ -146,15 +146,17 @@ class TrackingLoop(torch.nn.Module):
                 bb, conf = emm.track_raw(features, tb0.bbox, sr[0].bbox, z, tb0.size)
                 trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels"))
         dev = detections.bbox.device
-        fbuf, ibuf, rec_dev, M = ops.track_solve(
+        state = pool.device_state(dev)
+        fbuf, ibuf, rec_host, M = ops.track_solve(
             solver._segment(detections), trk, 1.0,
             (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)),
-            float(solver.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY)
-        pending = ops.track_solve_record_begin(rec_dev)         # record -> pinned memory, an event behind the copy
+            float(solver.NMS_THRESH), int(pool._max_dormant_frames), state, pool.DEVICE_CAPACITY, host_record=True)
+        ev = ops.stream_event(dev)          # behind the solver: its record lands in pinned host memory, no copy command
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
         act_boxes = ab.view(M, 4)
-        pre = emm.extract_cache_rows(features, act_boxes, rec_dev[1:2])            # runs while the host wakes up
-        rec = ops.track_solve_record_wait(pending)                                 # the frame's one synchronisation
+        pre = emm.extract_cache_rows(features, act_boxes, state[4:5])              # runs while the host wakes up
+        ops.wait_host_record(rec_host, ev)                                         # the frame's one synchronisation
+        rec = rec_host.numpy()[:8 + 3 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
         pool._mirror(rec, M)
         oi, ol, ai, al = ibuf.split((M, M, M, M))

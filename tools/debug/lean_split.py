@@ -37,11 +37,12 @@ with torch.no_grad():
         d = dets(k); t1 = T()
         z, sr, tb = loop.track_memory; tb0 = tb[0]
         bb, conf = emm.track_raw(f, tb0.bbox, sr[0].bbox, z, tb0.size); trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels")); t2 = T()
-        fbuf, ibuf, rec_dev, M = ops.track_solve(solver._segment(d), trk, 1.0, (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)), float(solver.NMS_THRESH), int(pool._max_dormant_frames), pool.device_state(dev), pool.DEVICE_CAPACITY); t3 = T()
-        pending = ops.track_solve_record_begin(rec_dev)
+        state = pool.device_state(dev)
+        fbuf, ibuf, rec_host, M = ops.track_solve(solver._segment(d), trk, 1.0, (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)), float(solver.NMS_THRESH), int(pool._max_dormant_frames), state, pool.DEVICE_CAPACITY, host_record=True); t3 = T()
+        ev = ops.stream_event(dev)
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M)); act_boxes = ab.view(M, 4)
-        prec = emm.extract_cache_rows(f, act_boxes, rec_dev[1:2]); t4 = T()
-        rec = ops.track_solve_record_wait(pending); t5 = T()
+        prec = emm.extract_cache_rows(f, act_boxes, state[4:5]); t4 = T()
+        ops.wait_host_record(rec_host, ev); rec = rec_host.numpy()[:8 + 3 * M + 3 * pool.DEVICE_CAPACITY].copy(); t5 = T()
         K, A = int(rec[0]), int(rec[1]); pool._mirror(rec, M)
         oi, ol, ai, al = ibuf.split((M, M, M, M))
         out = BoxList(ob.view(M, 4)[:K], d.size, mode="xyxy"); out.add_field("ids", oi[:K]); out.add_field("scores", osc[:K]); out.add_field("labels", ol[:K]); out.host_ids = rec[8 + M:8 + M + K]
@@ -50,5 +51,5 @@ with torch.no_grad():
         pool.note_memory(memory, act.host_ids); loop.track_memory = memory; t6 = T()
         for i, (a, b) in enumerate(((t0, t1), (t1, t2), (t2, t3), (t3, t4), (t4, t5), (t5, t6))): acc[i] += b - a
 torch.cuda.synchronize()
-names = ["dets", "head launch (track_raw)", "solver launch", "record copy + extract launch", "wait for the record", "views + mirror + memory"]
+names = ["dets", "head launch (track_raw)", "solver launch", "event + extract launch", "wait for the record", "views + mirror + memory"]
 print(json.dumps({k: round(v / N * 1e6, 1) for k, v in zip(names, acc)} | {"sum_us": round(sum(acc) / N * 1e6, 1), "tracks": A}))
