@@ -331,7 +331,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     // one horizontal 4-tap, the four lanes of a channel are combined vertically, the seven channel values are
     // broadcast and all lanes score the cell redundantly.  A lane evaluating its cell alone walked 112 dependent LDS
     // reads and ~1,000 instructions at one-wave issue rate — up to 17 k cycles with the rest of the workgroup waiting
-    // at the barrier (profiles/r02_decode_trace.md); cooperatively it is a few hundred cycles per nominee.
+    // at the barrier (profiles/r02u_decode_trace.jsonl); cooperatively it is a few hundred cycles per nominee.
     const bool have = best != 0ull;
     const bool nominee = have && (unsigned)(best >> 32) >= thr;
     const bool several = have && sk2 != 0u && sk2 >= thr;          // a second cell of this lane is in range too

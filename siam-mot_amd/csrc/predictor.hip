@@ -527,7 +527,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
         const int blocks32 = N * 2 * (C / 32);
-        // measured (profiles/r01_m): 16-channel tiles 1.79 us/track @N=30; 32-channel tiles 2.06 us/track @N=100
+        // measured in round 1 (profiles/r01_n_kernel_bench_tower_ablations.md): 16-channel tiles 1.79 us/track @N=30; 32-channel tiles 2.06 us/track @N=100
         const bool narrow = wino || blocks32 < 2 * 256 || !knobs().tower_wide;
         const int mt = narrow ? 1 : 2;
         const int tiles_per_tower = C / (16 * mt);

@@ -298,7 +298,7 @@ sr_xcorr_fused8_kernel(LevelParams P, int C, const float* __restrict__ sr, const
 #endif  // SMOT_DEBUG (generation 2)
 
 // ---- third generation (default): sample tables in registers, wave-uniform addressing, gathers in bulk ------------
-// What the phase traces of generation 2 showed (profiles/r02a_fused_trace.jsonl, ticks per workgroup @30 tracks):
+// What the phase traces of generation 2 showed (round-1 traces, ticks per workgroup @30 tracks):
 // tables 4.3 k, pooling 14 k on average but 26 k for the 33..64-column windows, correlation 12 k.  The pooling was
 // neither bandwidth- nor LDS-bound; it was a chain of dependent round trips: per pooled row one LDS read of the
 // weights, four loads' waits, four ds_bpermute gathers waited for one by one — 15 rows x 2 batches x ~400 cycles —
