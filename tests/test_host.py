@@ -218,3 +218,32 @@ def test_result_wire_format_matches_the_reference_contract():
     empty.add_field("scores", torch.zeros(0))
     empty.add_field("labels", torch.zeros(0, dtype=torch.int64))
     assert boxlists_to_entities(empty, 0, [0.0]) == []
+
+
+def test_wait_host_record_polls_then_falls_back_to_the_event():
+    """The tracking loop's one synchronisation (ops.wait_host_record): returns as soon as the record's completion
+    word is non-zero, falls back to the event behind the launch when it is not, and raises when even the event's
+    completion leaves the record incomplete (a faulted kernel must not read as an empty frame)."""
+    import torch
+    from siammot_amd import ops
+
+    class Ev(object):
+        def __init__(self, rec=None, value=0):
+            self.rec, self.value, self.calls = rec, value, 0
+
+        def synchronize(self):
+            self.calls += 1
+            if self.rec is not None:
+                self.rec[3] = self.value
+    done = torch.zeros(16, dtype=torch.int32)
+    done[3] = 7
+    ev = Ev()
+    ops.wait_host_record(done, ev)
+    assert ev.calls == 0                                   # polled: the event was never touched
+    late = torch.zeros(16, dtype=torch.int32)
+    ev = Ev(late, 3)
+    ops.wait_host_record(late, ev, spins=50)
+    assert ev.calls == 1 and int(late[3]) == 3
+    never = torch.zeros(16, dtype=torch.int32)
+    with pytest.raises(RuntimeError):
+        ops.wait_host_record(never, Ev(never, 0), spins=50)
