@@ -491,6 +491,9 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // regions alone with the level estimated (one tensor fewer, but the workgroup's exact level then costs a
     // dependent scalar load: 17.8 -> 18.4 us); the boxes through the scalar cache (sixteen s_load_dwordx4 per wave,
     // parked in LDS for the lanes: 106 SGPRs cost the kernel its occupancy target, 18.4 us).
+    // Also measured and dropped for the 33..64-column windows that set the makespan: three 10-row blocks per plane with
+    // the next block's row loads issued before the current block's gathers (96 VGPRs, two workgroups per CU):
+    // bit-identical, 17.0 instead of 16.75 us at 30 rois, 12.9 instead of 12.3 at 16 (profiles/r02_fused_pipelined_wide.jsonl).
     const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, lane, &n_assigned, &cg_assigned,
                                     &roi_assigned, &lvl_assigned);
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
