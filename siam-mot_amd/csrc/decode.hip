@@ -171,6 +171,14 @@ constexpr float DEC_TOL = 4e-6f;  // |fast score - exact score| bound used to no
                                   // magnitude: (1-sigma)*p*pen + sigma*window); measured gap: a few 1e-7
 constexpr int DEC_REC = 5;        // u64 words published per band: key, then seven floats (+ pad)
 constexpr int DEC_NOM = 64;       // nominee list per band (more: the whole band is re-scored exactly)
+// Static LDS of decode_kernel next to the dynamic logits image: dv 4 KiB + wy_tab 512 B + nom 256 B + wbest / flags;
+// the launch-time guard reserves this much so that a large Ho fails with a message instead of an opaque HIP error.
+constexpr size_t DEC_STATIC_LDS = 6 * 1024;
+// The cross-workgroup hand-off below (relaxed agent-scope stores, s_waitcnt vmcnt(0), relaxed ticket — no
+// release/acquire) relies on gfx9 write-through L2 semantics; refuse to build it for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "decode.hip: the ticket hand-off is written for gfx9 (CDNA) write-through stores"
+#endif
 
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
 typedef __attribute__((address_space(1))) unsigned gu32_t;
@@ -743,7 +751,7 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     const long long G = (long long)Ho * up;
     SMOT_REQUIRE(G <= 256 * DEC_MAX_COLS, "decode: grid %lld too wide (max %d)", G, 256 * DEC_MAX_COLS);
     const size_t smem = (size_t)7 * Ho * Ho * sizeof(float);
-    SMOT_REQUIRE(smem <= 64 * 1024 && Ho <= 64, "decode: Ho=%d too large for LDS", Ho);
+    SMOT_REQUIRE(smem + DEC_STATIC_LDS <= 64 * 1024 && Ho <= 64, "decode: Ho=%d too large for LDS", Ho);
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE((L.logits || L.part) && sr && boxes && hann && cand_ws && bb && conf, "decode: null pointer");
     SMOT_REQUIRE(((uintptr_t)cand_ws & 7) == 0, "decode: cand_ws must be 8-byte aligned");

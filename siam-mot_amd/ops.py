@@ -720,20 +720,43 @@ def nms(boxes, scores, thresh):
 _rec_pinned = {}
 
 
-_rec_host_ring = {}
+class HostRecordRing(object):
+    """Two pinned, device-accessible int32 buffers large enough for any solver record, and the event recorded behind
+    each launch — owned by ONE tracker (``TrackPool.host_record_ring``), so two tracking loops driven from different
+    threads or streams never re-zero or re-record each other's completion word.  The buffers alternate: the host has
+    copied the previous frame's record out before the next launch can overwrite it.  A frame that was aborted between
+    launch and wait (an exception, KeyboardInterrupt) leaves its buffer marked in flight; the stream is drained
+    before that buffer is handed out again, so a late store of the old kernel cannot complete a newer record."""
 
+    def __init__(self, dev, pool_capacity):
+        n = 8 + 3 * track_solve_max_boxes() + 3 * pool_capacity
+        self.dev = dev
+        self.bufs = [torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.in_flight = [False, False]
+        self.k = 0
+        self.event = torch.cuda.Event()
 
-def _host_record(dev, pool_capacity):
-    """A pinned, device-accessible int32 buffer large enough for any record (two per device, alternating: the host
-    has copied the previous frame's record out before the next launch can overwrite it)."""
-    n = 8 + 3 * track_solve_max_boxes() + 3 * pool_capacity
-    ring = _rec_host_ring.get((dev, n))
-    if ring is None:
-        ring = _rec_host_ring[(dev, n)] = [[torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)], 0]
-    ring[1] ^= 1
-    rec = ring[0][ring[1]]
-    rec[3] = 0                        # the kernel stores the frame index (>= 1) here last: the host's completion flag
-    return rec
+    def next(self):
+        self.k ^= 1
+        if self.in_flight[self.k]:
+            torch.cuda.current_stream(self.dev).synchronize()
+            self.in_flight = [False, False]
+        rec = self.bufs[self.k]
+        rec[3] = 0                    # the kernel stores the frame index (>= 1) here last: the host's completion flag
+        self.in_flight[self.k] = True
+        return rec
+
+    def record_event(self):
+        """Record this ring's event on the device's current stream (behind the solver launch)."""
+        self.event.record(torch.cuda.current_stream(self.dev))
+        return self.event
+
+    def wait(self, rec):
+        """The frame's one synchronisation: poll the completion word of ``rec``, event fallback."""
+        wait_host_record(rec, self.event)
+        for i, b in enumerate(self.bufs):
+            if b is rec:
+                self.in_flight[i] = False
 
 
 def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity,
@@ -745,9 +768,9 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     ``[10*M]`` = out_boxes | act_boxes | out_scores | act_scores, ``ibuf`` int64 ``[4*M]`` = out_ids | out_labels |
     act_ids | act_labels (capacity M rows each; the first K / A are valid) and ``rec``, the record on the DEVICE
     (``rec[0]`` = K, ``rec[1]`` = A, ...: include/smot_emm.h); ``track_solve_record(rec)`` brings it to the host.
-    ``host_record=True``: the kernel writes the record straight into pinned host memory (``rec`` is then that host
-    tensor; read it after an event behind this launch — no copy command; the count of active rows for device-side
-    consumers is ``pool_state[4:5]``)."""
+    ``host_record=ring`` (a ``HostRecordRing``): the kernel writes the record straight into the ring's next pinned
+    host buffer (``rec`` is then that host tensor; ``ring.record_event()`` behind this launch, ``ring.wait(rec)`` to
+    read it — no copy command; the count of active rows for device-side consumers is ``pool_state[4:5]``)."""
     lib = _lib or load_library()
     segs = []
     dev = pool_state.device
@@ -768,7 +791,7 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     nrec = 8 + 3 * M + 3 * pool_capacity
     fbuf = torch.empty((10 * max(M, 1),), dtype=_F32, device=dev)
     ibuf = torch.empty((4 * max(M, 1),), dtype=torch.int64, device=dev)
-    rec = _host_record(dev, pool_capacity) if host_record else torch.empty((nrec,), dtype=torch.int32, device=dev)
+    rec = host_record.next() if host_record else torch.empty((nrec,), dtype=torch.int32, device=dev)
     fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
     cur = torch.cuda.current_device()
     if cur != dev.index:
@@ -841,15 +864,6 @@ def wait_host_record(rec, event, spins=20000):
     event.synchronize()
     if flag[3] == 0:
         raise RuntimeError("siammot_amd.track_solve: the solver kernel finished without completing its record")
-
-
-def stream_event(dev):
-    """An event recorded on ``dev``'s current stream now (one reusable event per device)."""
-    ev = _rec_events.get(dev)
-    if ev is None:
-        ev = _rec_events[dev] = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(dev))
-    return ev
 
 
 def track_solve_max_boxes():

@@ -124,6 +124,8 @@ class TrackingLoop(torch.nn.Module):
         fast = getattr(self.solver, "_device_path", None)
         if fast is None or not detections.bbox.is_cuda or self.track.tracker.rz != 15:
             return False
+        if detections.mode != "xyxy" or not set(detections.fields()) <= self.solver._KERNEL_FIELDS:
+            return False                     # other box modes / extra fields: the general path keeps them
         mem = self.track_memory
         n = len(detections) + (len(mem[2][0]) if mem is not None else 0)
         return self.solver.nms_mask_fn is ops.nms_keep_mask and 0 < n <= ops.track_solve_max_boxes()
@@ -147,15 +149,16 @@ class TrackingLoop(torch.nn.Module):
                 trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels"))
         dev = detections.bbox.device
         state = pool.device_state(dev)
+        ring = pool.host_record_ring(dev)
         fbuf, ibuf, rec_host, M = ops.track_solve(
             solver._segment(detections), trk, 1.0,
             (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)),
-            float(solver.NMS_THRESH), int(pool._max_dormant_frames), state, pool.DEVICE_CAPACITY, host_record=True)
-        ev = ops.stream_event(dev)          # behind the solver: its record lands in pinned host memory, no copy command
+            float(solver.NMS_THRESH), int(pool._max_dormant_frames), state, pool.DEVICE_CAPACITY, host_record=ring)
+        ring.record_event()                 # behind the solver: its record lands in pinned host memory, no copy command
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
         act_boxes = ab.view(M, 4)
         pre = emm.extract_cache_rows(features, act_boxes, state[4:5])              # runs while the host wakes up
-        ops.wait_host_record(rec_host, ev)                                         # the frame's one synchronisation
+        ring.wait(rec_host)                                                        # the frame's one synchronisation
         rec = rec_host.numpy()[:8 + 3 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
         pool._mirror(rec, M)

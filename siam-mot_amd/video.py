@@ -159,20 +159,41 @@ def prefetch(frame_generator, depth=2):
     JPEG decode of frame t+1 overlaps the GPU work of frame t (the reference decodes inline)."""
     q = queue.Queue(maxsize=max(1, depth))
     end = object()
+    stop = threading.Event()
+
+    def put(item):
+        """Blocking put that gives up when the consumer is gone (it stopped early: an exception in the tracker, a
+        ``break``): the worker must not sit in ``q.put`` for ever holding the decoder and ``depth`` frames."""
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
 
     def work():
         try:
             for item in frame_generator:
-                q.put(item)
-            q.put(end)
+                if not put(item):
+                    break
+            else:
+                put(end)
         except BaseException as e:          # surface decoder errors on the consumer side
-            q.put(e)
+            put(e)
+        finally:
+            close = getattr(frame_generator, "close", None)
+            if close is not None:
+                close()
     t = threading.Thread(target=work, daemon=True)
     t.start()
-    while True:
-        item = q.get()
-        if item is end:
-            return
-        if isinstance(item, BaseException):
-            raise item
-        yield item
+    try:
+        while True:
+            item = q.get()
+            if item is end:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:                                # generator closed or exhausted: release the worker
+        stop.set()

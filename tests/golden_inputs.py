@@ -161,3 +161,121 @@ def refine_case_inputs():
         mixed_ids[row] = track_ids[k]
     return dict(features=feats, params=params, track_boxes=track_boxes, track_ids=track_ids,
                 track_labels=track_labels, track_scores=track_scores, mixed_boxes=mixed_boxes, mixed_ids=mixed_ids)
+
+
+# ---- closed-loop tracking sequences -----------------------------------
+# The reference's CombinedROIHeads.forward (roi_heads.py:22-52) with its own TrackHead / TrackSolver / TrackPool AND
+# its own EMM in the loop, over synthetic 720p-shaped maps (oracle/gen_golden_sequence.py).  Frames are a smooth
+# rotation through three independent noise fields, so a template extracted at frame t still correlates with frame
+# t+1 (as on video) while every frame differs.
+SEQ_CASES = {
+    # propagated boxes keep their matching score + 1 (a box head that returns its proposals unchanged)
+    "plain": dict(channels=128, image_wh=(1280, 704), frames=24, seed=101, thresholds=(0.4, 0.6, 0.4),
+                  max_dormant_frames=3, n_objects=12, refine=False, cls_bias=(1.0, -1.0), reg_gain=1.0),
+    # propagated boxes go through a box head as proposals (_refine_tracks, roi_heads.py:60-84)
+    "refine": dict(channels=128, image_wh=(1280, 704), frames=20, seed=78, thresholds=(0.4, 0.6, 0.4),
+                   max_dormant_frames=2, n_objects=10, refine=True, cls_bias=(1.0, -1.0), reg_gain=1.0,
+                   box_head=dict(resolution=7, sampling_ratio=2, mlp_dim=64, num_classes=2, score_thresh=0.05,
+                                 nms=0.5, reg_weights=(10.0, 10.0, 5.0, 5.0))),
+}
+# Random-init regression heads predict a box of about the bias size whatever the object: most objects are near that
+# size (straddling the FPN level 1 / 2 boundary at sqrt(area) = 224) so that tracks and detections keep meeting in
+# the solver's NMS; the small and the large object exercise levels 0 and 3 whenever a track starts on them.
+SEQ_OBJECT_SIZES = [(150, 300), (170, 340), (140, 290), (64, 128), (160, 330), (430, 540)]
+SEQ_REG_SIZE = (160.0, 320.0)
+
+
+class SequenceInputs(object):
+    """Seeded inputs of one closed-loop case: ``features(t)`` (5 FPN levels, fp32 numpy), ``detections(t)``
+    (boxes, scores), ``params`` (EMM predictor state_dict) and, for the refine case, ``box_head_params``."""
+
+    def __init__(self, name):
+        self.case = c = SEQ_CASES[name]
+        self.name = name
+        rs = np.random.RandomState(c["seed"])
+        shapes = feature_shapes(c["image_wh"], c["channels"])
+        self._fields = [[rs.standard_normal(s).astype(F32) for s in shapes] for _ in range(3)]
+        self._objects(rs)
+        boxes = np.array([[0, 0, SEQ_REG_SIZE[0], SEQ_REG_SIZE[1]]], dtype=F32)
+        self.params = predictor_params(rs, c["channels"], boxes)
+        self.params["cls.bias"] = np.array(c["cls_bias"], dtype=F32)
+        for k in ("reg.weight",):
+            self.params[k] = (self.params[k] * F32(c["reg_gain"])).astype(F32)
+        if c["refine"]:
+            b = c["box_head"]
+            d_in = c["channels"] * b["resolution"] ** 2
+            m, k = b["mlp_dim"], b["num_classes"]
+            self.box_head_params = {
+                "feature_extractor.fc6.weight": (rs.standard_normal((m, d_in)) / np.sqrt(d_in)).astype(F32),
+                "feature_extractor.fc6.bias": (0.1 * rs.standard_normal(m)).astype(F32),
+                "feature_extractor.fc7.weight": (rs.standard_normal((m, m)) / 8.0).astype(F32),
+                "feature_extractor.fc7.bias": (0.1 * rs.standard_normal(m)).astype(F32),
+                "predictor.cls_score.weight": (rs.standard_normal((k, m)) / 2.0).astype(F32),
+                "predictor.cls_score.bias": np.zeros(k, F32),
+                "predictor.bbox_pred.weight": (rs.standard_normal((4 * k, m)) / 4.0).astype(F32),
+                "predictor.bbox_pred.bias": np.zeros(4 * k, F32),
+            }
+
+    def _objects(self, rs):
+        c = self.case
+        W, H = c["image_wh"]
+        n, T = c["n_objects"], c["frames"]
+        self.obj_wh = np.array([SEQ_OBJECT_SIZES[i % len(SEQ_OBJECT_SIZES)] for i in range(n)], dtype=np.float64)
+        lo = self.obj_wh / 2 + 4
+        hi = np.array([W, H]) - self.obj_wh / 2 - 4
+        self.obj_c0 = lo + rs.uniform(0, 1, (n, 2)) * (hi - lo)
+        self.obj_vel = rs.uniform(-2.5, 2.5, (n, 2))
+        self.obj_first = np.where(np.arange(n) % 4 == 3, rs.randint(2, T // 2, n), 0)       # late arrivals
+        self.obj_last = np.where(np.arange(n) % 5 == 2, rs.randint(T // 2, T - 3, n), T)    # leave for good
+        # detector drop-outs: bursts of 1-3 frames
+        self.obj_seen = np.ones((n, T), dtype=bool)
+        for i in range(n):
+            for _ in range(int(rs.randint(0, 3))):
+                t0, ln = int(rs.randint(1, T - 3)), int(rs.randint(1, 4))
+                self.obj_seen[i, t0:t0 + ln] = False
+            self.obj_seen[i, :self.obj_first[i]] = False
+            self.obj_seen[i, self.obj_last[i]:] = False
+        self._det_seed = int(rs.randint(0, 2 ** 31 - 1))
+
+    def features(self, t):
+        th, ph = 0.12 * t, 0.7 * t
+        c0, c1, c2 = F32(np.cos(th)), F32(np.sin(th) * np.cos(ph)), F32(np.sin(th) * np.sin(ph))
+        return [((c0 * f0) + (c1 * f1)) + (c2 * f2) for f0, f1, f2 in zip(*self._fields)]
+
+    def detections(self, t):
+        c = self.case
+        W, H = c["image_wh"]
+        rs = np.random.RandomState(self._det_seed + 7919 * t)
+        ctr = self.obj_c0 + self.obj_vel * t
+        boxes = np.concatenate((ctr - self.obj_wh / 2, ctr + self.obj_wh / 2), 1) + rs.uniform(-1.5, 1.5, (len(ctr), 4))
+        boxes = boxes[self.obj_seen[:, t]]
+        nfp = int(rs.randint(0, 3))
+        fc = rs.uniform(60, [W - 60.0, H - 60.0], (nfp, 2))
+        fwh = rs.uniform(30, 110, (nfp, 2))
+        boxes = np.concatenate((boxes, np.concatenate((fc - fwh / 2, fc + fwh / 2), 1)), 0)
+        boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, W - 1)
+        boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, H - 1)
+        scores = rs.uniform(0.45, 0.99, len(boxes))
+        return boxes.astype(F32), scores.astype(F32)
+
+
+# ---- the benchmark configurations (BASELINE.json configs) whose reference outputs oracle/gen_golden_bench.py stores -----
+BENCH_FAMILIES = {
+    # siammot/configs/defaults.py:35-82 / configs/dla/DLA_34_FPN_EMM.yaml
+    "default": dict(rz=15, search_region=2.0, pad_pixels=512, min_search_wh=0, use_centerness=True, sigma=0.4,
+                    amodal=False, scales=(0.25, 0.125, 0.0625, 0.03125)),
+    # configs/dla/DLA_34_FPN_EMM_AOT.yaml:52-63
+    "aot": dict(rz=7, search_region=5.0, pad_pixels=256, min_search_wh=0, use_centerness=False, sigma=0.1,
+                amodal=False, scales=(0.25, 0.125, 0.0625, 0.03125)),
+}
+BENCH_CONFIGS = {
+    "n30": dict(channels=128, net_hw=(704, 1280), n=30, family="default"),       # configs[1]
+    "n100": dict(channels=128, net_hw=(704, 1280), n=100, family="default"),     # configs[2]
+    "cfg0": dict(channels=128, net_hw=(800, 800), n=4, family="default"),        # configs[0]: 256x256 frame -> 800x800
+    "cfg4": dict(channels=256, net_hw=(1056, 1920), n=50, family="default"),     # configs[4]: R-50-FPN, 1080p
+    "aot_n30": dict(channels=128, net_hw=(704, 1280), n=30, family="aot"),       # second yaml family at configs[1] size
+}
+
+
+def bench_channel_subset(C):
+    return [0, C // 2 - 1, C - 1]

@@ -1,0 +1,205 @@
+"""Replay of the closed-loop golden sequences (tests/golden/sequence_<case>.npz, written by
+oracle/gen_golden_sequence.py from the reference's own CombinedROIHeads / TrackHead / TrackSolver / TrackPool / EMM)
+through this repository's ``TrackingLoop``.
+
+``OracleEMM`` is the CPU stand-in for the head in the ``-m "not gpu"`` suite: the oracle restatement behind the
+``EMM`` interface (test infrastructure only — the product never imports it).
+"""
+import os
+
+import numpy as np
+import torch
+
+import golden_inputs as gi
+from siammot_amd.config import get_default_cfg
+from siammot_amd.structures import BoxList
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sequence_cfg(case):
+    cfg = get_default_cfg(channels=case["channels"])
+    th = cfg.MODEL.TRACK_HEAD
+    th.TRACK_THRESH, th.START_TRACK_THRESH, th.RESUME_TRACK_THRESH = case["thresholds"]
+    th.MAX_DORMANT_FRAMES = case["max_dormant_frames"]
+    if case["refine"]:
+        b = case["box_head"]
+        cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM = b["mlp_dim"]
+        cfg.MODEL.ROI_BOX_HEAD.NUM_CLASSES = b["num_classes"]
+        cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = b["resolution"]
+        cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = b["sampling_ratio"]
+        cfg.MODEL.ROI_HEADS.SCORE_THRESH = b["score_thresh"]
+        cfg.MODEL.ROI_HEADS.NMS = b["nms"]
+        cfg.MODEL.ROI_HEADS.BBOX_REG_WEIGHTS = b["reg_weights"]
+    return cfg
+
+
+class OracleEMM(torch.nn.Module):
+    """oracle/emm_oracle.py behind ``EMM.forward`` / ``EMM.extract_cache`` (CPU tensors)."""
+
+    def __init__(self, params, channels, track_utils, reference_ops=True):
+        super(OracleEMM, self).__init__()
+        self.reference_ops = reference_ops
+        from oracle import emm_oracle as O
+        self.O = O
+        self.ocfg = O.EMMConfig(channels=channels)
+        self.params = {k: torch.from_numpy(v) for k, v in params.items()}
+        self.track_utils = track_utils
+        self.last = None
+
+    def forward(self, features, boxes, sr, targets=None, template_features=None):
+        b = boxes[0]
+        bb, conf, _, inter = self.O.emm_forward(self.ocfg, self.params, list(features), b.bbox, sr[0].bbox,
+                                                template_features, b.size, return_intermediates=True,
+                                                reference_ops=self.reference_ops)
+        self.last = inter
+        out = BoxList(bb, b.size, mode="xyxy")
+        out.add_field("ids", b.get_field("ids"))
+        out.add_field("labels", b.get_field("labels"))
+        out.add_field("scores", conf)
+        return {}, [out], {}
+
+    def extract_cache(self, features, detection):
+        z, sr_bbox = self.O.extract_cache(self.ocfg, list(features), detection.bbox)
+        w, h = detection.size
+        pad = self.track_utils.pad_pixels
+        sr = BoxList(sr_bbox, [int(w + 2 * pad), int(h + 2 * pad)], mode="xyxy")
+        for f in detection.fields():
+            sr.add_field(f, detection.get_field(f))
+        return z, [sr], [detection]
+
+
+def iou_rows(a, b):
+    """IoU of matching rows (continuous boxes, no +1)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    iw = np.clip(np.minimum(a[:, 2], b[:, 2]) - np.maximum(a[:, 0], b[:, 0]), 0, None)
+    ih = np.clip(np.minimum(a[:, 3], b[:, 3]) - np.maximum(a[:, 1], b[:, 1]), 0, None)
+    inter = iw * ih
+    ua = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter
+    return np.where(ua > 0, inter / np.maximum(ua, 1e-30), 1.0)
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, "sequence_%s.npz" % name))
+
+
+def detections_boxlist(inp, t, device):
+    boxes, scores = inp.detections(t)
+    bl = BoxList(torch.from_numpy(boxes).to(device), inp.case["image_wh"], mode="xyxy")
+    bl.add_field("ids", torch.full((len(boxes),), -1, dtype=torch.int64, device=device))
+    bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64, device=device))
+    bl.add_field("scores", torch.from_numpy(scores).to(device))
+    return bl
+
+
+FLIP_MARGIN = 3e-6     # an arg-max of the reference whose best and second-best penalised scores are closer than this
+                       # can fall on the other cell in another fp32 implementation (tower summation order);
+                       # measured flips sit at margins of 1e-7 (profiles/r02_argmax_stats_n100.md)
+
+
+def probe_tracker(emm):
+    """Record the raw output of the head (before refinement / solver) of every frame: wraps ``forward`` and
+    ``track_raw`` of the instance.  Returns a dict whose ``last`` entry is ``(boxes, scores)`` or None."""
+    box = {"last": None}
+    fwd = emm.forward
+
+    def forward(features, boxes, sr, targets=None, template_features=None):
+        out = fwd(features, boxes, sr, targets=targets, template_features=template_features)
+        box["last"] = (out[1][0].bbox, out[1][0].get_field("scores"))
+        return out
+    emm.forward = forward
+    raw = getattr(emm, "track_raw", None)
+    if raw is not None:
+        def track_raw(*a, **k):
+            bb, conf = raw(*a, **k)
+            box["last"] = (bb, conf)
+            return bb, conf
+        emm.track_raw = track_raw
+    return box
+
+
+def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None):
+    """Run the loop over the sequence and compare every frame with the golden: ids, labels, pool state and memory
+    ids must be IDENTICAL in every frame; boxes >= 1 - 1e-3 IoU, scores within 1e-4.  With ``probe``
+    (``probe_tracker``) the raw head output is compared too, and a tracked row that lands one arg-max cell away from
+    the reference's is accepted ONLY when the reference's own stored margin for that row is below FLIP_MARGIN; that
+    track id is then held to IoU >= 0.97 from there on (its template moved by a cell) and reported in ``flips``.
+    Returns a dict of statistics; raises AssertionError (frame, row, stored margins) at the first divergence."""
+    n_frames = int(golden["n_frames"]) if frames is None else frames
+    pool = loop.solver.track_pool
+    stats = dict(min_iou=1.0, max_box_err=0.0, max_score_err=0.0, rows=0, frames=n_frames, tracked_rows=0,
+                 raw_rows=0, raw_max_box_err=0.0, raw_max_score_err=0.0, flips=[])
+    tainted = set()
+    loop.reset()
+    for t in range(n_frames):
+        p = "f%02d_" % t
+        feats_np = inp.features(t)
+        chk = np.array([float(f.astype(np.float64).sum()) for f in feats_np] +
+                       [float(np.abs(f.astype(np.float64)).sum()) for f in feats_np])
+        np.testing.assert_allclose(chk, golden[p + "feat_checksum"], rtol=1e-9, err_msg="inputs drifted, frame %d" % t)
+        feats = tuple(torch.from_numpy(f).to(device) for f in feats_np)
+        if probe is not None:
+            probe["last"] = None
+        out = loop(feats, detections_boxlist(inp, t, device))
+        has_trk = (p + "trk_margin") in golden.files
+        margin = golden[p + "trk_margin"] if has_trk else np.array([np.inf])
+        ctx = "case %s frame %d (min stored arg-max margin of the frame %.2e; flips so far %s)" % (
+            inp.name, t, float(margin.min()), stats["flips"])
+        # ---- the head's raw output (the tracked boxes before the solver) ------------------------------------------
+        if probe is not None and has_trk:
+            assert probe["last"] is not None, "the head did not run: " + ctx
+            rb, rs = probe["last"][0].cpu().numpy(), probe["last"][1].cpu().numpy()
+            gb, gs, gid = golden[p + "trk_boxes"], golden[p + "trk_scores"], golden[p + "trk_ids"]
+            assert rb.shape == gb.shape, "tracked rows %s vs %s: %s" % (rb.shape, gb.shape, ctx)
+            err = np.abs(rb - gb).max(axis=1)
+            for r in np.nonzero(err > 0.05)[0].tolist():
+                tid = int(gid[r])
+                if tid in tainted:
+                    continue
+                assert margin[r] < FLIP_MARGIN, "row %d (id %d) moved by %.3f px although the reference's arg-max " \
+                    "margin is %.2e: %s" % (r, tid, err[r], margin[r], ctx)
+                stats["flips"].append((t, tid, float(margin[r]), float(err[r])))
+                tainted.add(tid)
+            clean = np.array([int(i) not in tainted for i in gid])
+            if clean.any():
+                stats["raw_max_box_err"] = max(stats["raw_max_box_err"], float(err[clean].max()))
+                stats["raw_max_score_err"] = max(stats["raw_max_score_err"], float(np.abs(rs - gs)[clean].max()))
+            stats["raw_rows"] += len(gid)
+        # ---- the frame's result -----------------------------------------------------------------------------------
+        ids = out.get_field("ids").cpu().numpy()
+        assert ids.tolist() == golden[p + "out_ids"].tolist(), "ids differ: %s\n got %s\n ref %s" % (
+            ctx, ids.tolist(), golden[p + "out_ids"].tolist())
+        boxes = out.bbox.cpu().numpy()
+        scores = out.get_field("scores").cpu().numpy()
+        if len(ids):
+            iou = iou_rows(boxes, golden[p + "out_boxes"])
+            clean = np.array([int(i) not in tainted for i in ids])
+            if clean.any():
+                stats["min_iou"] = min(stats["min_iou"], float(iou[clean].min()))
+                stats["max_box_err"] = max(stats["max_box_err"], float(np.abs(boxes - golden[p + "out_boxes"])[clean].max()))
+                assert iou[clean].min() >= 1 - 1e-3, "box IoU %.6f at row %d: %s" % (
+                    iou[clean].min(), int(np.nonzero(clean)[0][iou[clean].argmin()]), ctx)
+            assert iou.min() >= 0.97, "box IoU %.4f of a track downstream of an attributed flip: %s" % (iou.min(), ctx)
+            stats["max_score_err"] = max(stats["max_score_err"], float(np.abs(scores - golden[p + "out_scores"]).max()))
+            assert np.abs(scores - golden[p + "out_scores"])[clean].max(initial=0.0) < 1e-4, "scores differ: %s" % ctx
+            assert out.get_field("labels").cpu().numpy().tolist() == golden[p + "out_labels"].tolist(), ctx
+        stats["rows"] += len(ids)
+        stats["tracked_rows"] += int((ids >= 0).sum())
+        # ---- pool state and the next frame's memory -----------------------------------------------------------------
+        assert sorted(pool.get_active_ids()) == golden[p + "pool_active"].tolist(), "active ids: " + ctx
+        dorm = sorted((int(k), int(v)) for k, v in pool._dormant_ids.items())
+        assert dorm == [tuple(r) for r in golden[p + "pool_dormant"].tolist()], "dormant ids: " + ctx
+        assert pool._max_id == int(golden[p + "pool_max_id"]), "max id: " + ctx
+        mem = loop.track_memory
+        mem_ids = mem[2][0].get_field("ids").cpu().numpy().tolist()
+        assert mem_ids == golden[p + "mem_ids"].tolist(), "memory ids: " + ctx
+        if len(mem_ids):
+            assert mem[0].shape[0] == len(mem_ids) == len(mem[1][0]), "memory rows: " + ctx
+            miou = iou_rows(mem[2][0].bbox.cpu().numpy(), golden[p + "mem_boxes"])
+            mclean = np.array([i not in tainted for i in mem_ids])
+            assert miou[mclean].min(initial=1.0) >= 1 - 1e-3 and miou.min() >= 0.97, "memory boxes: " + ctx
+            serr = np.abs(mem[1][0].bbox.cpu().numpy() - golden[p + "mem_sr"]).max(axis=1)
+            assert serr[mclean].max(initial=0.0) < 0.2, "memory search regions: " + ctx
+        if on_frame is not None:
+            on_frame(t, out)
+    return stats

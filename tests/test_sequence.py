@@ -1,0 +1,111 @@
+"""Closed-loop parity: the sequences that the reference's own CombinedROIHeads.forward produced with
+its own TrackHead / TrackSolver / TrackPool AND its own EMM in the loop (oracle/gen_golden_sequence.py,
+tests/golden/sequence_{plain,refine}.npz) replayed through this repository's ``TrackingLoop``:
+
+  CPU   the oracle restatement behind the EMM interface + the host solver (pins oracle and host glue in the loop);
+  GPU   the HIP head through (i) the general path, (ii) the lean one-launch path, (iii) ``RefineTracks`` on.
+"""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+import sequence_replay as SR
+from oracle import solver_oracle as SO
+from siammot_amd.box_refine import RefineTracks, TrackBoxHead
+from siammot_amd.solver import TrackPool, TrackSolver, builder_tracker_solver
+from siammot_amd.track_head import TrackHead, TrackingLoop
+from siammot_amd.track_utils import build_track_utils
+
+
+def _numpy_mask(boxes, scores, thresh):
+    keep = SO.nms_indices(boxes.cpu().numpy(), scores.cpu().numpy(), thresh)
+    m = torch.zeros(len(boxes), dtype=torch.bool)
+    m[torch.from_numpy(keep)] = True
+    return m
+
+
+def _numpy_boxlist_nms(boxlist, thresh):
+    keep = SO.nms_indices(boxlist.bbox.cpu().numpy(), boxlist.get_field("scores").cpu().numpy(), thresh)
+    return boxlist[torch.from_numpy(keep)]
+
+
+def _cpu_loop(name):
+    from oracle import box_head_oracle as BO
+    inp = gi.SequenceInputs(name)
+    case = inp.case
+    cfg = SR.sequence_cfg(case)
+    tu = build_track_utils(cfg)
+    pool = TrackPool(max_dormant_frames=case["max_dormant_frames"])
+    emm = SR.OracleEMM(inp.params, case["channels"], tu)
+    refine = None
+    if case["refine"]:
+        b = case["box_head"]
+        box = TrackBoxHead(cfg, case["channels"], nms_fn=_numpy_boxlist_nms,
+                           pooler=BO.OraclePooler(b["resolution"], cfg.MODEL.ROI_BOX_HEAD.POOLER_SCALES,
+                                                  b["sampling_ratio"])).eval()
+        box.load_state_dict({k: torch.from_numpy(v) for k, v in inp.box_head_params.items()})
+        refine = RefineTracks(box)
+    solver = TrackSolver(pool, *case["thresholds"], nms_mask_fn=_numpy_mask)
+    return inp, emm, TrackingLoop(TrackHead(emm, tu, pool).eval(), solver, refine).eval()
+
+
+@pytest.mark.parametrize("name", ["plain", "refine"])
+def test_closed_loop_on_cpu_equals_the_reference(name):
+    """Oracle head + this repository's TrackHead / solver / pool (+ RefineTracks / TrackBoxHead over the oracle
+    pooler) reproduce the reference's closed loop: same ids, same pool, boxes to fp32 rounding — every event type
+    fires in the sequence."""
+    golden = SR.load_golden(name)
+    for ev in ("start", "suspend", "resume", "expire"):
+        assert int(golden["events_" + ev]) > 0, ev
+    inp, emm, loop = _cpu_loop(name)
+    with torch.no_grad():
+        stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm))
+    assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
+    assert stats["tracked_rows"] > 300 and stats["raw_rows"] > 300, stats
+
+
+def _gpu_loop(name, lean):
+    from siammot_amd.emm import EMM
+    inp = gi.SequenceInputs(name)
+    case = inp.case
+    cfg = SR.sequence_cfg(case)
+    dev = "cuda:0"
+    tu = build_track_utils(cfg)
+    pool = TrackPool(max_dormant_frames=case["max_dormant_frames"])
+    emm = EMM(cfg, tu).to(dev).eval()
+    emm.predictor.load_state_dict({k: torch.from_numpy(v) for k, v in inp.params.items()})
+    refine = None
+    if case["refine"]:
+        box = TrackBoxHead(cfg, case["channels"]).to(dev).eval()
+        box.load_state_dict({k: torch.from_numpy(v) for k, v in inp.box_head_params.items()})
+        refine = RefineTracks(box)
+    solver = builder_tracker_solver(cfg, pool)
+    loop = TrackingLoop(TrackHead(emm, tu, pool).eval(), solver, refine).eval()
+    if not lean:
+        loop._lean_ok = lambda detections: False
+    return inp, emm, loop
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("refine", False), ("refine", True)])
+def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
+    """The real head in the loop, on the device: (i) general path, (ii) lean one-launch path, (iii) refinement on
+    (general and lean).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
+    may sit one arg-max cell away only where the reference's own margin is below SR.FLIP_MARGIN (reported)."""
+    golden = SR.load_golden(name)
+    inp, emm, loop = _gpu_loop(name, lean)
+    taken = {"lean": 0}
+    if lean:
+        step = loop._step_lean
+
+        def counted(*a, **k):
+            taken["lean"] += 1
+            return step(*a, **k)
+        loop._step_lean = counted
+    stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm))
+    print("closed loop %s lean=%s: %s" % (name, lean, stats))
+    if lean:
+        assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken
+    assert len(stats["flips"]) <= 2, stats
+    assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < 1e-4, stats

@@ -110,6 +110,41 @@ def test_track_pool_cache_and_life_cycle():
         pool.resume_track(0)
 
 
+def test_lazy_cache_drops_expired_ids_for_good():
+    """an id that expires while its row still sits in the lazily noted memory of the previous frame must not
+    come back through the next full flush (its entry would pin that frame's whole template tensor until reset())."""
+    from siammot_amd.solver import TrackPool
+    from siammot_amd.structures import BoxList
+    cap = TrackPool.DEVICE_CAPACITY
+
+    def memory(ids):
+        n = len(ids)
+        b = BoxList(torch.arange(4 * n).reshape(n, 4).float(), (100, 100))
+        b.add_field("ids", torch.tensor(ids))
+        return (torch.arange(n * 3).reshape(n, 3).float(), [b], [b])
+
+    def record(active, dormant, max_id, frame, M=4):
+        rec = np.zeros(8 + 3 * M + 3 * cap, dtype=np.int32)
+        rec[2], rec[3], rec[4], rec[5] = max_id, frame, len(active), len(dormant)
+        base = 8 + 3 * M
+        rec[base:base + len(active)] = sorted(active)
+        d = sorted(dormant.items())
+        rec[base + cap:base + cap + len(d)] = [k for k, _ in d]
+        rec[base + 2 * cap:base + 2 * cap + len(d)] = [v for _, v in d]
+        return rec
+
+    pool = TrackPool(max_dormant_frames=1)
+    pool._mirror(record({0, 1, 2}, {}, 2, 1), 4)
+    pool.note_memory(memory([0, 1, 2]), [0, 1, 2])
+    pool._mirror(record({0, 2}, {1: 0}, 2, 2), 4)              # id 1 goes dormant: materialised from the noted memory
+    assert set(pool.get_cache()) == {0, 1, 2}
+    pool.note_memory(memory([0, 2, 1]), [0, 2, 1])             # the dormant row is re-appended (track_head.py:77-98)
+    pool._mirror(record({0, 2}, {}, 2, 3), 4)                  # id 1 expires
+    assert 1 in pool._kill_ids
+    cache = pool.get_cache()                                   # full flush of the memory that still lists id 1
+    assert set(cache) == {0, 2} and set(cache) <= pool.get_active_ids() | pool.get_dormant_ids()
+
+
 @pytest.mark.gpu
 def test_solver_on_the_device_with_the_hip_nms():
     _run("cuda:0", None)
