@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 3
+#define SMOT_ABI_VERSION 4
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -82,6 +82,28 @@ int smot_roi_align_levels_fwd(const float* const* feats, const int* heights, con
                               const float* rois, const float* level_boxes, int R,
                               int out_h, int out_w, int sampling_ratio,
                               float* out, int32_t* levels_out, smot_stream_t stream);
+
+/*
+ * Single-level ROIAlign with upstream's native signature (SURVEY.md §8(b) "Native boundary").
+ *
+ * Replaces: [UPSTREAM] maskrcnn_benchmark._C.roi_align_forward(Tensor input, Tensor rois, float spatial_scale,
+ *   int pooled_h, int pooled_w, int sampling_ratio) -> Tensor, the call inside layers/roi_align.py::ROIAlign.forward
+ *   that the reference reaches through SRPooler (EMM/sr_pool.py:28-31,89) and the box head's Pooler
+ *   (box_head/box_head.py:46): legacy (non-"aligned") ROIAlign, sampling_ratio x sampling_ratio samples per bin.
+ *
+ *   input   device [num_images, C, H, W] contiguous
+ *   rois5   device [R,5] = (image index, x1, y1, x2, y2), the tensor convert_to_roi_format builds (sr_pool.py:40-51);
+ *           the image index is honoured (a row whose index is outside [0, num_images) pools to zeros — upstream reads
+ *           out of bounds there)
+ *   out     device [R, C, pooled_h, pooled_w], caller-allocated
+ *   pad_cells  0 for upstream's behaviour; > 0 treats the map as zero-padded by that many cells on every side
+ *           (TrackUtils.pad_feature, track_utils.py:87-107) with rois in padded coordinates, without the padded copy.
+ * SMOT_ERR_UNSUPPORTED: sampling_ratio <= 0 (adaptive grid) or > 4.  The reference-side monkey patch is in
+ * INTEGRATION.md §2.
+ */
+int smot_roi_align_fwd(const float* input, int num_images, int C, int H, int W, int pad_cells,
+                       const float* rois5, int R, float spatial_scale, int pooled_h, int pooled_w,
+                       int sampling_ratio, float* out, smot_stream_t stream);
 
 /*
  * Search-region boxes from template boxes.

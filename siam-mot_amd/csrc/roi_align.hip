@@ -28,7 +28,10 @@ template <int G>
 __global__ void __launch_bounds__(256)
 roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
                         const float* __restrict__ level_boxes, int PH, int PW, int ch_per_block,
-                        float* __restrict__ out, int32_t* __restrict__ levels_out) {
+                        float* __restrict__ out, int32_t* __restrict__ levels_out, int num_images) {
+    // num_images == 0: rois are [R,4] on the one image of the call (the level-routed pooler).
+    // num_images >= 1: rois are [R,5] = (image index, x1, y1, x2, y2) as upstream's _C.roi_align_forward takes them,
+    //                  P.feat[0] is [num_images, C, H, W]; a row whose index is out of range pools to zeros.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int wbound[4];              // ymin, ymax, xmin, xmax of the cells with non-zero weight
     const int ny = PH * G, nx = PW * G;
@@ -43,7 +46,8 @@ roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
     float* wx_hi = wx_lo + nx;
 
     const int r = blockIdx.x;
-    const float* roi = rois + (size_t)r * 4;
+    const float* roi = num_images ? rois + (size_t)r * 5 + 1 : rois + (size_t)r * 4;
+    const int image = num_images ? (int)rois[(size_t)r * 5] : 0;
     int lvl = 0;
     if (P.num_levels > 1) lvl = map_level(level_boxes + (size_t)r * 4, P.k_min, P.k_max);
     if (levels_out != nullptr && blockIdx.y == 0 && threadIdx.x == 0) levels_out[r] = lvl;
@@ -96,8 +100,8 @@ roi_align_levels_kernel(LevelParams P, int C, const float* __restrict__ rois,
     const int c0 = blockIdx.y * ch_per_block;
     const int c1 = min(C, c0 + ch_per_block);
     const int bins = PH * PW;
-    const float* __restrict__ f = P.feat[lvl];
-    if (ymax < ymin || xmax < xmin) {
+    const float* __restrict__ f = P.feat[lvl] + (size_t)image * C * H * W;
+    if (ymax < ymin || xmax < xmin || image < 0 || image >= max(num_images, 1)) {
         // every sample lies in the virtual zero border (or outside the padded map): exact zeros
         for (int c = c0; c < c1; ++c)
             for (int t = threadIdx.x; t < bins; t += blockDim.x) out[((size_t)r * C + c) * bins + t] = 0.0f;
@@ -255,9 +259,50 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
         const int rco = ensure_lds_optin((const void*)roi_align_levels_kernel<G>, 96 * 1024, "roi_align");   \
         if (rco) return rco;                                                                             \
         hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois, level_boxes, \
-                           out_h, out_w, ch_per_block, out, levels_out);                                 \
+                           out_h, out_w, ch_per_block, out, levels_out, 0);                              \
     }
     SMOT_REQUIRE(smem <= 96 * 1024, "roi_align: pooled size %dx%d needs too much LDS", out_h, out_w);
+    switch (sampling_ratio) {
+        case 1: LAUNCH(1); break;
+        case 2: LAUNCH(2); break;
+        case 3: LAUNCH(3); break;
+        default: LAUNCH(4); break;
+    }
+#undef LAUNCH
+    return check_launch("roi_align");
+}
+
+extern "C" int smot_roi_align_fwd(const float* input, int num_images, int C, int H, int W, int pad_cells,
+                                  const float* rois5, int R, float spatial_scale, int pooled_h, int pooled_w,
+                                  int sampling_ratio, float* out, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(num_images > 0 && C > 0 && H > 0 && W > 0 && pooled_h > 0 && pooled_w > 0 && R >= 0 && pad_cells >= 0 &&
+                     spatial_scale > 0.f,
+                 "roi_align: bad sizes B=%d C=%d H=%d W=%d pooled=%dx%d R=%d pad=%d scale=%g", num_images, C, H, W,
+                 pooled_h, pooled_w, R, pad_cells, (double)spatial_scale);
+    if (sampling_ratio <= 0 || sampling_ratio > 4) {
+        set_error("roi_align: sampling_ratio=%d unsupported (need 1..4; adaptive grid not implemented)",
+                  sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (R == 0) return SMOT_OK;
+    SMOT_REQUIRE(input && rois5 && out, "roi_align: null pointer");
+    LevelParams P;
+    {
+        const int rc = fill_level_params(&P, &input, &H, &W, &pad_cells, &spatial_scale, 1, "roi_align");
+        if (rc) return rc;
+    }
+    dim3 grid(R, (C + RA_CH - 1) / RA_CH);
+    const size_t smem = (size_t)(pooled_h + pooled_w) * sampling_ratio * 16 + (size_t)RA_CH * RA_WIN_FLOATS * sizeof(float);
+    SMOT_REQUIRE(smem <= 96 * 1024, "roi_align: pooled size %dx%d needs too much LDS", pooled_h, pooled_w);
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(G)                                                                                        \
+    {                                                                                                    \
+        const int rco = ensure_lds_optin((const void*)roi_align_levels_kernel<G>, 96 * 1024, "roi_align");   \
+        if (rco) return rco;                                                                             \
+        hipLaunchKernelGGL(roi_align_levels_kernel<G>, grid, dim3(256), smem, st, P, C, rois5,           \
+                           (const float*)nullptr, pooled_h, pooled_w, RA_CH, out, (int32_t*)nullptr, num_images); \
+    }
     switch (sampling_ratio) {
         case 1: LAUNCH(1); break;
         case 2: LAUNCH(2); break;

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -38,6 +38,7 @@ _SIGNATURES = {
     "smot_last_error": (ctypes.c_char_p, []),
     "smot_roi_align_levels_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i,
                                                  _vp, _vp, _vp]),
+    "smot_roi_align_fwd": (ctypes.c_int, [_vp, _i, _i, _i, _i, _i, _vp, _i, _f, _i, _i, _i, _vp, _vp]),
     "smot_search_region_fwd": (ctypes.c_int, [_vp, _i, _f, _f, _f, _vp, _vp]),
     "smot_xcorr_dw_fwd": (ctypes.c_int, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp, _vp]),
@@ -241,6 +242,26 @@ def roi_align_levels(features, rois, level_boxes, out_size, scales, sampling_rat
                                            int(sampling_ratio), _ptr(out), _ptr(levels), ln.stream)
     _check(rc, "roi_align_levels")
     return (out, levels) if return_levels else out
+
+
+def roi_align(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, pad_cells=0):
+    """[UPSTREAM] ``_C.roi_align_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio)``: one feature
+    level ``[B,C,H,W]``, rois ``[R,5]`` = (image index, x1, y1, x2, y2) -> ``[R,C,pooled_h,pooled_w]``, allocated here
+    with the input's options as upstream does.  ``pad_cells`` > 0: virtual zero border (rois in padded coordinates)."""
+    lib = load_library()
+    input = _dev_f32(input, "input")
+    rois = _dev_f32(rois, "rois")
+    if input.dim() != 4 or rois.dim() != 2 or rois.shape[1] != 5:
+        raise RuntimeError("siammot_amd.roi_align: input must be [B,C,H,W] and rois [R,5], got %s and %s"
+                           % (tuple(input.shape), tuple(rois.shape)))
+    B, C, H, W = input.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, int(pooled_h), int(pooled_w)), dtype=torch.float32, device=input.device)
+    with _Launch(input, rois) as ln:
+        rc = lib.smot_roi_align_fwd(_ptr(input), B, C, H, W, int(pad_cells), _ptr(rois), R, float(spatial_scale),
+                                    int(pooled_h), int(pooled_w), int(sampling_ratio), _ptr(out), ln.stream)
+    _check(rc, "roi_align")
+    return out
 
 
 def search_region(boxes, pad_pixels, search_expansion, min_search_wh):

@@ -15,6 +15,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 import golden_inputs as gi
 from oracle import emm_oracle as O
@@ -754,6 +755,47 @@ def test_box_head_pooler_7x7(ops):
     _assert_close(out, ref, 1e-5, 1e-5, "box-head Pooler 7x7")
     lv = O.level_mapper(_t(props))
     assert len(set(lv.tolist())) == 4           # all four levels exercised
+
+
+@pytest.mark.parametrize("ph,pw,g", [(7, 7, 2), (5, 9, 3), (30, 30, 2), (15, 15, 1)])
+def test_roi_align_upstream_signature_honours_the_image_index(ops, ph, pw, g):
+    """``smot_roi_align_fwd`` = [UPSTREAM] ``_C.roi_align_forward(input, rois[R,5], scale, ph, pw, sampling)``
+    (SURVEY.md §8(b) "Native boundary"): a batch of three images, rois that name their image, one row with an index
+    outside the batch (zeros).  Against the oracle's per-image ROIAlign; the ``layers.ROIAlign`` module is the
+    upstream-shaped layer over it; ``pad_cells`` equals pooling the explicitly zero-padded batch."""
+    from siammot_amd.layers import ROIAlign
+    rs = np.random.RandomState(100 * ph + g)
+    B, C, H, W = 3, 6, 40, 56
+    feat = rs.standard_normal((B, C, H, W)).astype(np.float32)
+    R = 23
+    wh = np.exp(rs.uniform(np.log(6), np.log(300), (R, 2)))
+    xy = rs.uniform(-30, 400, (R, 2)) * np.array([1.0, 0.7])
+    rois = np.concatenate((rs.randint(0, B, (R, 1)).astype(np.float64), xy, xy + wh), 1).astype(np.float32)
+    ref = O.roi_align(_t(feat), _t(rois), 0.125, ph, pw, g)
+    layer = ROIAlign((ph, pw), 0.125, g)
+    out = layer(_d(feat), _d(rois))
+    assert tuple(out.shape) == (R, C, ph, pw) and out.device.type == "cuda"
+    _assert_close(out, ref, 1e-5, 1e-5, "roi_align (upstream signature)")
+    bad = rois.copy()
+    bad[4, 0] = B
+    bad[5, 0] = -1
+    out_bad = ops.roi_align(_d(feat), _d(bad), 0.125, ph, pw, g)
+    assert float(out_bad[4].abs().max()) == 0.0 and float(out_bad[5].abs().max()) == 0.0
+    keep = [i for i in range(R) if i not in (4, 5)]
+    assert torch.equal(out_bad[keep], out[keep])
+    # virtual padding == pooling the padded batch with rois moved by the pad
+    pad = 9
+    padded = F.pad(_t(feat), [pad] * 4)
+    moved = rois.copy()
+    moved[:, 1:] += pad / 0.125
+    ref_p = O.roi_align(padded, _t(moved), 0.125, ph, pw, g)
+    out_p = ops.roi_align(_d(feat), _d(moved), 0.125, ph, pw, g, pad_cells=pad)
+    _assert_close(out_p, ref_p, 1e-5, 1e-5, "roi_align with virtual padding")
+    assert ops.roi_align(_d(feat), _d(rois[:0]), 0.125, ph, pw, g).shape == (0, C, ph, pw)
+    with pytest.raises(RuntimeError):
+        ops.roi_align(_d(feat), _d(rois[:, :4]), 0.125, ph, pw, g)
+    with pytest.raises(RuntimeError):
+        ops.roi_align(_d(feat), _d(rois), 0.125, ph, pw, 0)
 
 
 def _nms_reference(boxes, scores, thresh):
