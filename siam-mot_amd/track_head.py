@@ -161,7 +161,7 @@ class TrackingLoop(torch.nn.Module):
         ring.wait(rec_host)                                                        # the frame's one synchronisation
         rec = rec_host.numpy()[:8 + 3 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
-        pool._mirror(rec, M)
+        pool._mirror(rec, M, len(detections))
         oi, ol, ai, al = ibuf.split((M, M, M, M))
         cls = detections.__class__
         out = cls(ob.view(M, 4)[:K], detections.size, mode="xyxy")

@@ -60,7 +60,8 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
         assert int(golden["events_" + ev]) > 0, ev
     inp, emm, loop = _cpu_loop(name)
     with torch.no_grad():
-        stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm))
+        stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm),
+                          box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
     assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
     assert stats["tracked_rows"] > 300 and stats["raw_rows"] > 300, stats
 
@@ -103,7 +104,8 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
             taken["lean"] += 1
             return step(*a, **k)
         loop._step_lean = counted
-    stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm))
+    stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm),
+                      box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
     print("closed loop %s lean=%s: %s" % (name, lean, stats))
     if lean:
         assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken

@@ -145,6 +145,61 @@ def test_lazy_cache_drops_expired_ids_for_good():
     assert set(cache) == {0, 2} and set(cache) <= pool.get_active_ids() | pool.get_dormant_ids()
 
 
+def test_mirror_keeps_the_reference_order_of_dormant_ids():
+    """The device path hands the id tables back sorted; the row order of dormant tracks in the next memory follows the
+    insertion order of the reference's ``_dormant_ids`` dict (track_head.py:83), i.e. the order its solver suspends
+    ids in.  ``TrackPool._mirror`` rebuilds that order from the record; here the record is synthesised from the host
+    path (the reference's statements on the same Python containers) and the two dicts must agree item by item."""
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.structures import BoxList
+    cap = TrackPool.DEVICE_CAPACITY
+    pool_a = TrackPool(max_dormant_frames=3)
+    pool_b = TrackPool(max_dormant_frames=3)
+    solver = TrackSolver(pool_a, 0.4, 0.6, 0.4, nms_mask_fn=_numpy_mask)
+    rs = np.random.RandomState(5)
+    multi = 0
+    for f in range(60):
+        tracks = [t for t in list(pool_a.get_active_ids()) + list(pool_a.get_dormant_ids()) if rs.rand() > 0.1]
+        rs.shuffle(tracks)
+        n_det = int(rs.randint(0, 12))
+        n = n_det + len(tracks)
+        c = rs.uniform(60, [1200, 640], (n, 2))
+        if n > 4:
+            c[n // 2:] = c[rs.randint(0, n // 2, n - n // 2)] + rs.normal(0, 8, (n - n // 2, 2))
+        wh = rs.uniform(30, 110, (n, 2))
+        boxes = np.concatenate((c - wh / 2, c + wh / 2), 1).astype(np.float32)
+        ids = np.concatenate((np.full(n_det, -1), np.array(tracks, dtype=np.int64))).astype(np.int64)
+        scores = np.concatenate((rs.uniform(0.05, 0.999, n_det), 1.0 + rs.uniform(0.05, 1.0, len(tracks)))).astype(np.float32)
+        bl = BoxList(torch.from_numpy(boxes), (1280, 704), mode="xyxy")
+        bl.add_field("ids", torch.from_numpy(ids))
+        bl.add_field("scores", torch.from_numpy(scores.copy()))
+        before = set(pool_a._dormant_ids)
+        keep_mask = _numpy_mask(torch.from_numpy(boxes), torch.from_numpy(
+            scores + np.isin(ids, list(pool_a.get_active_ids())).astype(np.float32)), 0.5).numpy()
+        out = solver([bl])[0]
+        rows = np.nonzero(keep_mask)[0]
+        final = out.get_field("ids").numpy()
+        assert len(rows) == len(final)
+        M = n
+        rec = np.zeros(8 + 3 * M + 3 * cap, dtype=np.int32)
+        rec[0], rec[2], rec[3] = len(rows), pool_a._max_id, pool_a._frame_idx
+        rec[4], rec[5] = len(pool_a._active_ids), len(pool_a._dormant_ids)
+        rec[8:8 + len(rows)] = rows
+        rec[8 + M:8 + M + len(rows)] = final
+        base = 8 + 3 * M
+        rec[base:base + rec[4]] = sorted(pool_a._active_ids)
+        d = sorted(pool_a._dormant_ids.items())
+        rec[base + cap:base + cap + len(d)] = [k for k, _ in d]
+        rec[base + 2 * cap:base + 2 * cap + len(d)] = [v for _, v in d]
+        pool_b._memory_ids = [int(t) for t in tracks]
+        pool_b._mirror(rec, M, n_det)
+        assert list(pool_b._dormant_ids.items()) == list(pool_a._dormant_ids.items()), "frame %d" % f
+        assert list(pool_b.get_dormant_ids()) == list(pool_a.get_dormant_ids())
+        assert pool_b._active_ids == pool_a._active_ids and pool_b._max_id == pool_a._max_id
+        multi += len(set(pool_a._dormant_ids) - before) > 1
+    assert multi >= 5 and pool_a._max_id > 100       # several frames suspended more than one id at once
+
+
 @pytest.mark.gpu
 def test_solver_on_the_device_with_the_hip_nms():
     _run("cuda:0", None)
