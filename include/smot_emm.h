@@ -336,7 +336,7 @@ int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heig
  *   out_*          kept rows in ascending original order (boxes [M,4], scores back in [0,1], ids with new ids
  *                  started and inactive ones set to -1, labels); M = n_det + n_trk rows of capacity each.
  *   act_*          the rows of the output whose id is active after the update (the next frame's track targets).
- *   record         int32 [8 + 3*M + 3*pool_capacity], DEVICE memory or device-accessible pinned HOST memory (the
+ *   record         int32 [8 + 4*M + 3*pool_capacity], DEVICE memory or device-accessible pinned HOST memory (the
  *                  kernel's stores then land in host memory directly and the caller needs no copy, only an event
  *                  behind this launch): K (kept), A (active rows), max_id, frame_idx,
  *                  n_active, n_dormant, table overflow flag, M; kept original row [M]; kept id [M]; active-row id

@@ -711,19 +711,54 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                     cs[b] = c_;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // gathers in two groups of rows: all ds_bpermutes of a group are issued back to back and waited for
-                // once (one LDS round trip per group instead of one per tap); two groups keep the register peak
-                // (column sums + gathered taps + tables) under the 128 the correlation phase is scheduled for
+                // Horizontal taps.  A lane (= pooled column) needs the column sums of up to four window columns (other
+                // lanes' values).  ds_bpermute_b32 cost 10.6 LDS cycles per wave instruction here (SQ_LDS_IDX_ACTIVE,
+                // profiles/r02aa_pmc_counters.md: two thirds of the LDS pipe's busy time) — so the sums of a group of
+                // rows are staged in LDS instead (one ds_write_b32 per row, 2 array cycles) and every tap is a plain
+                // ds_read_b32 (2 cycles): 10 instead of 42 LDS cycles per pooled row.  The staging rows are this
+                // wave's own not-yet-written rows of the plane image (the batch's results are stored after its last
+                // gather; LDS operations of one wave execute in order, so neither a wait nor a barrier is needed).
+                // Rows are processed in two groups to keep the register peak (column sums + gathered taps + tables)
+                // where the correlation phase is scheduled for.  Same values, same FMA order: bit-identical.
                 constexpr int GR = (ROWS + 1) / 2;
+                if constexpr (!CHUNKED) {
+                    constexpr int SW = PAIR ? 32 : 64;                               // staged floats per row (and plane)
+                    static_assert(GR * SW <= ROWS * XS, "staging fits the batch's own image rows");
+                    float* stage = xdst + r0 * XS;
+#pragma unroll
+                    for (int g0 = 0; g0 < ROWS; g0 += GR) {
+#pragma unroll
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b) stage[(b - g0) * SW + col] = cs[b];
+                        float p[GR][G][2];
+#pragma unroll
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                            for (int ix = 0; ix < G; ++ix) {
+                                p[b - g0][ix][0] = stage[(b - g0) * SW + sxl[ix]];
+                                p[b - g0][ix][1] = stage[(b - g0) * SW + sxh[ix]];
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                            for (int ix = 0; ix < G; ++ix) {
+                                // (acc[b] is not live across the loads here: first written in this group)
+                                acc[b] = fmaf(hxw[ix], p[b - g0][ix][0], ix == 0 ? 0.0f : acc[b]);
+                                acc[b] = fmaf(lxw[ix], p[b - g0][ix][1], acc[b]);
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                // windows wider than a wave (rare): cross-lane gathers per 64-column chunk, two groups of rows
                 int al[G], ah[G];
                 bool inl[G], inh[G];
 #pragma unroll
                 for (int ix = 0; ix < G; ++ix) {
                     const int tl = sxl[ix] - cbase, th = sxh[ix] - cbase;
-                    inl[ix] = !CHUNKED || (unsigned)tl < 64u;
-                    inh[ix] = !CHUNKED || (unsigned)th < 64u;
-                    al[ix] = ((tl & 63) + 32 * half) << 2;                    // ds_bpermute takes byte addresses
-                    ah[ix] = ((th & 63) + 32 * half) << 2;
+                    inl[ix] = (unsigned)tl < 64u;
+                    inh[ix] = (unsigned)th < 64u;
+                    al[ix] = (tl & 63) << 2;                                  // ds_bpermute takes byte addresses
+                    ah[ix] = (th & 63) << 2;
                 }
 #pragma unroll
                 for (int g0 = 0; g0 < ROWS; g0 += GR) {
@@ -740,15 +775,11 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                     for (int b = g0; b < g0 + GR && b < ROWS; ++b)
 #pragma unroll
                         for (int ix = 0; ix < G; ++ix) {
-                            if (!CHUNKED) {
-                                // (acc[b] is not live across the loads here: first written in this group)
-                                acc[b] = fmaf(hxw[ix], p[b - g0][ix][0], ix == 0 ? 0.0f : acc[b]);
-                                acc[b] = fmaf(lxw[ix], p[b - g0][ix][1], acc[b]);
-                            } else {      // a tap outside the chunk adds nothing (not even 0 * garbage)
-                                acc[b] = inl[ix] ? fmaf(hxw[ix], p[b - g0][ix][0], acc[b]) : acc[b];
-                                acc[b] = inh[ix] ? fmaf(lxw[ix], p[b - g0][ix][1], acc[b]) : acc[b];
-                            }
+                            // a tap outside the chunk adds nothing (not even 0 * garbage)
+                            acc[b] = inl[ix] ? fmaf(hxw[ix], p[b - g0][ix][0], acc[b]) : acc[b];
+                            acc[b] = inh[ix] ? fmaf(lxw[ix], p[b - g0][ix][1], acc[b]) : acc[b];
                         }
+                }
                 }
             }
 #pragma unroll

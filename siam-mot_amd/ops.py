@@ -750,7 +750,7 @@ class HostRecordRing(object):
     before that buffer is handed out again, so a late store of the old kernel cannot complete a newer record."""
 
     def __init__(self, dev, pool_capacity):
-        n = 8 + 3 * track_solve_max_boxes() + 3 * pool_capacity
+        n = 8 + 4 * track_solve_max_boxes() + 3 * pool_capacity
         self.dev = dev
         self.bufs = [torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
         self.in_flight = [False, False]
@@ -809,7 +809,7 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
             raise RuntimeError("siammot_amd.track_solve: labels must be a contiguous int64 tensor on the boxes' device")
         segs.append((b.data_ptr(), s_.data_ptr(), i_.data_ptr(), l_.data_ptr() if l_ is not None else 0, b.shape[0]))
     M = segs[0][4] + segs[1][4]
-    nrec = 8 + 3 * M + 3 * pool_capacity
+    nrec = 8 + 4 * M + 3 * pool_capacity
     fbuf = torch.empty((10 * max(M, 1),), dtype=_F32, device=dev)
     ibuf = torch.empty((4 * max(M, 1),), dtype=torch.int64, device=dev)
     rec = host_record.next() if host_record else torch.empty((nrec,), dtype=torch.int32, device=dev)

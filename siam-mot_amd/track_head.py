@@ -159,9 +159,9 @@ class TrackingLoop(torch.nn.Module):
         act_boxes = ab.view(M, 4)
         pre = emm.extract_cache_rows(features, act_boxes, state[4:5])              # runs while the host wakes up
         ring.wait(rec_host)                                                        # the frame's one synchronisation
-        rec = rec_host.numpy()[:8 + 3 * M + 3 * pool.DEVICE_CAPACITY].copy()
+        rec = rec_host.numpy()[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
-        pool._mirror(rec, M, len(detections))
+        pool._mirror(rec, M)
         oi, ol, ai, al = ibuf.split((M, M, M, M))
         cls = detections.__class__
         out = cls(ob.view(M, 4)[:K], detections.size, mode="xyxy")

@@ -181,7 +181,8 @@ def test_mirror_keeps_the_reference_order_of_dormant_ids():
         final = out.get_field("ids").numpy()
         assert len(rows) == len(final)
         M = n
-        rec = np.zeros(8 + 3 * M + 3 * cap, dtype=np.int32)
+        rec = np.zeros(8 + 4 * M + 3 * cap, dtype=np.int32)
+        rec[8 + 3 * M + 3 * cap:] = ids
         rec[0], rec[2], rec[3] = len(rows), pool_a._max_id, pool_a._frame_idx
         rec[4], rec[5] = len(pool_a._active_ids), len(pool_a._dormant_ids)
         rec[8:8 + len(rows)] = rows
@@ -191,8 +192,7 @@ def test_mirror_keeps_the_reference_order_of_dormant_ids():
         d = sorted(pool_a._dormant_ids.items())
         rec[base + cap:base + cap + len(d)] = [k for k, _ in d]
         rec[base + 2 * cap:base + 2 * cap + len(d)] = [v for _, v in d]
-        pool_b._memory_ids = [int(t) for t in tracks]
-        pool_b._mirror(rec, M, n_det)
+        pool_b._mirror(rec, M)
         assert list(pool_b._dormant_ids.items()) == list(pool_a._dormant_ids.items()), "frame %d" % f
         assert list(pool_b.get_dormant_ids()) == list(pool_a.get_dormant_ids())
         assert pool_b._active_ids == pool_a._active_ids and pool_b._max_id == pool_a._max_id
