@@ -632,10 +632,13 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // One batch = ROWS pooled rows of one plane (or of a plane pair side by side).  `PAIR`: lanes 32..63 pool the
     // wave's second plane and the two waves of the pair split the pooled rows; `CHUNKED`: windows wider than 64
     // columns (rare: small batches keep its loop-carried accumulators out of the register peak).
-    auto pool = [&](auto pair_tag, auto chunk_tag, auto rows_tag) {
+    auto pool = [&](auto pair_tag, auto chunk_tag, auto x2_tag, auto rows_tag) {
         constexpr bool PAIR = decltype(pair_tag)::value;
         constexpr bool CHUNKED = decltype(chunk_tag)::value;
+        constexpr bool X2 = decltype(x2_tag)::value;           // a lane loads TWO adjacent window columns (33..64-column windows)
         constexpr int ROWS = decltype(rows_tag)::value;
+        constexpr int NV = X2 ? 2 : 1;
+        static_assert(!X2 || (PAIR && !CHUNKED), "two columns per lane is a form of the plane-pair mode");
         const int half = PAIR ? (lane >> 5) : 0;
         const int col = PAIR ? (lane & 31) : lane;
         const int pw = col < RX ? col : 0;
@@ -683,38 +686,52 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
 #pragma unroll 1
             for (int ch = 0; ch < nchunk; ++ch) {
                 const int cbase = ch << 6;                                   // first window column of the chunk
-                const int wcol = CHUNKED ? min(cbase + col, ww - 1) : min(col, ww - 1);
+                // first window column this lane loads.  X2: columns (wcol, wcol + 1); the last pair of an odd-width
+                // window is (ww-2, ww-1) — lanes past the window repeat it (same values to the same staging slots)
+                const int wcol = CHUNKED ? min(cbase + col, ww - 1) : (X2 ? min(2 * col, ww - 2) : min(col, ww - 1));
                 const unsigned voff = (unsigned)(xmin + wcol) * 4u + lane_plane;
-                float v[ROWS][G][2];
+                float v[ROWS][G][2][NV];
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
 #pragma unroll
                     for (int iy = 0; iy < G; ++iy) {
                         const int e = b * G + iy;
-                        v[b][iy][0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            rsrc, voff, __builtin_amdgcn_readlane((int)ol, e), 0));
-                        v[b][iy][1] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                            rsrc, voff, __builtin_amdgcn_readlane((int)oh, e), 0));
+                        if constexpr (X2) {
+                            typedef int v2i_t __attribute__((ext_vector_type(2)));
+                            const v2i_t l2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, __builtin_amdgcn_readlane((int)ol, e), 0);
+                            const v2i_t h2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, __builtin_amdgcn_readlane((int)oh, e), 0);
+                            v[b][iy][0][0] = __int_as_float(l2.x);
+                            v[b][iy][0][NV - 1] = __int_as_float(l2.y);
+                            v[b][iy][1][0] = __int_as_float(h2.x);
+                            v[b][iy][1][NV - 1] = __int_as_float(h2.y);
+                        } else {
+                            v[b][iy][0][0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                rsrc, voff, __builtin_amdgcn_readlane((int)ol, e), 0));
+                            v[b][iy][1][0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                rsrc, voff, __builtin_amdgcn_readlane((int)oh, e), 0));
+                        }
                     }
                 // fences: hipcc otherwise sinks the loads to their first use (4 loads, wait, use, next 4 loads ...)
                 __builtin_amdgcn_sched_barrier(0);
-                float cs[ROWS];
+                float cs[ROWS][NV];
 #pragma unroll
-                for (int b = 0; b < ROWS; ++b) {
-                    float c_ = 0.0f;
+                for (int b = 0; b < ROWS; ++b)
 #pragma unroll
-                    for (int iy = 0; iy < G; ++iy) {
-                        const int e = b * G + iy;
-                        c_ = fmaf(rl_f(wl, e), v[b][iy][0], c_);
-                        c_ = fmaf(rl_f(wh, e), v[b][iy][1], c_);
+                    for (int k = 0; k < NV; ++k) {
+                        float c_ = 0.0f;
+#pragma unroll
+                        for (int iy = 0; iy < G; ++iy) {
+                            const int e = b * G + iy;
+                            c_ = fmaf(rl_f(wl, e), v[b][iy][0][k], c_);
+                            c_ = fmaf(rl_f(wh, e), v[b][iy][1][k], c_);
+                        }
+                        cs[b][k] = c_;
                     }
-                    cs[b] = c_;
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 // Horizontal taps.  A lane (= pooled column) needs the column sums of up to four window columns (other
                 // lanes' values).  ds_bpermute_b32 cost 10.6 LDS cycles per wave instruction here (SQ_LDS_IDX_ACTIVE,
                 // profiles/r02aa_pmc_counters.md: two thirds of the LDS pipe's busy time) — so the sums of a group of
-                // rows are staged in LDS instead (one ds_write_b32 per row, 2 array cycles) and every tap is a plain
+                // rows are staged in LDS instead (one ds_write per row, 2 array cycles) and every tap is a plain
                 // ds_read_b32 (2 cycles): 10 instead of 42 LDS cycles per pooled row.  The staging rows are this
                 // wave's own not-yet-written rows of the plane image (the batch's results are stored after its last
                 // gather; LDS operations of one wave execute in order, so neither a wait nor a barrier is needed).
@@ -722,13 +739,16 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                 // where the correlation phase is scheduled for.  Same values, same FMA order: bit-identical.
                 constexpr int GR = (ROWS + 1) / 2;
                 if constexpr (!CHUNKED) {
-                    constexpr int SW = PAIR ? 32 : 64;                               // staged floats per row (and plane)
-                    static_assert(GR * SW <= ROWS * XS, "staging fits the batch's own image rows");
+                    constexpr int SW = (X2 || !PAIR) ? 64 : 32;                      // staged floats per row (and plane)
+                    static_assert(GR * SW <= (RH - (RH / ROWS) * ROWS == 0 ? ROWS : RH - (RH / ROWS) * ROWS) * XS,
+                                  "staging fits the image rows of the wave's LAST batch");
                     float* stage = xdst + r0 * XS;
 #pragma unroll
                     for (int g0 = 0; g0 < ROWS; g0 += GR) {
 #pragma unroll
-                        for (int b = g0; b < g0 + GR && b < ROWS; ++b) stage[(b - g0) * SW + col] = cs[b];
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) stage[(b - g0) * SW + wcol + k] = cs[b][k];
                         float p[GR][G][2];
 #pragma unroll
                         for (int b = g0; b < g0 + GR && b < ROWS; ++b)
@@ -749,37 +769,37 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
-                // windows wider than a wave (rare): cross-lane gathers per 64-column chunk, two groups of rows
-                int al[G], ah[G];
-                bool inl[G], inh[G];
+                    // windows wider than 64 columns (rare): cross-lane gathers per 64-column chunk, two groups of rows
+                    int al[G], ah[G];
+                    bool inl[G], inh[G];
 #pragma unroll
-                for (int ix = 0; ix < G; ++ix) {
-                    const int tl = sxl[ix] - cbase, th = sxh[ix] - cbase;
-                    inl[ix] = (unsigned)tl < 64u;
-                    inh[ix] = (unsigned)th < 64u;
-                    al[ix] = (tl & 63) << 2;                                  // ds_bpermute takes byte addresses
-                    ah[ix] = (th & 63) << 2;
-                }
+                    for (int ix = 0; ix < G; ++ix) {
+                        const int tl = sxl[ix] - cbase, th = sxh[ix] - cbase;
+                        inl[ix] = (unsigned)tl < 64u;
+                        inh[ix] = (unsigned)th < 64u;
+                        al[ix] = (tl & 63) << 2;                                  // ds_bpermute takes byte addresses
+                        ah[ix] = (th & 63) << 2;
+                    }
 #pragma unroll
-                for (int g0 = 0; g0 < ROWS; g0 += GR) {
-                    float p[GR][G][2];
+                    for (int g0 = 0; g0 < ROWS; g0 += GR) {
+                        float p[GR][G][2];
 #pragma unroll
-                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b)
 #pragma unroll
-                        for (int ix = 0; ix < G; ++ix) {
-                            p[b - g0][ix][0] = __int_as_float(__builtin_amdgcn_ds_bpermute(al[ix], __float_as_int(cs[b])));
-                            p[b - g0][ix][1] = __int_as_float(__builtin_amdgcn_ds_bpermute(ah[ix], __float_as_int(cs[b])));
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
+                            for (int ix = 0; ix < G; ++ix) {
+                                p[b - g0][ix][0] = __int_as_float(__builtin_amdgcn_ds_bpermute(al[ix], __float_as_int(cs[b][0])));
+                                p[b - g0][ix][1] = __int_as_float(__builtin_amdgcn_ds_bpermute(ah[ix], __float_as_int(cs[b][0])));
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+                        for (int b = g0; b < g0 + GR && b < ROWS; ++b)
 #pragma unroll
-                        for (int ix = 0; ix < G; ++ix) {
-                            // a tap outside the chunk adds nothing (not even 0 * garbage)
-                            acc[b] = inl[ix] ? fmaf(hxw[ix], p[b - g0][ix][0], acc[b]) : acc[b];
-                            acc[b] = inh[ix] ? fmaf(lxw[ix], p[b - g0][ix][1], acc[b]) : acc[b];
-                        }
-                }
+                            for (int ix = 0; ix < G; ++ix) {
+                                // a tap outside the chunk adds nothing (not even 0 * garbage)
+                                acc[b] = inl[ix] ? fmaf(hxw[ix], p[b - g0][ix][0], acc[b]) : acc[b];
+                                acc[b] = inh[ix] ? fmaf(lxw[ix], p[b - g0][ix][1], acc[b]) : acc[b];
+                            }
+                    }
                 }
             }
 #pragma unroll
@@ -789,12 +809,22 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
             }
         }
     };
+    // <= 32 columns: a wave pools two planes side by side (lane = plane half x column), the two waves of a plane
+    // pair split the pooled rows: ONE batch of 60 row loads per wave.  33..64 columns: the same plane-pair form with
+    // TWO adjacent columns per lane (8-byte loads), two batches of 8 rows: a wide window now costs the load
+    // instructions of a narrow one (it was one plane per wave in two batches of 15 rows — twice the load, FMA and
+    // tap instructions per plane, and those workgroups set the kernel's makespan: 25 k vs 12 k cycles of pooling).
+    // Wider than 64 (degenerate aspect ratios): one plane per wave in 64-column chunks.
     if (ww <= 32) {
-        pool(std::true_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+        pool(std::true_type{}, std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+#ifdef SMOT_DEBUG
+    } else if (ww <= 64 && S.abl == 3) {      // A/B (measurement library, SMOT_FUSED_ABL=3): one plane per wave, two batches
+        pool(std::false_type{}, std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+#endif
     } else if (ww <= 64) {
-        pool(std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+        pool(std::true_type{}, std::false_type{}, std::true_type{}, std::integral_constant<int, (RH + 1) / 2>{});
     } else {
-        pool(std::false_type{}, std::true_type{}, std::integral_constant<int, (RH + 2) / 3>{});
+        pool(std::false_type{}, std::true_type{}, std::false_type{}, std::integral_constant<int, (RH + 2) / 3>{});
     }
     FX_TRACE(3)
     __syncthreads();                                      // every plane of the workgroup pooled (pairs share rows)
