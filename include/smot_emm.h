@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 4
+#define SMOT_ABI_VERSION 5
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -311,6 +311,34 @@ int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heig
                                       const float* boxes, int capacity, const int* n_valid, int rz,
                                       int sampling_ratio, float pad_pixels, float search_expansion,
                                       float min_search_wh, float* templates, float* sr, smot_stream_t stream);
+
+/*
+ * Box-head post-processing of the propagated tracks + the score average of _refine_tracks, one launch, no host sync.
+ *
+ * Replaces, when every proposal is a track (ids >= 0 and labels given — what CombinedROIHeads._refine_tracks passes to
+ * the box head, siammot/modelling/roi_heads.py:60-84): PostProcessor.forward / filter_results
+ * (siammot/modelling/box_head/inference.py:46-185: soft-max, BoxCoder.decode [UPSTREAM modeling/box_coder.py], track
+ * rows keep their label's probability + 1, clip_to_image(remove_empty=False), per-class grouping) and
+ * roi_heads.py:66-82 (score = (box-head score + matching score + 1) / 2, or the box-head score alone for TRACKTOR).
+ *
+ *   head_out   device [N, ld]: columns [0, K) = FPNPredictor.cls_score logits, [K, K + 4*KR) = bbox_pred deltas
+ *              (KR = K, or 2 with CLS_AGNOSTIC_BBOX_REG: the last four columns are used, inference.py:67-68)
+ *   boxes      device [N,4] xyxy proposals (the boxes EMM.forward propagated); labels / ids device [N] int64;
+ *   track_conf device [N] matching scores in [0, 1] (the + 1 band is applied inside)
+ *   wx..wh     BBOX_REG_WEIGHTS; xform_clip = log(1000/16); clip_w / clip_h = image size, 0 = INPUT.AMODAL
+ *   out_*      device [N,4] / [N] / [N] int64 / [N] int64: exactly N rows, grouped by label in ascending order, input
+ *              order inside a label (the order the reference's per-class loop produces); like the reference the
+ *              matching scores are taken in INPUT order and the box-head scores in OUTPUT order (roi_heads.py:66,70).
+ * Preconditions (checked by the host wrapper, not here): SCORE_THRESH < 1 (a track row scores p + 1 and is never
+ * dropped), labels in [1, K).  N <= smot_box_refine_post_max_rows().
+ */
+int smot_box_refine_post_max_rows(void);
+int smot_box_refine_post_fwd(const float* head_out, int ld, int num_classes, int reg_classes,
+                             const float* boxes, const int64_t* labels, const int64_t* ids, const float* track_conf,
+                             int N, float wx, float wy, float ww, float wh, float xform_clip,
+                             float clip_w, float clip_h, int tracktor,
+                             float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
+                             smot_stream_t stream);
 
 /*
  * Track solver: one launch for a frame's TrackSolver.forward + pool transitions + active-row filter.

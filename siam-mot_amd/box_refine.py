@@ -19,6 +19,7 @@ import math
 import torch
 from torch import nn
 
+from . import ops
 from .poolers import Pooler
 from .structures import BoxList, boxlist_nms, cat_boxlist
 
@@ -172,6 +173,44 @@ class TrackBoxHead(nn.Module):
         x = self.feature_extractor(features, proposals)
         return x, self.post_processor(self.predictor(x), proposals), {}
 
+    # ---- the propagated tracks on raw device tensors: no BoxList, no host synchronisation -----------------------------
+    def _track_weights(self):
+        """``cls_score`` and ``bbox_pred`` as ONE [K + 4*KR, dim] GEMM operand (+ bias), rebuilt when either parameter
+        changes (load_state_dict / .to() bump the version counters or replace the storage)."""
+        cs, bp = self.predictor.cls_score, self.predictor.bbox_pred
+        stamp = tuple((t.data_ptr(), t._version) for t in (cs.weight, cs.bias, bp.weight, bp.bias))
+        hit = self.__dict__.get("_track_w")
+        if hit is None or hit[0] != stamp:
+            with torch.no_grad():
+                hit = (stamp, torch.cat((cs.weight, bp.weight), 0).t().contiguous(), torch.cat((cs.bias, bp.bias), 0))
+            self.__dict__["_track_w"] = hit
+        return hit[1], hit[2]
+
+    def raw_ok(self, n):
+        """``refine_raw`` applies: HIP pooler, a threshold no track row can fall under, few enough rows."""
+        pp = self.post_processor
+        return (isinstance(self.feature_extractor.pooler, Pooler) and pp.score_thresh < 1.0
+                and 0 < n <= ops.box_refine_post_max_rows() and self.predictor.cls_score.weight.is_cuda)
+
+    @torch.no_grad()
+    def refine_raw(self, features, boxes, conf, ids, labels, image_wh, tracktor=False):
+        """The box head on N propagated tracks (every row a track with a label in [1, K)) followed by the score rule of
+        ``_refine_tracks`` (roi_heads.py:60-84): HIP pooler -> three library GEMMs -> ONE post-processing launch
+        (csrc/box_refine.hip).  Returns ``(boxes [N,4], scores [N] in the (1, 2] band, ids [N], labels [N])`` in the
+        box head's output order.  Same numbers as ``forward`` + ``RefineTracks`` (tests/test_box_refine.py)."""
+        fe, pp = self.feature_extractor, self.post_processor
+        pooler = fe.pooler
+        x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
+        h = torch.addmm(fe.fc6.bias, x.view(x.shape[0], -1), fe.fc6.weight.t()).relu_()
+        h = torch.addmm(fe.fc7.bias, h, fe.fc7.weight.t()).relu_()
+        w, b = self._track_weights()
+        out = torch.addmm(b, h, w)
+        K = self.predictor.cls_score.out_features
+        KR = self.predictor.bbox_pred.out_features // 4
+        bc = pp.box_coder
+        return ops.box_refine_post(out, K, KR, boxes, labels, ids, conf, bc.weights, bc.bbox_xform_clip,
+                                   None if pp.amodal_inference else image_wh, tracktor)
+
 
 class RefineTracks(object):
     """roi_heads.py:60-84 as a callable: ``refine(features, [tracks]) -> [tracks]``.
@@ -184,6 +223,14 @@ class RefineTracks(object):
     def __init__(self, box_head, tracktor=False):
         self.box = box_head
         self.tracktor = bool(tracktor)
+
+    def raw_ok(self, n):
+        """The device-only form applies (the tracking loop's one-launch path keeps its single synchronisation)."""
+        ok = getattr(self.box, "raw_ok", None)
+        return ok is not None and ok(n)
+
+    def refine_raw(self, features, boxes, conf, ids, labels, image_wh):
+        return self.box.refine_raw(features, boxes, conf, ids, labels, image_wh, self.tracktor)
 
     def __call__(self, features, tracks):
         if len(tracks[0]) == 0:

@@ -1,0 +1,149 @@
+// Box-head post-processing of the propagated tracks — the device half of CombinedROIHeads._refine_tracks.
+//
+// Replaces, for proposals that are ALL tracks (ids >= 0, labels given — what _refine_tracks passes,
+// reference siammot/modelling/roi_heads.py:60-84): PostProcessor.forward + filter_results
+// (siammot/modelling/box_head/inference.py:46-185: soft-max, BoxCoder.decode [UPSTREAM box_coder.py], "a track row
+// keeps only its own label's probability + 1", clip_to_image, per-class threshold, grouping by label) and the score
+// average of _refine_tracks (roi_heads.py:66-76), in ONE launch and without a host synchronisation.  The reference
+// (and siammot_amd.box_refine.PostProcessor, the general path) runs ~25 tensor ops with a .nonzero() per class here.
+//
+// Why no row can be dropped on this path: a track row's score is p_label + 1 > 1 > score_thresh (the host wrapper
+// refuses score_thresh >= 1), rows with ids >= 0 bypass the NMS (inference.py:165-174), clip_to_image is called with
+// remove_empty=False.  The output therefore has exactly N rows: the rows grouped by label in ascending order, input
+// order inside a label (inference.py:152-185) — rank = #(label_j < label_i) + #(j < i, label_j == label_i).
+// The reference's quirk is kept: the box head's scores arrive in OUTPUT order, the matching scores are taken in
+// INPUT order (roi_heads.py:66,70,75), so out_scores[p] = (det[p] + (track_conf[p] + 1)) / 2.
+//
+// One workgroup (N <= 512 rows, one thread per row); arithmetic in the reference's op order, fp32, separately rounded.
+#include "smot_common.h"
+
+namespace smot {
+
+constexpr int BR_MAXN = 512;
+constexpr int BR_MAXK = 16;       // classes incl. background held in registers per row
+
+struct BoxRefineArgs {
+    const float* logits;     // [N, ldo] : columns [0, K) class logits, columns [K, K + 4*KR) box deltas
+    int ldo, K, KR;          // KR = K (per-class regression) or 2 (class-agnostic: the LAST four columns are used)
+    const float* boxes;      // [N,4] proposals (the propagated boxes)
+    const long long* labels; // [N]
+    const long long* ids;    // [N]
+    const float* track_conf; // [N] matching scores in [0,1] (the +1 band is applied here)
+    float wx, wy, ww, wh, xform_clip;
+    float clip_w, clip_h;    // image size, or 0: amodal (no clipping)
+    int tracktor;
+    float* out_boxes;        // [N,4]
+    float* out_scores;       // [N]
+    long long* out_ids;      // [N]
+    long long* out_labels;   // [N]
+};
+
+__global__ void __launch_bounds__(BR_MAXN) box_refine_post_kernel(BoxRefineArgs A, int N) {
+    __shared__ int slab[BR_MAXN];
+    __shared__ float sdet[BR_MAXN];
+    const int i = threadIdx.x;
+    int lab = 0;
+    float det = 0.0f;
+    float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
+    long long id = -1;
+    if (i < N) {
+        lab = (int)A.labels[i];
+        id = A.ids[i];
+        const float* row = A.logits + (size_t)i * A.ldo;
+        // F.softmax(class_logits, -1): max, exp of the difference, sum in class order, divide
+        float m = row[0];
+        for (int k = 1; k < A.K; ++k) m = fmaxf(m, row[k]);
+        float s = 0.0f, el = 0.0f;
+        for (int k = 0; k < A.K; ++k) {
+            const float e = expf(sub_rn(row[k], m));
+            s = add_rn(s, e);
+            if (k == lab) el = e;
+        }
+        det = add_rn(div_rn(el, s), 1.0f);                                   // inference.py:102: prob + 1
+        // BoxCoder.decode on the label's four deltas (class-agnostic: the last four columns, inference.py:67-68)
+        const int r4 = (A.KR == A.K) ? 4 * lab : 4 * (A.KR - 1);
+        const float* d = row + A.K + r4;
+        const float x1 = A.boxes[i * 4 + 0], y1 = A.boxes[i * 4 + 1], x2 = A.boxes[i * 4 + 2], y2 = A.boxes[i * 4 + 3];
+        const float w = add_rn(sub_rn(x2, x1), 1.0f), h = add_rn(sub_rn(y2, y1), 1.0f);
+        const float cx = add_rn(x1, mul_rn(0.5f, w)), cy = add_rn(y1, mul_rn(0.5f, h));
+        const float dx = div_rn(d[0], A.wx), dy = div_rn(d[1], A.wy);
+        const float dw = fminf(div_rn(d[2], A.ww), A.xform_clip), dh = fminf(div_rn(d[3], A.wh), A.xform_clip);
+        const float pcx = add_rn(mul_rn(dx, w), cx), pcy = add_rn(mul_rn(dy, h), cy);
+        const float pw = mul_rn(expf(dw), w), ph = mul_rn(expf(dh), h);
+        bx1 = sub_rn(pcx, mul_rn(0.5f, pw));
+        by1 = sub_rn(pcy, mul_rn(0.5f, ph));
+        bx2 = sub_rn(add_rn(pcx, mul_rn(0.5f, pw)), 1.0f);
+        by2 = sub_rn(add_rn(pcy, mul_rn(0.5f, ph)), 1.0f);
+        if (A.clip_w > 0.0f) {                                               // clip_to_image(remove_empty=False)
+            bx1 = clamp_nan(bx1, 0.0f, A.clip_w - 1.0f);
+            by1 = clamp_nan(by1, 0.0f, A.clip_h - 1.0f);
+            bx2 = clamp_nan(bx2, 0.0f, A.clip_w - 1.0f);
+            by2 = clamp_nan(by2, 0.0f, A.clip_h - 1.0f);
+        }
+        slab[i] = lab;
+    }
+    __syncthreads();
+    int pos = 0;
+    if (i < N) {
+        for (int j = 0; j < N; ++j) {
+            const int lj = slab[j];
+            pos += (lj < lab || (lj == lab && j < i)) ? 1 : 0;
+        }
+        sdet[pos] = det;
+        A.out_boxes[pos * 4 + 0] = bx1;
+        A.out_boxes[pos * 4 + 1] = by1;
+        A.out_boxes[pos * 4 + 2] = bx2;
+        A.out_boxes[pos * 4 + 3] = by2;
+        A.out_ids[pos] = id;
+        A.out_labels[pos] = (long long)lab;
+    }
+    __syncthreads();
+    if (i < N) {
+        const float d = sdet[i];                                             // the box head's score of OUTPUT row i
+        // roi_heads.py:66,75: (det_scores + (track_scores + 1)) / 2 — the matching score of INPUT row i
+        A.out_scores[i] = A.tracktor ? d : div_rn(add_rn(d, add_rn(A.track_conf[i], 1.0f)), 2.0f);
+    }
+}
+
+}  // namespace smot
+
+extern "C" int smot_box_refine_post_max_rows(void) { return smot::BR_MAXN; }
+
+extern "C" int smot_box_refine_post_fwd(const float* head_out, int ld, int num_classes, int reg_classes,
+                                        const float* boxes, const int64_t* labels, const int64_t* ids,
+                                        const float* track_conf, int N, float wx, float wy, float ww, float wh,
+                                        float xform_clip, float clip_w, float clip_h, int tracktor, float* out_boxes,
+                                        float* out_scores, int64_t* out_ids, int64_t* out_labels, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && N <= BR_MAXN, "box_refine_post: N=%d not in [0,%d]", N, BR_MAXN);
+    SMOT_REQUIRE(num_classes >= 2 && (reg_classes == num_classes || reg_classes == 2) &&
+                     ld >= num_classes + 4 * reg_classes,
+                 "box_refine_post: bad head shape K=%d KR=%d ld=%d", num_classes, reg_classes, ld);
+    SMOT_REQUIRE(wx > 0.f && wy > 0.f && ww > 0.f && wh > 0.f, "box_refine_post: regression weights must be positive");
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(head_out && boxes && labels && ids && track_conf && out_boxes && out_scores && out_ids && out_labels,
+                 "box_refine_post: null pointer");
+    BoxRefineArgs A;
+    A.logits = head_out;
+    A.ldo = ld;
+    A.K = num_classes;
+    A.KR = reg_classes;
+    A.boxes = boxes;
+    A.labels = (const long long*)labels;
+    A.ids = (const long long*)ids;
+    A.track_conf = track_conf;
+    A.wx = wx;
+    A.wy = wy;
+    A.ww = ww;
+    A.wh = wh;
+    A.xform_clip = xform_clip;
+    A.clip_w = clip_w;
+    A.clip_h = clip_h;
+    A.tracktor = tracktor;
+    A.out_boxes = out_boxes;
+    A.out_scores = out_scores;
+    A.out_ids = (long long*)out_ids;
+    A.out_labels = (long long*)out_labels;
+    hipLaunchKernelGGL(box_refine_post_kernel, dim3(1), dim3(BR_MAXN), 0, (hipStream_t)stream, A, N);
+    return check_launch("box_refine_post");
+}

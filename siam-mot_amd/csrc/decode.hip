@@ -57,11 +57,6 @@ __device__ __forceinline__ void cubic_src(int d, float inv_up, int* base, float*
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
-// torch.clamp semantics: NaN stays NaN
-__device__ __forceinline__ float clamp_nan(float v, float lo, float hi) {
-    return (v != v) ? v : fminf(fmaxf(v, lo), hi);
-}
-
 __device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
     return a * w[0] + b * w[1] + c * w[2] + d * w[3];
 }

@@ -61,4 +61,9 @@ __device__ __forceinline__ float max_nan(float a, float b) {
     return (a != a) ? a : ((b != b) ? b : fmaxf(a, b));
 }
 
+// torch.clamp semantics: NaN stays NaN
+__device__ __forceinline__ float clamp_nan(float v, float lo, float hi) {
+    return (v != v) ? v : fminf(fmaxf(v, lo), hi);
+}
+
 }  // namespace smot

@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -65,6 +65,9 @@ _SIGNATURES = {
                                                   _vp, _vp, _vp]),
     "smot_emm_extract_cache_masked_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _f, _f,
                                                          _vp, _vp, _vp]),
+    "smot_box_refine_post_max_rows": (ctypes.c_int, []),
+    "smot_box_refine_post_fwd": (ctypes.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _i,
+                                                _vp, _vp, _vp, _vp, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -885,6 +888,43 @@ def wait_host_record(rec, event, spins=20000):
     event.synchronize()
     if flag[3] == 0:
         raise RuntimeError("siammot_amd.track_solve: the solver kernel finished without completing its record")
+
+
+def box_refine_post(head_out, num_classes, reg_classes, boxes, labels, ids, track_conf, weights, xform_clip, clip_wh,
+                    tracktor=False):
+    """``smot_box_refine_post_fwd``: the box head's post-processing of N propagated tracks + the score average of
+    ``_refine_tracks`` in one launch (no synchronisation).  ``head_out`` ``[N, K + 4*KR]`` = class logits | box deltas
+    (one GEMM over the concatenated ``cls_score`` / ``bbox_pred`` weights).  Returns ``(boxes [N,4], scores [N], ids [N],
+    labels [N])`` in the box head's output order."""
+    lib = _lib or load_library()
+    head_out = _dev_f32(head_out, "head_out")
+    boxes = _dev_f32(boxes, "boxes")
+    track_conf = _dev_f32(track_conf, "track_conf")
+    N = boxes.shape[0]
+    dev = boxes.device
+    for name, t in (("labels", labels), ("ids", ids)):
+        if not (t.is_cuda and t.dtype is torch.int64 and t.is_contiguous() and t.device == dev and t.shape[0] == N):
+            raise RuntimeError("siammot_amd.box_refine_post: %s must be a contiguous int64 [N] tensor on the boxes' device" % name)
+    if head_out.dim() != 2 or head_out.shape[0] != N or head_out.shape[1] < num_classes + 4 * reg_classes:
+        raise RuntimeError("siammot_amd.box_refine_post: head_out %s does not hold %d logits + %d deltas for %d rows"
+                           % (tuple(head_out.shape), num_classes, 4 * reg_classes, N))
+    out_boxes = torch.empty((N, 4), dtype=_F32, device=dev)
+    out_scores = torch.empty((N,), dtype=_F32, device=dev)
+    out_ids = torch.empty((N,), dtype=torch.int64, device=dev)
+    out_labels = torch.empty((N,), dtype=torch.int64, device=dev)
+    cw, ch = (0.0, 0.0) if clip_wh is None else (float(clip_wh[0]), float(clip_wh[1]))
+    with _Launch(head_out, boxes, track_conf, labels, ids) as ln:
+        rc = lib.smot_box_refine_post_fwd(_ptr(head_out), head_out.shape[1], int(num_classes), int(reg_classes), _ptr(boxes),
+                                          _ptr(labels), _ptr(ids), _ptr(track_conf), N, float(weights[0]),
+                                          float(weights[1]), float(weights[2]), float(weights[3]), float(xform_clip), cw, ch,
+                                          int(bool(tracktor)), _ptr(out_boxes), _ptr(out_scores), _ptr(out_ids),
+                                          _ptr(out_labels), ln.stream)
+    _check(rc, "box_refine_post")
+    return out_boxes, out_scores, out_ids, out_labels
+
+
+def box_refine_post_max_rows():
+    return (_lib or load_library()).smot_box_refine_post_max_rows()
 
 
 def track_solve_max_boxes():

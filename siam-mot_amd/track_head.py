@@ -117,10 +117,15 @@ class TrackingLoop(torch.nn.Module):
         self.track.reset_track_pool()
 
     def _lean_ok(self, detections):
-        """The per-frame fast path applies: this repository's EMM head, no box-head refinement, the one-launch
-        solver, device tensors."""
-        if self.refine_tracks is not None or not hasattr(self.track.tracker, "track_raw"):
+        """The per-frame fast path applies: this repository's EMM head, no box-head refinement or one with a
+        device-only form (``refine_raw``), the one-launch solver, device tensors."""
+        if not hasattr(self.track.tracker, "track_raw"):
             return False
+        if self.refine_tracks is not None:
+            mem = self.track_memory
+            ok = getattr(self.refine_tracks, "raw_ok", None)
+            if ok is None or (mem is not None and len(mem[2][0]) > 0 and not ok(len(mem[2][0]))):
+                return False
         fast = getattr(self.solver, "_device_path", None)
         if fast is None or not detections.bbox.is_cuda or self.track.tracker.rz != 15:
             return False
@@ -139,6 +144,7 @@ class TrackingLoop(torch.nn.Module):
         emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
         mem = self.track_memory
         trk = None
+        bias = 1.0                                 # propagated boxes keep their matching score, moved to the (1, 2] band
         if mem is None:
             pool.reset()                                                           # track_head.py:39-40
         else:
@@ -147,11 +153,14 @@ class TrackingLoop(torch.nn.Module):
             if z.numel() > 0:
                 bb, conf = emm.track_raw(features, tb0.bbox, sr[0].bbox, z, tb0.size)
                 trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels"))
+                if self.refine_tracks is not None:                                 # roi_heads.py:43-44,60-84, on the device
+                    trk = self.refine_tracks.refine_raw(features, bb, conf, trk[2], trk[3], tb0.size)
+                    bias = 0.0                     # the refined scores are in the band already
         dev = detections.bbox.device
         state = pool.device_state(dev)
         ring = pool.host_record_ring(dev)
         fbuf, ibuf, rec_host, M = ops.track_solve(
-            solver._segment(detections), trk, 1.0,
+            solver._segment(detections), trk, bias,
             (float(solver.track_thresh), float(solver.start_thresh), float(solver.resume_track_thresh)),
             float(solver.NMS_THRESH), int(pool._max_dormant_frames), state, pool.DEVICE_CAPACITY, host_record=ring)
         ring.record_event()                 # behind the solver: its record lands in pinned host memory, no copy command

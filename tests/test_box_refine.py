@@ -126,6 +126,43 @@ def test_box_head_on_the_hip_pooler_and_nms_matches_reference_golden():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tracktor", [False, True])
+def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(tracktor):
+    """``RefineTracks.refine_raw`` (HIP pooler -> three GEMMs -> smot_box_refine_post_fwd: no BoxList, no host
+    synchronisation) on the seven propagated tracks of the golden case — three classes, labels {1, 2}: the rows come
+    back grouped by label and the matching scores are paired in input order, as the reference's
+    ``_refine_tracks`` (roi_heads.py:60-84) over its own ``ROIBoxHead`` produced them; TRACKTOR = the box head's score
+    alone, against the general path."""
+    c, inp, g = gi.REFINE_CASE, gi.refine_case_inputs(), np.load(GOLD)
+    dev = "cuda"
+    head = TrackBoxHead(_cfg(), c["channels"])
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in inp["params"].items()}, strict=True)
+    head = head.to(dev).eval()
+    feats = [torch.from_numpy(f).to(dev) for f in inp["features"]]
+    refine = RefineTracks(head, tracktor=tracktor)
+    assert refine.raw_ok(7)
+    args = [torch.from_numpy(inp[k].copy()).to(dev) for k in ("track_boxes", "track_scores", "track_ids", "track_labels")]
+    refine.refine_raw(feats, *args, c["image_wh"])           # first call: builds the concatenated head weights
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")                  # any host synchronisation inside raises
+    try:
+        bb, sc, ids, lab = refine.refine_raw(feats, *args, c["image_wh"])
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    with torch.no_grad():
+        r = refine(feats, [_proposals(inp["track_boxes"], inp["track_ids"], dev, inp["track_labels"],
+                                      inp["track_scores"])])[0]
+    assert ids.cpu().tolist() == r.get_field("ids").cpu().tolist() == g["refine_ids"].tolist()
+    assert lab.cpu().tolist() == r.get_field("labels").cpu().tolist() == g["refine_labels"].tolist()
+    np.testing.assert_allclose(bb.cpu().numpy(), r.bbox.cpu().numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(sc.cpu().numpy(), r.get_field("scores").cpu().numpy(), rtol=0, atol=2e-6)
+    if not tracktor:
+        np.testing.assert_allclose(bb.cpu().numpy(), g["refine_bbox"], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(sc.cpu().numpy(), g["refine_scores"], rtol=0, atol=2e-5)
+    assert float(sc.min()) > 1.0 and float(sc.max()) <= 2.0
+
+
+@pytest.mark.gpu
 def test_tracking_loop_with_refine_tracks_runs_the_reference_order():
     """TrackingLoop(refine_tracks=RefineTracks(box head)): the propagated boxes go through the box head as proposals
     (roi_heads.py:43-45), come back with scores in the (1, 2] band, and the tracks keep their ids over frames."""
