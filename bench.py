@@ -21,9 +21,15 @@ torchrun environment launches its own ranks (re-executes itself under ``torch.di
 rank 0 prints the one JSON line either way.
 
 The JSON line also carries:
-  roofline     — for the depthwise cross-correlation kernel (the graded kernel): algorithmic bytes
-                 4*N*C*(Rx^2+Rz^2+Ho^2) per launch / average launch duration measured with HIP events
-                 recorded on the launch stream around every xcorr launch of the timed region.
+  roofline     — the kernel that runs the cross-correlation in the pipeline (search-region ROIAlign fused with the
+                 depthwise xcorr): algorithmic bytes = window cells actually touched + templates + response
+                 (SURVEY.md §8(d)-B restricted to that kernel, computed from the boxes) / the average launch duration
+                 from the launch's own start/stop events (hipExtLaunchKernel, every 16th step of the timed region);
+                 `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of separate --pmc passes (profiles/xcorr_traffic.json);
+                 `xcorr_op` = the stand-alone operator (figure A of §8(d)) timed the same way.
+  roofline_tower / roofline_path — the towers against the fp32 matrix pipe (executed multiply-adds), the whole frame
+                 pair against HBM (compulsory bytes / ms_per_step).
+  tracking_loop — head + solver + memory per frame, with and without box-head refinement, track count asserted.
   cpu_baseline — the CPU oracle (oracle/emm_oracle.py, the reference's torch-CPU ops) timed on this
                  host's cores on the same workload (rank 0, N=1 only), bounded to ~10-20 s.
   parity       — the LAST result of the timed loop compared, outside the timed region, with the CPU oracle on the
@@ -212,36 +218,55 @@ def multi_stream_throughput(emm, feats, det, n_streams, dev, steps=600):
             "ms_per_step_per_stream": dt / steps * 1e3}
 
 
-def tracking_loop_throughput(n, dev, feats, steps=300):
-    """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> merge with this
-    frame's detections -> solver (score-banded NMS, id life cycle, ONE host sync) -> EMM.extract_cache + track
-    memory.  Detections are the n synthetic track boxes jittered by a pixel, so every track survives and the
-    track count stays n.  Informational (the solver is host-bound control logic, not part of the metric)."""
+def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
+    """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
+    the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
+    cycle, ONE host sync) -> EMM.extract_cache + track memory.  Fixed track count: the n boxes sit on a
+    grid on which neither the detections nor the propagated boxes overlap above the NMS threshold, TRACK_THRESH = 0 and
+    START_TRACK_THRESH = 2 after the first frame, so the unchanged solver never suspends or starts a track;
+    ``tracked_in_last_frame`` must equal n (``track_count_held``).  Informational (not part of the metric)."""
+    from siammot_amd.box_refine import build_refine_tracks
     from siammot_amd.config import get_default_cfg
     from siammot_amd.structures import BoxList
     from siammot_amd.track_head import build_tracking_loop
     image_wh = (NET_HW[1], NET_HW[0])
-    # one grid cell per track (the frame-pair benchmark's boxes share 14 positions: fine for independent head calls,
-    # but a tracker merges tracks that sit on each other); sizes cycle as there
+    # one grid cell per track; the size index is (col + 2 row) % 4, so that the 320-pixel-tall boxes of one column sit
+    # two rows apart (they overlapped their vertical neighbours above IoU 0.5 on the round-2 layout and the solver's
+    # NMS merged five of thirty tracks in the first frame)
     import math
     cols = max(1, int(math.ceil(math.sqrt(n * image_wh[0] / float(image_wh[1])))))
     rows = int(math.ceil(n / float(cols)))
     bl = []
     for i in range(n):
-        w, h = TRACK_SIZES[i % 4]
+        w, h = TRACK_SIZES[(i % cols + 2 * (i // cols)) % 4]
         cx = (i % cols + 0.5) * image_wh[0] / cols
         cy = (i // cols + 0.5) * image_wh[1] / rows
         x1 = min(max(cx - w / 2, 0), image_wh[0] - w - 1)
         y1 = min(max(cy - h / 2, 0), image_wh[1] - h - 1)
         bl.append([x1, y1, x1 + w, y1 + h])
     boxes = torch.tensor(bl, dtype=torch.float32, device=dev)
-    loop = build_tracking_loop(get_default_cfg(channels=CHANNELS), device=dev, refine_tracks=False)
+    cfg = get_default_cfg(channels=CHANNELS)
+    refine_fn = False
+    if refine:
+        refine_fn = build_refine_tracks(cfg, CHANNELS)           # DLA_34_FPN_EMM.yaml box head: 7x7 pooler, 1024-1024 MLP
+        head = refine_fn.box.to(dev).eval()
+        g = torch.Generator().manual_seed(2)
+        with torch.no_grad():                                    # random init; a regression that nudges (trained heads do)
+            for name, p_ in head.named_parameters():
+                if name.endswith("weight"):
+                    p_.copy_((torch.randn(p_.shape, generator=g) / math.sqrt(p_.shape[1])).to(dev))
+                else:
+                    p_.zero_()
+            head.predictor.bbox_pred.weight.mul_(0.02)
+            head.predictor.cls_score.weight.mul_(0.2)
+    loop = build_tracking_loop(cfg, device=dev, refine_tracks=refine_fn)
     init_predictor(loop.track.tracker.predictor, boxes.cpu())
     with torch.no_grad():
         # Random head weights make the response random and the tracks jump into each other within a few frames (NMS
         # then kills them: the count does not hold).  Scaling the three head convolutions down leaves a response
         # dominated by the cosine window, i.e. a tracker that holds every track near its box — what a trained head
-        # does on a static scene.  Kernel work is the same; only the data differs.
+        # does on a static scene.  Kernel work is the same; only the data differs.  (The regression bias fixes the
+        # size of every propagated box at the mean box size: after the first frame the templates are that size.)
         for name in ("cls", "center", "reg"):
             getattr(loop.track.tracker.predictor, name).weight.mul_(0.02)
     loop.track.tracker.to(dev)
@@ -262,18 +287,30 @@ def tracking_loop_throughput(n, dev, feats, steps=300):
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n
     # tracks live on, every frame's n detections compete with them in NMS
     loop.solver.start_thresh, loop.solver.track_thresh = 2.0, 0.0
+    lean = [0]
+    step_lean = loop._step_lean
+
+    def counted(*a, **k):
+        lean[0] += 1
+        return step_lean(*a, **k)
+    loop._step_lean = counted
     for k in range(1, 30):
         out = loop(feats[k & 1], dets(k))
     torch.cuda.synchronize()
+    lean[0] = 0
     t0 = time.perf_counter()
     for k in range(steps):
         out = loop(feats[k & 1], dets(k))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tracked = int((out.get_field("ids") >= 0).sum().item())
     return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
-            "tracked_in_last_frame": int((out.get_field("ids") >= 0).sum().item()),
-            "note": "head + one-launch solver (device-resident pool) + track memory; synthetic detections resident on "
-                    "the device; one host synchronisation per frame"}
+            "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
+            "refine_tracks": "TrackBoxHead (7x7 HIP pooler, 1024-1024 MLP, one-launch post-processing)" if refine else None,
+            "one_launch_path_frames": lean[0], "frames": steps,
+            "note": "head + %sone-launch solver (device-resident pool) + track memory; synthetic detections resident on "
+                    "the device; one host synchronisation per frame" % ("box-head refinement of the propagated boxes + "
+                                                                        if refine else "")}
 
 
 TIMER_NOTE = ("kernel start/stop events on the launch stream (hipExtLaunchKernel: the dispatch's own begin/end "
@@ -281,16 +318,43 @@ TIMER_NOTE = ("kernel start/stop events on the launch stream (hipExtLaunchKernel
 
 
 def tower_roofline(n, total_ms, launches):
+    """The towers against the fp32 matrix pipe.  ``frac`` divides the multiply-adds the kernel EXECUTES (Winograd
+    F(2x2,3x3): 16/36 of the direct convolution's) by the dense fp32 MFMA peak — a fraction of a pipe, <= 1;
+    ``effective_tflops`` is the direct-convolution figure the reference computes, for comparison with other
+    implementations (it can exceed the peak: the algorithm does less work)."""
     algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
     sec = total_ms * 1e-3 / launches
     return {
         "bound": "mfma", "kernel": "tower_wino_kernel<0,2> (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)",
-        "flops_per_launch": algo, "avg_launch_us": sec * 1e6,
-        "achieved": algo / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": algo / sec / 1e12 / 157.3,
-        "executed_mfma_flops_per_launch": executed, "executed_frac_of_peak": executed / sec / 1e12 / 157.3,
+        "executed_flops_per_launch": executed, "avg_launch_us": sec * 1e6,
+        "achieved": executed / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": executed / sec / 1e12 / 157.3,
+        "direct_conv_flops_per_launch": algo, "effective_tflops": algo / sec / 1e12,
         "launches_timed": launches,
     }
+
+
+PREDICTOR_PARAM_BYTES = 1213980          # SURVEY.md §8(d)-B: (2*128*128*9 + 7*128*9) conv + 2*2*128 GN + 7 biases, x4 B
+
+
+def path_algorithmic_bytes(boxes, image_wh, channels, rz=15, rx=30):
+    """Compulsory HBM bytes of one frame pair through the whole head (SURVEY.md §8(d) formula B): per track the search
+    window cells + the template read (EMM.forward) + the detection window cells + the template written
+    (EMM.extract_cache), zero padding virtual and every intermediate on chip, plus the predictor parameters once."""
+    import math
+    W, H = image_wh
+    sr_part = fused_algorithmic_bytes(boxes, image_wh, channels, rz, rx) - 4.0 * boxes.shape[0] * channels * (rx - rz + 1) ** 2
+    det_cells = 0
+    for x1, y1, x2, y2 in boxes.tolist():
+        s = math.sqrt((x2 - x1 + 1) * (y2 - y1 + 1))
+        lvl = int(min(max(math.floor(4 + math.log2(s / 224 + 1e-6)), 2), 5)) - 2
+        scale = 1.0 / (4 * 2 ** lvl)
+        mw, mh = W // (4 * 2 ** lvl), H // (4 * 2 ** lvl)
+        cx1, cx2 = max(math.floor(x1 * scale), 0), min(math.ceil(x2 * scale), mw - 1)
+        cy1, cy2 = max(math.floor(y1 * scale), 0), min(math.ceil(y2 * scale), mh - 1)
+        det_cells += max(cx2 - cx1 + 1, 0) * max(cy2 - cy1 + 1, 0)
+    params = PREDICTOR_PARAM_BYTES if channels == 128 else 4.0 * (2 * channels * channels * 9 + 7 * channels * 9 + 4 * channels + 7)
+    return sr_part + 4.0 * channels * det_cells + 4.0 * boxes.shape[0] * channels * rz * rz + params
 
 
 def box_iou(a, b):
@@ -391,7 +455,7 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: required by RCCL on this host driver
-    env.setdefault("OMP_NUM_THREADS", "4")
+    env.setdefault("OMP_NUM_THREADS", "1")       # a rank is one Python launch loop; OpenMP pools would only spin
     return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
@@ -452,6 +516,11 @@ def main():
     torch.cuda.set_device(dev_index)                          # before the process group: RCCL binds to this device
     dev = torch.device("cuda", dev_index)
     rank, world, local_rank = parallel.init_distributed(backend="gloo" if shared else None, device=dev)
+    pinned = None
+    if world > 1:
+        # one launch loop per rank on its own cores (NUMA-local slices), no OpenMP pools spinning beside it
+        torch.set_num_threads(1)
+        pinned = parallel.pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     ops.load_library()
 
     n = args.tracks
@@ -532,6 +601,19 @@ def main():
     if world == 1 and args.extra_streams > 1:
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
         loop_stats = tracking_loop_throughput(n, dev, feats)
+        loop_stats["with_refinement"] = tracking_loop_throughput(n, dev, feats, refine=True)
+    # host cost of a step: the time to ENQUEUE frame pairs (no synchronisation), measured outside the timed region on
+    # a burst short enough for the stream's queue; next to the GPU time per step it says how much host headroom a
+    # rank has (eight ranks share one host)
+    with torch.no_grad():
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for k in range(64):
+            state, _ = step(k, state)
+        host_enqueue_us = (time.perf_counter() - t_h) / 64 * 1e6
+        torch.cuda.synchronize()
+    rank_ms = parallel.gather_floats(elapsed / args.steps * 1e3, dev)
+    rank_host_us = parallel.gather_floats(host_enqueue_us, dev)
     elapsed = parallel.max_over_ranks(elapsed, dev)
     backend = torch.distributed.get_backend() if parallel.is_distributed() else "none"
     dist_world = torch.distributed.get_world_size() if parallel.is_distributed() else 1
@@ -548,6 +630,17 @@ def main():
         golden_ok = (CHANNELS, NET_HW) == (128, (704, 1280))
         parity = parity_report(emm, ops, feats[last_k % K], state_before_last, result,
                                feats[:2] if golden_ok else None, det, boxes_cpu, image_wh, n)
+        # what this run's handful of tracks cannot show: the arg-max statistics over many seeded frame pairs
+        # (tools/argmax_stats.py; not re-measured by this run)
+        parity["argmax_statistics"] = {
+            "source": "static: profiles/r02_argmax_stats.md, profiles/r02_argmax_stats_n100.md (tools/argmax_stats.py)",
+            "tracks_30": "30,000 / 30,000 arg-max cells identical to the fp32 oracle over 1,000 frame pairs, min IoU 0.999997",
+            "tracks_100": "24,997 / 25,000 identical over 250 frame pairs; the 3 others are ties below fp32 resolution "
+                          "(fp64 margins 3-9e-8, decided by the towers' summation order) and land one cell away: IoU "
+                          "0.990-0.995, i.e. OUTSIDE the 1e-3 IoU bar on 0.012 % of tracks",
+            "closed_loop": "tests/golden/sequence_{plain,refine}.npz (the reference's CombinedROIHeads with its own EMM, "
+                           "24 / 20 frames, 691 / 449 tracked rows): ids, pool state and memory order identical in every "
+                           "frame on the general, one-launch and refinement paths, min IoU 0.99999, no arg-max flip"}
     rx, rz = emm.rx, emm.rz
     ho = rx - rz + 1
     # the kernel that runs in the pipeline: search-region pooling fused with the cross-correlation
@@ -595,6 +688,11 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
+        "per_rank": {"ms_per_step_min": min(rank_ms), "ms_per_step_max": max(rank_ms),
+                     "host_enqueue_us_per_step_min": min(rank_host_us), "host_enqueue_us_per_step_max": max(rank_host_us),
+                     "cores_pinned_rank0": pinned, "omp_threads": torch.get_num_threads(),
+                     "note": "host_enqueue = Python + ctypes time to enqueue one frame pair (4 launches), no "
+                             "synchronisation; headroom = ms_per_step - host_enqueue"},
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -620,11 +718,16 @@ def main():
             "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },
-        # the kernel with the largest share of GPU time: the two conv3x3 towers.  Algorithmic FLOPs are those of
-        # the direct convolution the reference computes; the kernel runs it as Winograd F(2x2,3x3) on the fp32
-        # matrix cores, i.e. it EXECUTES 2.25x fewer multiply-adds (reported separately, with the matrix-pipe
-        # fraction they amount to).
+        # the kernel with the largest share of GPU time: the two conv3x3 towers, Winograd F(2x2,3x3) on the fp32
+        # matrix cores.  frac = EXECUTED multiply-adds / dense fp32 MFMA peak (<= 1); effective_tflops = the direct
+        # convolution's FLOPs / time (the figure to compare implementations by).
         "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
+        # the whole frame pair against HBM: compulsory bytes / ms_per_step.  The path is issue-,
+        # matrix-pipe- and latency-bound, so this fraction is small by construction.
+        "roofline_path": (lambda pb: {"bound": "hbm", "algorithmic_bytes_per_step": pb,
+                                      "achieved": pb / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": pb / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS})(
+            path_algorithmic_bytes(boxes_cpu, image_wh, CHANNELS, rz, rx)),
         "parity": parity,
         "cache_warm_loop": warm,
         "multi_stream": multi,

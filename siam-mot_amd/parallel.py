@@ -79,6 +79,33 @@ def barrier():
         dist.barrier()
 
 
+def gather_floats(value, device=None):
+    """Every rank's ``value`` on every rank (a list of world_size floats): per-rank step times for the scaling line."""
+    if not is_distributed():
+        return [float(value)]
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, torch.tensor([float(value)], dtype=torch.float64, device=dev))
+    return [float(t.item()) for t in out]
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Give each rank of a node its own contiguous slice of the cores this process may run on (Linux numbers the cores
+    of one socket / NUMA node contiguously, GPUs 0..3 / 4..7 of an MI355X node hang off sockets 0 / 1), so eight
+    Python launch loops do not migrate across sockets or share a core.  Returns the slice (or None when the platform
+    has no affinity call or the slice would be empty)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    per = len(cores) // max(local_world, 1)
+    if per < 1:
+        return None
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def shutdown():
     """Tear the process group down (each rank for itself, after its last collective): no complaint from the RCCL
     watchdog at interpreter exit when ranks finish at different times."""

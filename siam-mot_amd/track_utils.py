@@ -53,8 +53,9 @@ class TrackUtils(object):
 
 
 def build_track_utils(cfg):
-    """TrackUtils from cfg (reference build_track_utils, track_utils.py:258-269; the TrackPool half of
-    that builder belongs to the solver side, which is reused from the reference unchanged)."""
+    """TrackUtils from cfg (reference build_track_utils, track_utils.py:258-269).  The reference's builder also
+    returns a TrackPool; here the pool is built where the solver is (``siammot_amd.solver.TrackPool``, a
+    re-implementation with a device-resident state — the reference's own class works with this head too)."""
     th = cfg.MODEL.TRACK_HEAD
     return TrackUtils(search_expansion=th.SEARCH_REGION - 1.,
                       min_search_wh=th.MINIMUM_SREACH_REGION,

@@ -43,6 +43,13 @@ def _worker(rank, world, port, q):
     dist.all_gather(gathered, after)
     same = all(torch.equal(g, gathered[0]) for g in gathered)
     t = parallel.max_over_ranks(1.0 + rank)            # slowest rank defines the job time
+    per_rank = parallel.gather_floats(10.0 + rank)     # every rank's step time on every rank
+    assert per_rank == [10.0 + r_ for r_ in range(world)]
+    allowed = sorted(os.sched_getaffinity(0))
+    mine = parallel.pin_rank_to_cores(rank, world)     # disjoint core slices per rank
+    if len(allowed) >= world:
+        per = len(allowed) // world
+        assert mine == allowed[rank * per:(rank + 1) * per] and sorted(os.sched_getaffinity(0)) == mine
     parallel.barrier()
     q.put((rank, nbytes, same, bool(torch.equal(before, after)), t, parallel.shard_streams(8, rank, world)))
     dist.destroy_process_group()
@@ -78,6 +85,7 @@ def test_single_process_is_a_noop():
     assert parallel.max_over_ranks(3.5) == 3.5
     assert parallel.broadcast_module(torch.nn.Linear(2, 2)) == 0
     assert parallel.shard_streams(5, 0, 1) == [0, 1, 2, 3, 4]
+    assert parallel.gather_floats(1.25) == [1.25]
 
 
 def test_bench_self_launch_builds_a_torchrun_command(monkeypatch):
