@@ -251,24 +251,31 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
         refine_fn = build_refine_tracks(cfg, CHANNELS)           # DLA_34_FPN_EMM.yaml box head: 7x7 pooler, 1024-1024 MLP
         head = refine_fn.box.to(dev).eval()
         g = torch.Generator().manual_seed(2)
-        with torch.no_grad():                                    # random init; a regression that nudges (trained heads do)
+        with torch.no_grad():                                    # random init of the MLP and the classifier
             for name, p_ in head.named_parameters():
                 if name.endswith("weight"):
                     p_.copy_((torch.randn(p_.shape, generator=g) / math.sqrt(p_.shape[1])).to(dev))
                 else:
                     p_.zero_()
-            head.predictor.bbox_pred.weight.mul_(0.02)
+            head.predictor.bbox_pred.weight.zero_()             # zero deltas decode to the proposal itself: tracks hold
             head.predictor.cls_score.weight.mul_(0.2)
     loop = build_tracking_loop(cfg, device=dev, refine_tracks=refine_fn)
     init_predictor(loop.track.tracker.predictor, boxes.cpu())
     with torch.no_grad():
-        # Random head weights make the response random and the tracks jump into each other within a few frames (NMS
-        # then kills them: the count does not hold).  Scaling the three head convolutions down leaves a response
-        # dominated by the cosine window, i.e. a tracker that holds every track near its box — what a trained head
-        # does on a static scene.  Kernel work is the same; only the data differs.  (The regression bias fixes the
-        # size of every propagated box at the mean box size: after the first frame the templates are that size.)
+        # A tracker that HOLDS its tracks, as a trained head does on a static scene (random head weights move every box
+        # by a few pixels per frame — a random walk that merges neighbours within a few hundred frames, and the count
+        # does not hold): the three head convolutions are zeroed, so the penalised score is the cosine window and the
+        # arg-max is its centre cell, and the regression bias is made asymmetric by the half-cell offset of the
+        # reference's location grid (cell 128 of 256 sits (2w+1)/958 right of the search region's centre,
+        # track_core.py:184-225), so the decoded box lands exactly on the box it came from.  Kernel work is the same;
+        # only the data differs.  (Every propagated box has the size the regression bias encodes: after the first frame
+        # the templates are that size, not the four-size mix of the frame-pair workload.)
+        pr = loop.track.tracker.predictor
         for name in ("cls", "center", "reg"):
-            getattr(loop.track.tracker.predictor, name).weight.mul_(0.02)
+            getattr(pr, name).weight.zero_()
+        mw, mh = 2.0 * float(pr.reg.bias[0]), 2.0 * float(pr.reg.bias[1])
+        dx, dy = (2.0 * mw + 1.0) / 958.0, (2.0 * mh + 1.0) / 958.0
+        pr.reg.bias.copy_(torch.tensor([0.5 * mw + dx, 0.5 * mh + dy, 0.5 * mw - dx, 0.5 * mh - dy]))
     loop.track.tracker.to(dev)
 
     # the detector's output of two alternating frames, resident on the device before the loop (synthesising it is
