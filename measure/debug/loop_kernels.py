@@ -1,5 +1,5 @@
 """The tracking loop under rocprofv3: per-kernel durations of one frame (head + solver + masked template extraction).
-    cd /tmp && rocprofv3 --kernel-trace --stats -d <out> -o loop -- python tools/debug/loop_kernels.py"""
+    cd /tmp && rocprofv3 --kernel-trace --stats -d <out> -o loop -- python measure/debug/loop_kernels.py"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import bench

@@ -1,4 +1,4 @@
-# scratch: one GPU-box session for the kernel under work (edit freely; tools/gpu_round.sh is the full round)
+# scratch: one GPU-box session for the kernel under work (edit freely; measure/gpu_round.sh is the full round)
 set -x
 python - <<'PY'
 import sys, json, torch

@@ -1,5 +1,5 @@
 # quick GPU session: the parity tests that touch the pooling / correlation / head kernels + bench lines at 30 and 100 tracks
-# usage: gpurun --timeout 900 -- 'bash tools/gpu_quick.sh TAG'
+# usage: gpurun --timeout 900 -- 'bash measure/gpu_quick.sh TAG'
 TAG=${1:-q}
 mkdir -p gpurun_out
 timeout 600 python -m pytest tests/test_hip_parity.py tests/test_sequence.py -m gpu -q --no-header -rf --tb=short -x -k "${KEXPR:-fused or pool or benchmark or emm or closed or roi}" > gpurun_out/${TAG}_pytest.log 2>&1

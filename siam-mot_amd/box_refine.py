@@ -24,6 +24,15 @@ from .poolers import Pooler
 from .structures import BoxList, boxlist_nms, cat_boxlist
 
 
+_addmm_relu = getattr(torch, "_addmm_activation", None)      # bias + ReLU in the GEMM's epilogue (hipBLASLt) when offered
+
+
+def _linear_relu(x, layer):
+    if _addmm_relu is not None:
+        return _addmm_relu(layer.bias, x, layer.weight.t())
+    return torch.addmm(layer.bias, x, layer.weight.t()).relu_()
+
+
 class BoxCoder(object):
     """[UPSTREAM] maskrcnn_benchmark/modeling/box_coder.py ``decode``: deltas (dx, dy, dw, dh) / weights applied to
     boxes measured with the legacy +1 width, ``dw`` / ``dh`` clamped at log(1000/16)."""
@@ -201,8 +210,8 @@ class TrackBoxHead(nn.Module):
         fe, pp = self.feature_extractor, self.post_processor
         pooler = fe.pooler
         x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
-        h = torch.addmm(fe.fc6.bias, x.view(x.shape[0], -1), fe.fc6.weight.t()).relu_()
-        h = torch.addmm(fe.fc7.bias, h, fe.fc7.weight.t()).relu_()
+        h = _linear_relu(x.view(x.shape[0], -1), fe.fc6)
+        h = _linear_relu(h, fe.fc7)
         w, b = self._track_weights()
         out = torch.addmm(b, h, w)
         K = self.predictor.cls_score.out_features

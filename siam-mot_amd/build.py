@@ -5,7 +5,7 @@
 
 Two libraries come out of the same sources:
   csrc/libsmot_emm.so        the product: no environment variable is read, no kernel A/B switch, no ablation;
-  csrc/libsmot_emm_debug.so  the measurement build (-DSMOT_DEBUG, + xcorr_variants.hip): older kernel generations,
+  csrc/libsmot_emm_debug.so  the measurement build (-DSMOT_DEBUG, + measure/csrc/xcorr_variants.hip): older kernel generations,
                              A/B switches and timing ablations for tools/ and the A/B tests (csrc/knobs.h).
 
 The library is plain HIP behind a C ABI (include/smot_emm.h): no torch headers, so it is
@@ -20,6 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
 LIB_DEBUG = os.path.join(CSRC, "libsmot_emm_debug.so")
+MEASURE_CSRC = os.path.join(os.path.dirname(HERE), "measure", "csrc")      # measurement-only sources (not product)
 DEBUG_ONLY_SOURCES = ["xcorr_variants.hip"]
 SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "tower_conv.hip", "preprocess.hip",
            "emm_fused.hip", "track_solver.hip", "box_refine.hip"]
@@ -39,9 +40,13 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm under /opt/rocm)")
 
 
+def _src(name):
+    return os.path.join(MEASURE_CSRC if name in DEBUG_ONLY_SOURCES else CSRC, name)
+
+
 def _deps(sources):
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
-    return [os.path.join(CSRC, s) for s in sources] + hdrs + [
+    return [_src(s) for s in sources] + hdrs + [
         os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"), os.path.abspath(__file__)]
 
 
@@ -62,11 +67,11 @@ def _build_one(lib, sources, extra_flags, objdir, verbose):
     for s in sources:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)
-        src = os.path.join(CSRC, s)
+        src = _src(s)
         # per-object staleness: recompile only what changed (a header change recompiles everything)
         if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t) and lib_t:
             continue
-        jobs.append([hipcc] + FLAGS + extra_flags + ["-c", src, "-o", obj])
+        jobs.append([hipcc] + FLAGS + extra_flags + ["-I", CSRC, "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -245,9 +245,9 @@ extern "C" int smot_roi_align_levels_fwd(const float* const* feats, const int* h
         if (rc) return rc;
     }
 
-    // the two EMM pooler shapes (15x15 templates, 30x30 search regions, 2x2 samples) take the separable
+    // the EMM pooler shapes (15x15 templates, 30x30 search regions) and the box head's 7x7, 2x2 samples, take the separable
     // wave-per-two-planes kernel of sr_xcorr.hip; everything else the generic kernel below
-    if (out_h == out_w && (out_h == 15 || out_h == 30) && sampling_ratio == 2 && !knobs().roi_generic)
+    if (out_h == out_w && (out_h == 7 || out_h == 15 || out_h == 30) && sampling_ratio == 2 && !knobs().roi_generic)
         return launch_roi_pool_separable(P, C, rois, num_levels > 1 ? level_boxes : rois, R, out_h, out, levels_out,
                                          (hipStream_t)stream);
     const int ch_per_block = RA_CH;

@@ -326,7 +326,7 @@ __device__ __forceinline__ float rl_f(float v, int lane_const) {
 // Which (roi, channel group) a workgroup takes.  The grid is (rois, channel groups) and the hardware dispatches
 // workgroups in linear order (x fastest), L and L + 256 onto the same CU while the launch fits the chip; a roi whose
 // window is wider than 32 columns costs about twice a narrow one (two row blocks per plane), so the order in which
-// rois appear in the caller's tensor decided how evenly the CUs were loaded (tools/debug/pairing_probe.py: the same 30
+// rois appear in the caller's tensor decided how evenly the CUs were loaded (measure/debug/pairing_probe.py: the same 30
 // boxes, 18.9 us in the benchmark's size-cycling order, 17.6 us sorted by width; 49.2 vs 42.5 us at 100).  Every
 // workgroup therefore ranks the rois by a cost class itself — lane = roi, three ballots per 64 rois, all wave-uniform
 // — and takes its item from the cost-sorted list; results do not depend on the assignment (it is a bijection).
@@ -883,6 +883,9 @@ int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, co
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order()};
     if (out_size == 30) {
         launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
+    } else if (out_size == 7) {        // the box head's 7x7 pooler (box_head.py:46, roi_heads.py:60-84): same kernel
+        SMOT_LAUNCH((sr_xcorr_fused9_kernel<7, 15, 2, false>), grid, dim3(512), 0, st, P, C, rois, level_boxes,
+                    (const float*)nullptr, (float*)nullptr, out, levels_out, none);
     } else {
         launch_fused<15, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     }

@@ -113,7 +113,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int tile0 = (slot % wg_per_track) * OCT;      // first 16-channel tile (OCT = 2: tile0, tile0 + 1: same tower)
     if (n >= N) return;
     if (zero_words != nullptr && tile0 == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
-    // (Workgroups b and b + 256 share a CU — HW_ID trace in tools/debug/tower_bench.py.  Delaying the second
+    // (Workgroups b and b + 256 share a CU — HW_ID trace in measure/debug/tower_bench.py.  Delaying the second
     // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
     // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
     const float* __restrict__ in = resp + (size_t)n * C * 256;

@@ -9,7 +9,7 @@
 // Fast path (Ho == 16): two planes per wavefront, 4x2 output patches per lane (xcorr_patch2.h; the same FMA
 // phase runs inside the fused pooling+correlation kernel of sr_xcorr.hip).  The earlier generations of this
 // kernel (wave-per-plane with scalar taps, four planes per wave, packed FMA, one plane per wave, 4x4x1 matrix
-// instruction) are bit-identical A/B material and live in xcorr_variants.hip, which is compiled into the
+// instruction) are bit-identical A/B material and live in measure/csrc/xcorr_variants.hip, which is compiled into the
 // SMOT_DEBUG library only (libsmot_emm_debug.so).
 #include "smot_common.h"
 #include "knobs.h"
