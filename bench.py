@@ -218,6 +218,30 @@ def multi_stream_throughput(emm, feats, det, n_streams, dev, steps=600):
             "ms_per_step_per_stream": dt / steps * 1e3}
 
 
+def hipgraph_loop_throughput(emm, feats, det, state, steps):
+    """The timed frame-pair loop captured as ONE hipGraph per revolution of the feature ring
+    (siammot_amd.graphs.FramePairRing: len(feats) frame pairs = 4 x len(feats) kernel launches + two small copies per
+    hipGraphLaunch) and replayed: the same kernels on the same inputs, the host out of the way.  Informational — `value`
+    is the eager loop; this says what a launch-overhead-free host would get and what a replay costs the host."""
+    from siammot_amd.graphs import FramePairRing
+    ring = FramePairRing(emm, feats, det, state)
+    revs = max(4, steps // len(feats))
+    for _ in range(8):
+        ring.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(revs):
+        ring.replay()
+    t_host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the graph's last step against the eager path on the same memory: the replay computes the same frame pair
+    res = ring.results[-1]
+    return {"value": revs * len(feats) / dt, "unit": "frame-pairs/s", "ms_per_step": dt / (revs * len(feats)) * 1e3,
+            "frame_pairs_per_graph": len(feats), "kernel_nodes_per_graph": 4 * len(feats),
+            "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
+
+
 def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
     """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
     the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
@@ -483,6 +507,7 @@ def main():
     ap.add_argument("--feature-sets", type=int, default=FEATURE_SETS,
                     help="distinct synthetic frames the timed loop rotates through (8 x 38 MB exceeds the 256 MiB "
                          "Infinity Cache; 2 = the cache-warm loop of round 1)")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the frame-pair loop")
     ap.add_argument("--extra-streams", type=int, default=2,
                     help="after the timed region, also measure S independent video streams on S HIP streams of the same "
                          "GPU (reported as `multi_stream`, not as `value`); 0 disables")
@@ -604,7 +629,13 @@ def main():
             warm = {"feature_sets": 2, "value": args.steps / w_elapsed, "unit": "frame-pairs/s",
                     "ms_per_step": w_elapsed / args.steps * 1e3,
                     "note": "two alternating frames (77 MB) stay resident in the 256 MiB Infinity Cache"}
-    multi = loop_stats = None
+    multi = loop_stats = graph_stats = None
+    if world == 1 and not args.no_graph:
+        try:
+            with torch.no_grad():
+                graph_stats = hipgraph_loop_throughput(emm, feats, det, state, args.steps)
+        except Exception as e:                      # a capture failure must not cost the run its headline
+            graph_stats = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if world == 1 and args.extra_streams > 1:
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
         loop_stats = tracking_loop_throughput(n, dev, feats)
@@ -737,6 +768,7 @@ def main():
             path_algorithmic_bytes(boxes_cpu, image_wh, CHANNELS, rz, rx)),
         "parity": parity,
         "cache_warm_loop": warm,
+        "hipgraph_loop": graph_stats,
         "multi_stream": multi,
         "tracking_loop": loop_stats,
     }

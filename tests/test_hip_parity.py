@@ -1038,3 +1038,37 @@ def test_decode_near_ties_elect_the_exact_argmax(ops):
         total += len(same)
         exact += int(same.sum())
     assert exact >= 0.9 * total, "only %d/%d arg-max cells identical to the fp32 oracle" % (exact, total)
+
+
+def test_frame_pair_ring_graph_replays_the_eager_loop(ops):
+    """siammot_amd.graphs.FramePairRing: three frame pairs (twelve kernel launches) captured as one hipGraph; two
+    replays chain through the static memory exactly like six eager steps — bitwise."""
+    from siammot_amd.graphs import FramePairRing
+    from siammot_amd.structures import BoxList
+    case = dict(gi.EMM_CASES["default"], channels=32)
+    rs = np.random.RandomState(77)
+    shapes = gi.feature_shapes(case["image_wh"], 32)
+    feats = [tuple(_d(rs.standard_normal(s).astype(np.float32)) for s in shapes) for _ in range(3)]
+    boxes = np.array(case["boxes"][:5], dtype=np.float32)
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in gi.predictor_params(rs, 32, boxes).items()})
+    det = BoxList(_d(boxes), case["image_wh"], mode="xyxy")
+    det.add_field("ids", torch.arange(len(boxes), device=DEV))
+    det.add_field("labels", torch.ones(len(boxes), dtype=torch.int64, device=DEV))
+    with torch.no_grad():
+        state = emm.extract_cache(feats[2], det)
+        eager, st = [], state
+        for k in range(6):
+            _, res, _ = emm(feats[k % 3], st[2], st[1], template_features=st[0])
+            eager.append((res[0].bbox.clone(), res[0].get_field("scores").clone()))
+            st = emm.extract_cache(feats[k % 3], det)
+        ring = FramePairRing(emm, feats, det, state)
+        # (the capture itself ran warm-up revolutions: reset the ring's memory to the starting state)
+        ring.z0.copy_(state[0])
+        ring.sr0_bbox.copy_(state[1][0].bbox)
+        for rev in range(2):
+            results = ring.replay()
+            torch.cuda.synchronize()
+            for k in range(3):
+                assert torch.equal(results[k].bbox, eager[3 * rev + k][0]), (rev, k)
+                assert torch.equal(results[k].get_field("scores"), eager[3 * rev + k][1]), (rev, k)
