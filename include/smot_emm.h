@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 5
+#define SMOT_ABI_VERSION 6
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -339,6 +339,47 @@ int smot_box_refine_post_fwd(const float* head_out, int ld, int num_classes, int
                              float clip_w, float clip_h, int tracktor,
                              float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
                              smot_stream_t stream);
+
+/*
+ * The whole box-head refinement of the propagated tracks behind one call (eight launches, no host synchronisation).
+ *
+ * Replaces: CombinedROIHeads._refine_tracks (siammot/modelling/roi_heads.py:60-84) = ROIBoxHead.forward on the
+ *   propagated boxes as proposals (box_head/box_head.py:46-50: [UPSTREAM] Pooler 7x7 -> fc6 -> ReLU -> fc7 -> ReLU ->
+ *   cls_score / bbox_pred -> PostProcessor, box_head/inference.py:46-185) + the score average (roi_heads.py:66-82).
+ *   feats / heights / widths / scales: the FPN levels as in smot_roi_align_levels_fwd (the level of a roi is picked by
+ *   the roi itself, no padding); pooled = POOLER_RESOLUTION (7; 15 and 30 also run), sampling_ratio 2;
+ *   fc6_w [dim6, C*pooled^2], fc7_w [dim7, dim6], cls_w [num_classes, dim7], reg_w [4*reg_classes, dim7] (+ biases) as
+ *   the state_dict holds them; the remaining arguments as smot_box_refine_post_fwd.
+ *   ws: device fp32 [smot_box_refine_ws_floats(...)], 16-byte aligned.   N <= 64.
+ * SMOT_ERR_UNSUPPORTED: another pooler shape or layer widths that are not multiples of 4 (use the stage-wise entries).
+ */
+long long smot_box_refine_ws_floats(int N, int C, int pooled, int dim6, int dim7, int num_classes, int reg_classes);
+int smot_box_refine_fwd(const float* const* feats, const int* heights, const int* widths, const float* scales,
+                        int num_levels, int C, int pooled, int sampling_ratio, const float* boxes,
+                        const int64_t* labels, const int64_t* ids, const float* track_conf, int N,
+                        const float* fc6_w, const float* fc6_b, int dim6, const float* fc7_w, const float* fc7_b, int dim7,
+                        const float* cls_w, const float* cls_b, int num_classes,
+                        const float* reg_w, const float* reg_b, int reg_classes,
+                        float wx, float wy, float ww, float wh, float xform_clip, float clip_w, float clip_h, int tracktor,
+                        float* ws, float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
+                        smot_stream_t stream);
+
+/*
+ * y = act(x W^T + b) on a handful of rows: the box head's linear layers for the propagated tracks.
+ *
+ * Replaces: [UPSTREAM] FPN2MLPFeatureExtractor.fc6 / fc7 (+ ReLU) and FPNPredictor.cls_score / bbox_pred as
+ *   ROIBoxHead.forward calls them (siammot/modelling/box_head/box_head.py:46-50) from
+ *   CombinedROIHeads._refine_tracks (roi_heads.py:60-84), where x has one row per propagated track.
+ *   x device [M, K] (M <= smot_linear_rows_max_rows(), K % 4 == 0, 16-byte aligned), W device [N, K] as
+ *   torch.nn.Linear stores it, bias device [N] or NULL, relu 0/1, ws device fp32 [smot_linear_rows_ws_floats(M, K, N)]
+ *   (16-byte aligned scratch for the split-K partial sums), y device [M, ldy] (ldy >= N: several layers can write
+ *   column blocks of one row-major buffer).  Two launches (split-K partial products on the fp32 matrix cores, then the
+ *   slice-ordered sum + bias + ReLU); deterministic.  SMOT_ERR_UNSUPPORTED: K % 4 != 0.
+ */
+int smot_linear_rows_max_rows(void);
+long long smot_linear_rows_ws_floats(int M, int K, int N);
+int smot_linear_rows_fwd(const float* x, int M, int K, const float* W, const float* bias, int N, int relu,
+                         float* ws, float* y, int ldy, smot_stream_t stream);
 
 /*
  * Track solver: one launch for a frame's TrackSolver.forward + pool transitions + active-row filter.

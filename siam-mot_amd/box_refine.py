@@ -209,14 +209,34 @@ class TrackBoxHead(nn.Module):
         box head's output order.  Same numbers as ``forward`` + ``RefineTracks`` (tests/test_box_refine.py)."""
         fe, pp = self.feature_extractor, self.post_processor
         pooler = fe.pooler
+        cs, bp = self.predictor.cls_score, self.predictor.bbox_pred
+        bc = pp.box_coder
+        n = boxes.shape[0]
+        if (n <= ops.linear_rows_max_rows() and pooler.output_size[0] in (7, 15, 30) and pooler.sampling_ratio == 2
+                and fe.fc6.in_features % 4 == 0 and fe.fc6.out_features % 4 == 0 and fe.fc7.out_features % 4 == 0):
+            # the common case (tens of tracks, the yaml's 7x7 / 1024-1024 head): everything behind ONE C-ABI call
+            return ops.box_refine(features, pooler.scales, pooler.output_size[0], pooler.sampling_ratio, boxes, labels, ids,
+                                  conf, (fe.fc6.weight, fe.fc6.bias, fe.fc7.weight, fe.fc7.bias, cs.weight, cs.bias,
+                                         bp.weight, bp.bias), bc.weights, bc.bbox_xform_clip,
+                                  None if pp.amodal_inference else image_wh, tracktor)
         x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
-        h = _linear_relu(x.view(x.shape[0], -1), fe.fc6)
-        h = _linear_relu(h, fe.fc7)
-        w, b = self._track_weights()
-        out = torch.addmm(b, h, w)
+        x = x.view(x.shape[0], -1)
+        if x.shape[0] <= ops.linear_rows_max_rows() and x.shape[1] % 4 == 0 and fe.fc6.out_features % 4 == 0 \
+                and fe.fc7.out_features % 4 == 0:
+            # a handful of rows: weight-streaming kernels on all CUs (csrc/linear_rows.hip); the two predictor layers
+            # write the column blocks of one buffer
+            h = ops.linear_rows(x, fe.fc6.weight, fe.fc6.bias, relu=True)
+            h = ops.linear_rows(h, fe.fc7.weight, fe.fc7.bias, relu=True)
+            out = torch.empty((x.shape[0], cs.out_features + bp.out_features), dtype=torch.float32, device=x.device)
+            ops.linear_rows(h, cs.weight, cs.bias, out=out)
+            ops.linear_rows(h, bp.weight, bp.bias, out=out[:, cs.out_features:])
+        else:
+            h = _linear_relu(x, fe.fc6)
+            h = _linear_relu(h, fe.fc7)
+            w, b = self._track_weights()
+            out = torch.addmm(b, h, w)
         K = self.predictor.cls_score.out_features
         KR = self.predictor.bbox_pred.out_features // 4
-        bc = pp.box_coder
         return ops.box_refine_post(out, K, KR, boxes, labels, ids, conf, bc.weights, bc.bbox_xform_clip,
                                    None if pp.amodal_inference else image_wh, tracktor)
 

@@ -147,3 +147,74 @@ extern "C" int smot_box_refine_post_fwd(const float* head_out, int ld, int num_c
     hipLaunchKernelGGL(box_refine_post_kernel, dim3(1), dim3(BR_MAXN), 0, (hipStream_t)stream, A, N);
     return check_launch("box_refine_post");
 }
+
+
+// ---- the whole refinement of the propagated tracks behind ONE call ------------------------------------------------------
+// HIP 7x7 pooler -> fc6 + ReLU -> fc7 + ReLU -> cls_score | bbox_pred -> post-processing: eight launches enqueued by one
+// C-ABI crossing (the Python layer paid one ctypes call + one tensor allocation per stage).
+#include "roi_common.h"
+namespace smot {
+int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
+                              int out_size, float* out, int32_t* levels_out, hipStream_t st);          // sr_xcorr.hip
+int launch_linear_rows(const float* x, int M, int K, const float* W, const float* bias, int N, int relu, float* ws,
+                       float* y, int ldy, hipStream_t st);                                              // linear_rows.hip
+int launch_linear_rows2(const float* x, int M, int K, const float* W, const float* bias, int N1, const float* W2,
+                        const float* bias2, int N2, int relu, float* ws, float* y, int ldy, hipStream_t st);
+}
+extern "C" long long smot_linear_rows_ws_floats(int M, int K, int N);
+
+static inline size_t br_align4(size_t n) { return (n + 3) & ~(size_t)3; }
+
+extern "C" long long smot_box_refine_ws_floats(int N, int C, int pooled, int dim6, int dim7, int num_classes,
+                                               int reg_classes) {
+    if (N <= 0 || N > 64) return 0;
+    const int K0 = C * pooled * pooled, NH = num_classes + 4 * reg_classes;
+    long long g = smot_linear_rows_ws_floats(N, K0, dim6);
+    const long long g7 = smot_linear_rows_ws_floats(N, dim6, dim7), gh = smot_linear_rows_ws_floats(N, dim7, num_classes + 4 * reg_classes);
+    if (g7 > g) g = g7;
+    if (gh > g) g = gh;
+    return (long long)(br_align4((size_t)N * K0) + br_align4((size_t)N * dim6) + br_align4((size_t)N * dim7) +
+                       br_align4((size_t)N * NH)) + g;
+}
+
+extern "C" int smot_box_refine_fwd(const float* const* feats, const int* heights, const int* widths, const float* scales,
+                                   int num_levels, int C, int pooled, int sampling_ratio, const float* boxes,
+                                   const int64_t* labels, const int64_t* ids, const float* track_conf, int N,
+                                   const float* fc6_w, const float* fc6_b, int dim6, const float* fc7_w,
+                                   const float* fc7_b, int dim7, const float* cls_w, const float* cls_b, int num_classes,
+                                   const float* reg_w, const float* reg_b, int reg_classes, float wx, float wy, float ww,
+                                   float wh, float xform_clip, float clip_w, float clip_h, int tracktor, float* ws,
+                                   float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
+                                   smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && N <= 64, "box_refine: N=%d not in [0,64] (use the stage-wise entries)", N);
+    const int K0 = C * pooled * pooled;
+    if (!((pooled == 7 || pooled == 15 || pooled == 30) && sampling_ratio == 2 && (K0 & 3) == 0 && (dim6 & 3) == 0 &&
+          (dim7 & 3) == 0)) {
+        set_error("box_refine: pooler %dx%d / sampling %d / layer widths %d,%d,%d not covered by the one-call path", pooled,
+                  pooled, sampling_ratio, K0, dim6, dim7);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(boxes && ws && fc6_w && fc7_w && cls_w && reg_w, "box_refine: null pointer");
+    SMOT_REQUIRE(((uintptr_t)ws & 15) == 0, "box_refine: ws must be 16-byte aligned");
+    LevelParams P;
+    int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "box_refine");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int NH = num_classes + 4 * reg_classes;
+    float* x0 = ws;
+    float* h6 = x0 + br_align4((size_t)N * K0);
+    float* h7 = h6 + br_align4((size_t)N * dim6);
+    float* ho = h7 + br_align4((size_t)N * dim7);
+    float* gw = ho + br_align4((size_t)N * NH);
+    rc = launch_roi_pool_separable(P, C, boxes, boxes, N, pooled, x0, nullptr, st);          // Pooler: level of the roi itself
+    if (rc) return rc;
+    if ((rc = launch_linear_rows(x0, N, K0, fc6_w, fc6_b, dim6, 1, gw, h6, dim6, st))) return rc;
+    if ((rc = launch_linear_rows(h6, N, dim6, fc7_w, fc7_b, dim7, 1, gw, h7, dim7, st))) return rc;
+    // cls_score | bbox_pred side by side in one launch pair
+    if ((rc = launch_linear_rows2(h7, N, dim7, cls_w, cls_b, num_classes, reg_w, reg_b, 4 * reg_classes, 0, gw, ho, NH, st)))
+        return rc;
+    return smot_box_refine_post_fwd(ho, NH, num_classes, reg_classes, boxes, labels, ids, track_conf, N, wx, wy, ww, wh,
+                                    xform_clip, clip_w, clip_h, tracktor, out_boxes, out_scores, out_ids, out_labels, stream);
+}

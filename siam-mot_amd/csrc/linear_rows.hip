@@ -1,0 +1,194 @@
+// Linear layers on a handful of rows — the box head's fc6 / fc7 / cls_score|bbox_pred for the propagated tracks.
+//
+// Replaces, inside CombinedROIHeads._refine_tracks (reference siammot/modelling/roi_heads.py:60-84 ->
+// box_head/box_head.py:46-50 -> [UPSTREAM] FPN2MLPFeatureExtractor / FPNPredictor): y = act(x W^T + b) with
+// x [M, K], M = number of propagated tracks (tens), W [N, K] as torch.nn.Linear stores it.  At M = 30 the library GEMM
+// (hipBLASLt through torch) runs fc6 (K = 6272, N = 1024: 25.7 MB of weights) on 128 workgroups in 20 us; the layer is
+// WEIGHT STREAMING — every weight is used M times — so the job is to pull W through all 256 CUs at HBM speed.
+//
+//   * split-K: workgroup = (64 output neurons, one K slice), grid chosen for >= 2 workgroups per CU; four waves, each
+//     a 16-neuron tile; per step of 64 k a lane loads four float4 of its neuron's weights (256 contiguous bytes per
+//     neuron per step: whole lines) and the workgroup stages the x slice [rows][64 k] in LDS once for all four waves;
+//   * the products run on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-add, D[neuron][row]): A = weights, B = x^T read
+//     back from LDS as float4 (element j of a lane's float4 is the operand of the j-th MFMA, for A and B alike, so no
+//     shuffles); the next step's loads are in flight while the current one multiplies;
+//   * the partial sums of the K slices are written out and a second, tiny launch adds them in slice order (+ bias,
+//     ReLU): deterministic, and the kernel boundary is the cross-XCD visibility point (no atomics).
+// Rows: up to 64 (1..4 row tiles of 16); K must be a multiple of 4 (the wrapper falls back to the library otherwise).
+#include "smot_common.h"
+#include "tower_common.h"
+
+namespace smot {
+
+constexpr int LR_NB = 64;        // neurons per workgroup (4 waves x 16)
+constexpr int LR_KS = 64;        // k per step (a lane holds four float4 of weights: 4 KB per wave per step in flight)
+constexpr int LR_XS = 68;        // LDS row stride of the staged x slice (floats)
+
+template <int MT>                // row tiles of 16
+__global__ void __launch_bounds__(256)
+linear_rows_partial_kernel(const float* __restrict__ x, int M, int K, const float* __restrict__ W, int N,
+                           const float* __restrict__ W2, int N1, int kslice, float* __restrict__ part) {
+    // (W2 != nullptr: two layers on the same input side by side — neurons [0, N1) are rows of W, [N1, N) rows of W2:
+    // cls_score | bbox_pred in one launch)
+    __shared__ __attribute__((aligned(16))) float xs[2][MT * 16][LR_XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = blockIdx.x, s = blockIdx.y;
+    const int k_begin = s * kslice, k_end = min(K, k_begin + kslice);
+    const int n = nb * LR_NB + wave * 16 + (lane & 15);
+    const int kq = lane >> 4;
+    const bool n_ok = n < N;
+    const int nc = min(n, N - 1);
+    const float* __restrict__ wrow = (W2 != nullptr && nc >= N1) ? W2 + (size_t)(nc - N1) * K : W + (size_t)nc * K;
+    // x staging: thread t loads float4 (row t / 16 (+16 q), k4 = (t % 16) * 4)
+    const int xr = tid >> 4, xk = (tid & 15) * 4;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 wreg[4], xreg[MT];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int k = k0 + 16 * h + 4 * kq;
+            wreg[h] = (n_ok && k < k_end) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < MT; ++q) {
+            const int r = xr + 16 * q, k = k0 + xk;
+            xreg[q] = (r < M && k < k_end) ? *reinterpret_cast<const float4*>(x + (size_t)r * K + k)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < MT; ++q) *reinterpret_cast<float4*>(&xs[buf][xr + 16 * q][xk]) = xreg[q];
+    };
+    const int nsteps = (k_end - k_begin + LR_KS - 1) / LR_KS;
+    if (nsteps > 0) {
+        fetch(k_begin);
+        float4 wcur[4] = {wreg[0], wreg[1], wreg[2], wreg[3]};
+        stash(0);
+        __syncthreads();
+        for (int st = 0; st < nsteps; ++st) {
+            const int buf = st & 1;
+            if (st + 1 < nsteps) fetch(k_begin + (st + 1) * LR_KS);           // next step's loads in flight
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float a4[4] = {wcur[h].x, wcur[h].y, wcur[h].z, wcur[h].w};
+                float4 b4[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    b4[t] = *reinterpret_cast<const float4*>(&xs[buf][t * 16 + (lane & 15)][16 * h + 4 * kq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < MT; ++t) {
+                        const float b = j == 0 ? b4[t].x : (j == 1 ? b4[t].y : (j == 2 ? b4[t].z : b4[t].w));
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b, acc[t], 0, 0, 0);
+                    }
+            }
+            if (st + 1 < nsteps) {
+                stash(buf ^ 1);                  // the other buffer: its readers passed the barrier of the previous step
+#pragma unroll
+                for (int h = 0; h < 4; ++h) wcur[h] = wreg[h];
+            }
+            __syncthreads();
+        }
+    }
+    // D[neuron = 4 * (lane >> 4) + r][row = lane & 15 (+ 16 t)] -> part[s][nb][row][neuron]
+    float* __restrict__ p = part + ((size_t)(s * gridDim.x + nb) * (MT * 16)) * LR_NB;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int row = t * 16 + (lane & 15);
+        *reinterpret_cast<float4*>(p + (size_t)row * LR_NB + wave * 16 + 4 * (lane >> 4)) =
+            make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+linear_rows_reduce_kernel(const float* __restrict__ part, int S, int nblk, int rows_pad, int M, int N,
+                          const float* __restrict__ bias, const float* __restrict__ bias2, int N1, int relu,
+                          float* __restrict__ y, int ldy) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // (row, neuron)
+    if (e >= M * N) return;
+    const int m = e / N, n = e - m * N;
+    const int nb = n / LR_NB, nl = n - nb * LR_NB;
+    const float* __restrict__ p = part + ((size_t)nb * rows_pad + m) * LR_NB + nl;
+    const size_t stride = (size_t)nblk * rows_pad * LR_NB;         // between K slices
+    float v = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 8) {                            // eight independent loads, then the ordered adds
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = (s0 + q < S) ? p[(size_t)(s0 + q) * stride] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (s0 + q < S) v = add_rn(v, t[q]);
+    }
+    const float* __restrict__ bsel = (bias2 != nullptr && n >= N1) ? bias2 + (n - N1) : (bias != nullptr ? bias + n : nullptr);
+    if (bsel != nullptr) v = add_rn(v, *bsel);
+    if (relu) v = fmaxf(v, 0.0f);
+    y[(size_t)m * ldy + n] = v;
+}
+
+// Launch geometry shared by the workspace query and the launcher.
+struct LinearRowsPlan {
+    int mt, nblk, S, kslice;
+    size_t part_floats;
+};
+inline LinearRowsPlan linear_rows_plan(int M, int K, int N) {
+    LinearRowsPlan P;
+    P.mt = (M + 15) / 16;
+    P.nblk = (N + LR_NB - 1) / LR_NB;
+    const int ksteps = (K + LR_KS - 1) / LR_KS;
+    int S = (512 + P.nblk - 1) / P.nblk;            // about two workgroups per CU
+    if (S > ksteps) S = ksteps;
+    if (S < 1) S = 1;
+    P.kslice = ((ksteps + S - 1) / S) * LR_KS;
+    P.S = (K + P.kslice - 1) / P.kslice;
+    P.part_floats = (size_t)P.S * P.nblk * (P.mt * 16) * LR_NB;
+    return P;
+}
+
+// W2 / bias2 / N2: a second layer on the same input whose N2 outputs follow the first layer's N1 = N columns of y
+int launch_linear_rows2(const float* x, int M, int K, const float* W, const float* bias, int N1, const float* W2,
+                        const float* bias2, int N2, int relu, float* ws, float* y, int ldy, hipStream_t st) {
+    const int N = N1 + N2;
+    const LinearRowsPlan P = linear_rows_plan(M, K, N);
+    dim3 grid(P.nblk, P.S);
+    switch (P.mt) {
+        case 1: hipLaunchKernelGGL(linear_rows_partial_kernel<1>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 2: hipLaunchKernelGGL(linear_rows_partial_kernel<2>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 3: hipLaunchKernelGGL(linear_rows_partial_kernel<3>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+    }
+    hipLaunchKernelGGL(linear_rows_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, (const float*)ws, P.S, P.nblk,
+                       P.mt * 16, M, N, bias, bias2, N1, relu, y, ldy);
+    return check_launch("linear_rows");
+}
+
+int launch_linear_rows(const float* x, int M, int K, const float* W, const float* bias, int N, int relu, float* ws,
+                       float* y, int ldy, hipStream_t st) {
+    return launch_linear_rows2(x, M, K, W, bias, N, nullptr, nullptr, 0, relu, ws, y, ldy, st);
+}
+
+}  // namespace smot
+
+extern "C" int smot_linear_rows_max_rows(void) { return 64; }
+
+extern "C" long long smot_linear_rows_ws_floats(int M, int K, int N) {
+    if (M <= 0 || M > 64 || K <= 0 || N <= 0) return 0;
+    return (long long)smot::linear_rows_plan(M, K, N).part_floats;
+}
+
+extern "C" int smot_linear_rows_fwd(const float* x, int M, int K, const float* W, const float* bias, int N, int relu,
+                                    float* ws, float* y, int ldy, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(M >= 0 && M <= 64 && K > 0 && N > 0 && ldy >= N, "linear_rows: bad sizes M=%d K=%d N=%d ldy=%d", M, K, N, ldy);
+    if ((K & 3) != 0) {
+        set_error("linear_rows: K=%d is not a multiple of 4 (use the library GEMM)", K);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (M == 0) return SMOT_OK;
+    SMOT_REQUIRE(x && W && ws && y, "linear_rows: null pointer");
+    SMOT_REQUIRE((((uintptr_t)x | (uintptr_t)W | (uintptr_t)ws) & 15) == 0, "linear_rows: x, W and ws must be 16-byte aligned");
+    return launch_linear_rows(x, M, K, W, bias, N, relu, ws, y, ldy, (hipStream_t)stream);
+}

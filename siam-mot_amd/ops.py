@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -68,6 +68,13 @@ _SIGNATURES = {
     "smot_box_refine_post_max_rows": (ctypes.c_int, []),
     "smot_box_refine_post_fwd": (ctypes.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _i,
                                                 _vp, _vp, _vp, _vp, _vp]),
+    "smot_box_refine_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i, _i, _i, _i]),
+    "smot_box_refine_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i,
+                                           _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
+                                           _f, _f, _f, _f, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "smot_linear_rows_max_rows": (ctypes.c_int, []),
+    "smot_linear_rows_ws_floats": (ctypes.c_longlong, [_i, _i, _i]),
+    "smot_linear_rows_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -921,6 +928,85 @@ def box_refine_post(head_out, num_classes, reg_classes, boxes, labels, ids, trac
                                           _ptr(out_labels), ln.stream)
     _check(rc, "box_refine_post")
     return out_boxes, out_scores, out_ids, out_labels
+
+
+_lin_ws = {}
+
+
+def box_refine(features, scales, pooled, sampling_ratio, boxes, labels, ids, track_conf, layers, weights, xform_clip,
+               clip_wh, tracktor=False):
+    """``smot_box_refine_fwd``: 7x7 pooler -> fc6 -> fc7 -> cls_score | bbox_pred -> post-processing of N <= 64
+    propagated tracks in ONE call (eight launches, no synchronisation).  ``layers`` = (fc6.weight, fc6.bias, fc7.weight,
+    fc7.bias, cls_score.weight, cls_score.bias, bbox_pred.weight, bbox_pred.bias).  Returns ``(boxes, scores, ids,
+    labels)`` in the box head's output order."""
+    lib = _lib or load_library()
+    L = len(scales)
+    feats = [_dev_f32(features[l], "features[%d]" % l) for l in range(L)]
+    boxes = _dev_f32(boxes, "boxes")
+    track_conf = _dev_f32(track_conf, "track_conf")
+    w6, b6, w7, b7, wc, bc, wr, br = [_dev_f32(t, "box head parameter") for t in layers]
+    N, C, dev = boxes.shape[0], feats[0].shape[1], boxes.device
+    K, KR = wc.shape[0], wr.shape[0] // 4
+    for name, t in (("labels", labels), ("ids", ids)):
+        if not (t.is_cuda and t.dtype is torch.int64 and t.is_contiguous() and t.device == dev and t.shape[0] == N):
+            raise RuntimeError("siammot_amd.box_refine: %s must be a contiguous int64 [N] tensor on the boxes' device" % name)
+    if w6.shape[1] != C * pooled * pooled or w7.shape[1] != w6.shape[0] or wc.shape[1] != w7.shape[0] or wr.shape[1] != w7.shape[0]:
+        raise RuntimeError("siammot_amd.box_refine: layer shapes do not chain")
+    need = int(lib.smot_box_refine_ws_floats(N, C, int(pooled), w6.shape[0], w7.shape[0], K, KR))
+    ws = _lin_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _lin_ws[dev] = torch.empty((max(need, 1 << 20),), dtype=_F32, device=dev)
+    out_boxes = torch.empty((N, 4), dtype=_F32, device=dev)
+    out_scores = torch.empty((N,), dtype=_F32, device=dev)
+    out_ids = torch.empty((N,), dtype=torch.int64, device=dev)
+    out_labels = torch.empty((N,), dtype=torch.int64, device=dev)
+    fp = (ctypes.c_void_p * L)(*[f.data_ptr() for f in feats])
+    hs = (ctypes.c_int * L)(*[f.shape[2] for f in feats])
+    wsz = (ctypes.c_int * L)(*[f.shape[3] for f in feats])
+    sc = (ctypes.c_float * L)(*[float(s_) for s_ in scales])
+    cast = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    cw, ch = (0.0, 0.0) if clip_wh is None else (float(clip_wh[0]), float(clip_wh[1]))
+    with _Launch(boxes, track_conf, labels, ids, w6, *feats) as ln:
+        rc = lib.smot_box_refine_fwd(cast(fp), cast(hs), cast(wsz), cast(sc), L, C, int(pooled), int(sampling_ratio),
+                                     _ptr(boxes), _ptr(labels), _ptr(ids), _ptr(track_conf), N,
+                                     _ptr(w6), _ptr(b6), w6.shape[0], _ptr(w7), _ptr(b7), w7.shape[0],
+                                     _ptr(wc), _ptr(bc), K, _ptr(wr), _ptr(br), KR,
+                                     float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]),
+                                     float(xform_clip), cw, ch, int(bool(tracktor)), _ptr(ws), _ptr(out_boxes),
+                                     _ptr(out_scores), _ptr(out_ids), _ptr(out_labels), ln.stream)
+    _check(rc, "box_refine")
+    return out_boxes, out_scores, out_ids, out_labels
+
+
+def linear_rows(x, weight, bias=None, relu=False, out=None):
+    """``smot_linear_rows_fwd``: ``act(x @ weight.T + bias)`` for x ``[M, K]`` with M <= ``linear_rows_max_rows()`` rows
+    (the box head's layers on the propagated tracks: weight streaming on all CUs instead of the library's 128
+    workgroups at M = 30).  ``out``: an ``[M, >=N]`` row-major view to write into (column block).  Launch only."""
+    lib = _lib or load_library()
+    x = _dev_f32(x, "x")
+    weight = _dev_f32(weight, "weight")
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise RuntimeError("siammot_amd.linear_rows: x is [%d,%d], weight [%d,%d]" % (M, K, N, weight.shape[1]))
+    if bias is not None:
+        bias = _dev_f32(bias, "bias")
+    y = out if out is not None else torch.empty((M, N), dtype=_F32, device=x.device)
+    if y.stride(1) != 1 or y.shape[0] != M or y.shape[1] < N:
+        raise RuntimeError("siammot_amd.linear_rows: out must be a row-major [M, >=N] view")
+    need = int(lib.smot_linear_rows_ws_floats(M, K, N))
+    ws = _lin_ws.get(x.device)
+    if ws is None or ws.numel() < need:
+        ws = _lin_ws[x.device] = torch.empty((max(need, 1 << 20),), dtype=_F32, device=x.device)
+    with _Launch(x, weight, y) as ln:
+        rc = lib.smot_linear_rows_fwd(_ptr(x), M, K, _ptr(weight), _ptr(bias), N, int(bool(relu)), _ptr(ws), _ptr(y),
+                                      y.stride(0), ln.stream)
+    _check(rc, "linear_rows")
+    return y
+
+
+def linear_rows_max_rows():
+    return (_lib or load_library()).smot_linear_rows_max_rows()
 
 
 def box_refine_post_max_rows():

@@ -126,8 +126,8 @@ def test_box_head_on_the_hip_pooler_and_nms_matches_reference_golden():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tracktor", [False, True])
-def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(tracktor):
+@pytest.mark.parametrize("tracktor,one_call", [(False, True), (True, True), (False, False)])
+def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(tracktor, one_call, monkeypatch):
     """``RefineTracks.refine_raw`` (HIP pooler -> three GEMMs -> smot_box_refine_post_fwd: no BoxList, no host
     synchronisation) on the seven propagated tracks of the golden case — three classes, labels {1, 2}: the rows come
     back grouped by label and the matching scores are paired in input order, as the reference's
@@ -141,6 +141,9 @@ def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(trac
     feats = [torch.from_numpy(f).to(dev) for f in inp["features"]]
     refine = RefineTracks(head, tracktor=tracktor)
     assert refine.raw_ok(7)
+    if not one_call:          # the stage-wise form (more than 64 rows, other layer widths): library GEMMs + post kernel
+        import siammot_amd.ops as ops_
+        monkeypatch.setattr(ops_, "linear_rows_max_rows", lambda: 0)
     args = [torch.from_numpy(inp[k].copy()).to(dev) for k in ("track_boxes", "track_scores", "track_ids", "track_labels")]
     refine.refine_raw(feats, *args, c["image_wh"])           # first call: builds the concatenated head weights
     torch.cuda.synchronize()
@@ -160,6 +163,34 @@ def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(trac
         np.testing.assert_allclose(bb.cpu().numpy(), g["refine_bbox"], rtol=0, atol=2e-3)
         np.testing.assert_allclose(sc.cpu().numpy(), g["refine_scores"], rtol=0, atol=2e-5)
     assert float(sc.min()) > 1.0 and float(sc.max()) <= 2.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,relu", [(30, 6272, 1024, True), (30, 1024, 1024, True), (7, 1024, 10, False),
+                                        (64, 6272, 64, False), (1, 64, 3, True), (33, 100, 130, False), (16, 36, 2, False)])
+def test_linear_rows_matches_the_library_gemm(M, K, N, relu):
+    """``smot_linear_rows_fwd`` (split-K weight streaming on the fp32 matrix cores + slice-ordered reduction) against a
+    float64 reference: the box head's layers at the sizes of DLA_34_FPN_EMM.yaml (fc6 6272 -> 1024, fc7, predictor) and
+    edge shapes (one row, 64 rows, K not a multiple of the step, N below a tile, a column-block output)."""
+    import siammot_amd.ops as ops
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    x = torch.randn((M, K), generator=g).cuda()
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).cuda()
+    b = torch.randn((N,), generator=g).cuda()
+    ref = x.double() @ w.double().t() + b.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    y = ops.linear_rows(x, w, b, relu=relu)
+    assert y.shape == (M, N)
+    scale = float((x.double().abs() @ w.double().abs().t()).max())
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * scale
+    assert torch.equal(y, ops.linear_rows(x, w, b, relu=relu))                     # deterministic
+    buf = torch.full((M, N + 5), -7.0, device="cuda")
+    ops.linear_rows(x, w, None, relu=False, out=buf[:, 3:])                        # column block, no bias
+    assert torch.equal(buf[:, :3], torch.full((M, 3), -7.0, device="cuda")) and float(buf[:, 3 + N:].max()) == -7.0
+    assert float((buf[:, 3:3 + N].double() - (ref - b.double() if not relu else x.double() @ w.double().t())).abs().max()) <= 2e-6 * scale
+    with pytest.raises(RuntimeError):
+        ops.linear_rows(torch.randn((3, 6), device="cuda"), torch.randn((4, 6), device="cuda"))      # K % 4 != 0
 
 
 @pytest.mark.gpu
