@@ -318,17 +318,22 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n
     # tracks live on, every frame's n detections compete with them in NMS
     loop.solver.start_thresh, loop.solver.track_thresh = 2.0, 0.0
-    lean = [0]
-    step_lean = loop._step_lean
+    lean = [0, 0]
+    step_lean, step_native = loop._step_lean, loop._step_native
 
     def counted(*a, **k):
         lean[0] += 1
         return step_lean(*a, **k)
-    loop._step_lean = counted
+
+    def counted_native(*a, **k):
+        lean[0] += 1
+        lean[1] += 1
+        return step_native(*a, **k)
+    loop._step_lean, loop._step_native = counted, counted_native
     for k in range(1, 30):
         out = loop(feats[k & 1], dets(k))
     torch.cuda.synchronize()
-    lean[0] = 0
+    lean[0] = lean[1] = 0
     t0 = time.perf_counter()
     for k in range(steps):
         out = loop(feats[k & 1], dets(k))
@@ -338,7 +343,7 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
     return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
             "refine_tracks": "TrackBoxHead (7x7 HIP pooler, 1024-1024 MLP, one-launch post-processing)" if refine else None,
-            "one_launch_path_frames": lean[0], "frames": steps,
+            "one_launch_path_frames": lean[0], "one_call_frames": lean[1], "frames": steps,
             "note": "head + %sone-launch solver (device-resident pool) + track memory; synthetic detections resident on "
                     "the device; one host synchronisation per frame" % ("box-head refinement of the propagated boxes + "
                                                                         if refine else "")}

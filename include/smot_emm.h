@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 6
+#define SMOT_ABI_VERSION 7
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -424,6 +424,71 @@ int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_
                          float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
                          float* act_boxes, int64_t* act_ids, int64_t* act_labels, float* act_scores,
                          int* record, smot_stream_t stream);
+
+/*
+ * One tracking frame behind ONE call: the launches of smot_emm_track_fwd (3) [+ smot_box_refine_fwd (8)] +
+ * smot_track_solve_fwd (1) + smot_emm_extract_cache_masked_fwd (1) enqueued back to back on `stream`.
+ *
+ * Replaces the inference branch of CombinedROIHeads.forward from `self.track(...)` on
+ * (siammot/modelling/roi_heads.py:38-50): TrackHead.forward_inference -> EMM.forward (track_head.py:37-46),
+ * _refine_tracks (roi_heads.py:60-84), cat_boxlist + TrackSolver.forward (track_solver.py:36-108),
+ * TrackHead.get_track_memory -> EMM.extract_cache on the rows the solver leaves active (track_head.py:54-75,99-110).
+ * Every field is an argument of one of the four entry points above and means what it means there; the outputs of a
+ * stage are the inputs of the next (the propagated boxes / scores feed the refinement or the solver, the solver's
+ * act_boxes and pool_state[4] feed the masked template extraction).  n_trk == 0 skips the head and the refinement
+ * (first frame, or an empty memory); refine == 0 skips the refinement (the solver then applies trk_score_bias = 1).
+ * The host reads `record` (pinned host memory) as with smot_track_solve_fwd.  Plain C struct: no padding surprises —
+ * pointers first, then 32-bit fields.
+ */
+typedef struct smot_frame_args {
+    /* FPN levels (HOST arrays of num_levels entries, as in smot_roi_align_levels_fwd) */
+    const float* const* feats;
+    const int* heights;
+    const int* widths;
+    const int* pad_cells;        /* search-region pooling (virtual padding) */
+    const float* scales;
+    /* track memory of the previous frame */
+    const float* tpl_boxes;      /* [n_trk,4] */
+    const float* sr;             /* [n_trk,4] */
+    const float* templates;      /* [n_trk,C,rz,rz] */
+    const int64_t* trk_ids;      /* [n_trk] */
+    const int64_t* trk_labels;   /* [n_trk] */
+    /* head */
+    const float* const* predictor_params;   /* HOST array of 13 device pointers (smot_emm_track_fwd) */
+    const float* hann;
+    float* head_ws;              /* smot_emm_track_ws_floats(n_trk, C, rx, rz) */
+    float* trk_boxes;            /* [n_trk,4] out: propagated boxes */
+    float* trk_conf;             /* [n_trk]   out: matching scores */
+    /* box-head refinement (refine != 0) */
+    const float* fc6_w; const float* fc6_b; const float* fc7_w; const float* fc7_b;
+    const float* cls_w; const float* cls_b; const float* reg_w; const float* reg_b;
+    float* refine_ws;            /* smot_box_refine_ws_floats(...) */
+    float* ref_boxes;            /* [n_trk,4] out */
+    float* ref_scores;           /* [n_trk]   out */
+    int64_t* ref_ids;            /* [n_trk]   out */
+    int64_t* ref_labels;         /* [n_trk]   out */
+    /* this frame's detections */
+    const float* det_boxes; float* det_scores; const int64_t* det_ids; const int64_t* det_labels;
+    /* solver */
+    int* pool_state;
+    float* out_boxes; float* out_scores; int64_t* out_ids; int64_t* out_labels;
+    float* act_boxes; int64_t* act_ids; int64_t* act_labels; float* act_scores;
+    int* record;
+    /* next frame's memory (capacity n_det + n_trk rows; the first pool_state[4] are written) */
+    float* next_templates;
+    float* next_sr;
+    /* sizes and scalars */
+    int num_levels, C, n_trk, n_det;
+    int rx, rz, sampling_ratio, gn_groups, up, use_centerness;
+    int refine, box_pooled, box_sampling_ratio, dim6, dim7, num_classes, reg_classes, tracktor;
+    int max_dormant_frames, pool_capacity;
+    float gn_eps, pad_pixels, one_minus_sigma, sigma, clip_w, clip_h;
+    float box_wx, box_wy, box_ww, box_wh, box_xform_clip;
+    float track_thresh, start_thresh, resume_thresh, nms_thresh;
+    float search_expansion, min_search_wh;
+} smot_frame_args;
+
+int smot_track_frame_fwd(const smot_frame_args* args, smot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,16 @@ def wrap(obj, name, key=None):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); acc[key] = acc.get(key, 0.0) + time.perf_counter() - t0; return r
     setattr(obj, name, g)
-for n in ("emm_track", "box_refine", "track_solve", "emm_extract_cache"):
+for n in ("emm_track", "box_refine", "track_solve", "emm_extract_cache", "track_frame", "_geometry", "_param_block"):
     wrap(ops, n)
 wrap(ops.HostRecordRing, "wait", "record_wait")
+wrap(ops.FrameArgs, "pack", "args_pack")
+from siammot_amd.track_head import TrackingLoop
+wrap(TrackingLoop, "_finish_frame", "finish_frame")
+wrap(TrackingLoop, "_native_ok", "native_ok")
+wrap(TrackingLoop, "_lean_ok", "lean_ok")
+if len(sys.argv) > 2 and sys.argv[2] == "python":
+    TrackingLoop._native_ok = lambda self, d: False
 bench.tracking_loop_throughput(30, dev, feats, steps=50, refine=refine)
 acc.clear()
 out = bench.tracking_loop_throughput(30, dev, feats, steps=600, refine=refine)

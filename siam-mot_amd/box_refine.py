@@ -195,6 +195,13 @@ class TrackBoxHead(nn.Module):
             self.__dict__["_track_w"] = hit
         return hit[1], hit[2]
 
+    def one_call_ok(self, n):
+        """The whole refinement of ``n`` rows fits ``smot_box_refine_fwd`` (and so the one-call tracking frame)."""
+        fe, pooler = self.feature_extractor, self.feature_extractor.pooler
+        return (self.raw_ok(n) and n <= ops.linear_rows_max_rows() and pooler.output_size[0] in (7, 15, 30)
+                and pooler.sampling_ratio == 2 and fe.fc6.in_features % 4 == 0 and fe.fc6.out_features % 4 == 0
+                and fe.fc7.out_features % 4 == 0)
+
     def raw_ok(self, n):
         """``refine_raw`` applies: HIP pooler, a threshold no track row can fall under, few enough rows."""
         pp = self.post_processor
@@ -215,10 +222,14 @@ class TrackBoxHead(nn.Module):
         if (n <= ops.linear_rows_max_rows() and pooler.output_size[0] in (7, 15, 30) and pooler.sampling_ratio == 2
                 and fe.fc6.in_features % 4 == 0 and fe.fc6.out_features % 4 == 0 and fe.fc7.out_features % 4 == 0):
             # the common case (tens of tracks, the yaml's 7x7 / 1024-1024 head): everything behind ONE C-ABI call
-            return ops.box_refine(features, pooler.scales, pooler.output_size[0], pooler.sampling_ratio, boxes, labels, ids,
-                                  conf, (fe.fc6.weight, fe.fc6.bias, fe.fc7.weight, fe.fc7.bias, cs.weight, cs.bias,
-                                         bp.weight, bp.bias), bc.weights, bc.bbox_xform_clip,
-                                  None if pp.amodal_inference else image_wh, tracktor)
+            out = ops.box_refine(features, pooler.scales, pooler.output_size[0], pooler.sampling_ratio, boxes, labels, ids,
+                                 conf, (fe.fc6.weight, fe.fc6.bias, fe.fc7.weight, fe.fc7.bias, cs.weight, cs.bias,
+                                        bp.weight, bp.bias), bc.weights, bc.bbox_xform_clip,
+                                 None if pp.amodal_inference else image_wh, tracktor)
+            hook = self.__dict__.get("raw_output_hook")      # tests / probes: (boxes, scores, ids, labels) of the refinement
+            if hook is not None:
+                hook(*out)
+            return out
         x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
         x = x.view(x.shape[0], -1)
         if x.shape[0] <= ops.linear_rows_max_rows() and x.shape[1] % 4 == 0 and fe.fc6.out_features % 4 == 0 \

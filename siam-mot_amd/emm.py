@@ -170,9 +170,13 @@ class EMM(nn.Module):
             st = self.__dict__["_static"] = (pr.param_dict(), tuple(fe.scales), fe.sampling_ratio, pr.gn_groups,
                                              pr.gn_eps)
         params, scales, sampling_ratio, gn_groups, gn_eps = st
-        return ops.emm_track(features, boxes, sr, template_features, params, self.rx, self.rz, scales, sampling_ratio,
-                             self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
-                             clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps)
+        out = ops.emm_track(features, boxes, sr, template_features, params, self.rx, self.rz, scales, sampling_ratio,
+                            self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
+                            clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps)
+        hook = self.__dict__.get("raw_output_hook")          # tests / probes: the head's output before refinement / solver
+        if hook is not None:
+            hook(out[0], out[1])
+        return out
 
     def extract_cache(self, features, detection):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""

@@ -12,6 +12,7 @@ Operator ↔ reference map (reference paths relative to amazon-science/siam-mot)
 """
 import contextlib
 import ctypes
+import struct
 import weakref
 import os
 
@@ -22,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -75,6 +76,7 @@ _SIGNATURES = {
     "smot_linear_rows_max_rows": (ctypes.c_int, []),
     "smot_linear_rows_ws_floats": (ctypes.c_longlong, [_i, _i, _i]),
     "smot_linear_rows_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
+    "smot_track_frame_fwd": (ctypes.c_int, [_vp, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -1011,6 +1013,59 @@ def linear_rows_max_rows():
 
 def box_refine_post_max_rows():
     return (_lib or load_library()).smot_box_refine_post_max_rows()
+
+
+_FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "tpl_boxes", "sr", "templates", "trk_ids", "trk_labels",
+               "predictor_params", "hann", "head_ws", "trk_boxes", "trk_conf",
+               "fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "reg_w", "reg_b", "refine_ws",
+               "ref_boxes", "ref_scores", "ref_ids", "ref_labels",
+               "det_boxes", "det_scores", "det_ids", "det_labels", "pool_state",
+               "out_boxes", "out_scores", "out_ids", "out_labels", "act_boxes", "act_ids", "act_labels", "act_scores",
+               "record", "next_templates", "next_sr")
+_FRAME_INTS = ("num_levels", "C", "n_trk", "n_det", "rx", "rz", "sampling_ratio", "gn_groups", "up", "use_centerness",
+               "refine", "box_pooled", "box_sampling_ratio", "dim6", "dim7", "num_classes", "reg_classes", "tracktor",
+               "max_dormant_frames", "pool_capacity")
+_FRAME_FLOATS = ("gn_eps", "pad_pixels", "one_minus_sigma", "sigma", "clip_w", "clip_h",
+                 "box_wx", "box_wy", "box_ww", "box_wh", "box_xform_clip",
+                 "track_thresh", "start_thresh", "resume_thresh", "nms_thresh", "search_expansion", "min_search_wh")
+
+
+class FrameArgs(object):
+    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 44 pointers, 20 ints, 17 floats, in the header's
+    order.  Fields are plain Python attributes (``__slots__``); ``pack()`` writes all of them with one ``struct.pack_into``
+    (a ctypes.Structure costs ~0.4 us per field assignment — 30 us per frame for this block)."""
+    __slots__ = _FRAME_PTRS + _FRAME_INTS + _FRAME_FLOATS + ("_buf", "_addr")
+    _FMT = struct.Struct("<%dQ%di%df" % (len(_FRAME_PTRS), len(_FRAME_INTS), len(_FRAME_FLOATS)))
+
+    def __init__(self):
+        for n in _FRAME_PTRS + _FRAME_INTS:
+            setattr(self, n, 0)
+        for n in _FRAME_FLOATS:
+            setattr(self, n, 0.0)
+        self._buf = ctypes.create_string_buffer(self._FMT.size + 8)
+        self._addr = ctypes.addressof(self._buf)
+
+    def pack(self):
+        g = self.__getattribute__
+        self._FMT.pack_into(self._buf, 0, *[g(n) or 0 for n in _FRAME_PTRS], *[int(g(n)) for n in _FRAME_INTS],
+                            *[float(g(n)) for n in _FRAME_FLOATS])
+        return self._addr
+
+
+def track_frame(args, dev):
+    """``smot_track_frame_fwd``: head [+ box-head refinement] + solver + masked template extraction of ONE tracking frame
+    enqueued by one call (``args``: a filled ``FrameArgs``).  Launch only."""
+    lib = _lib or load_library()
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+    try:
+        rc = lib.smot_track_frame_fwd(args.pack(), _stream(dev))
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
+    if rc:
+        _check(rc, "track_frame")
 
 
 def track_solve_max_boxes():

@@ -7,9 +7,10 @@ the whole tracker — head, solver, pool — can run from this repository with O
 reference writes one boolean per track into a device tensor, track_head.py:103-108).
 
 ``TrackingLoop`` is the detector-agnostic frame step: FPN features + this frame's detections in, tracked boxes out.
-Per frame it enqueues the head (3 launches), the one-launch solver and the masked template extraction of the rows the
-solver leaves active, then synchronises once on the solver's record (``_step_lean``; the general path covers other
-solvers, CPU tensors and a ``refine_tracks`` callable).  The box-head refinement of the propagated boxes
+Per frame it enqueues the head (3 launches), [the box-head refinement of the propagated boxes (8 launches),] the
+one-launch solver and the masked template extraction of the rows the solver leaves active (``_step_lean``; opt-in
+``_step_native``: the same sequence behind ONE library call, ``smot_track_frame_fwd``; the general path covers other
+solvers, CPU tensors and any ``refine_tracks`` callable), then synchronises once on the solver's record.  The box-head refinement of the propagated boxes
 (``_refine_tracks``, roi_heads.py:60-84) belongs to the detector: ``siammot_amd.box_refine.RefineTracks`` wraps any
 box head with the reference's call signature.
 """
@@ -168,6 +169,13 @@ class TrackingLoop(torch.nn.Module):
         act_boxes = ab.view(M, 4)
         pre = emm.extract_cache_rows(features, act_boxes, state[4:5])              # runs while the host wakes up
         ring.wait(rec_host)                                                        # the frame's one synchronisation
+        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre)
+
+    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre):
+        """After the record arrived: mirror the pool, slice the outputs, build the next track memory."""
+        emm, pool = self.track.tracker, self.solver.track_pool
+        ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
+        act_boxes = ab.view(M, 4)
         rec = rec_host.numpy()[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
         pool._mirror(rec, M)
@@ -195,9 +203,153 @@ class TrackingLoop(torch.nn.Module):
         self.track_memory = memory
         return out
 
+    # ---- the same frame behind ONE library call ------------------------------------------------------------------------
+    def _native_ok(self, detections):
+        """``smot_track_frame_fwd`` applies: the one-launch path's conditions, the 15x15 template pooler's masked kernel
+        and — with refinement — a box head whose whole chain fits ``smot_box_refine_fwd``."""
+        if not self.__dict__.get("native_frame", False):
+            return False              # opt-in (``loop.native_frame = True``): see _step_native
+        emm = self.track.tracker
+        fz = emm.feature_extractor.pooler_z
+        if not (emm.rz == 15 and fz.sampling_ratio == 2):
+            return False
+        mem = self.track_memory
+        n_trk = len(mem[2][0]) if mem is not None and mem[0].numel() > 0 else 0
+        if self.refine_tracks is not None and n_trk > 0:
+            box = getattr(self.refine_tracks, "box", None)
+            ok = getattr(box, "one_call_ok", None)
+            if ok is None or not ok(n_trk):
+                return False
+        return True
+
+    def _native_state(self, dev):
+        """The argument block of ``smot_track_frame_fwd`` with everything that does not change from frame to frame."""
+        st = self.__dict__.get("_native")
+        if st is not None and st[1] == dev:
+            return st[0]
+        emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
+        tu = emm.track_utils
+        a = ops.FrameArgs()
+        fe, pr = emm.feature_extractor.pooler_x, emm.predictor
+        a.rx, a.rz, a.sampling_ratio = emm.rx, emm.rz, fe.sampling_ratio
+        a.gn_groups, a.gn_eps, a.up = pr.gn_groups, pr.gn_eps, ops.UP_SCALE
+        a.use_centerness = 1 if emm.use_centerness else 0
+        a.pad_pixels, a.one_minus_sigma, a.sigma = emm.pad_pixels, 1 - emm.sigma, emm.sigma
+        a.track_thresh, a.start_thresh, a.resume_thresh = solver.track_thresh, solver.start_thresh, solver.resume_track_thresh
+        a.nms_thresh, a.max_dormant_frames, a.pool_capacity = solver.NMS_THRESH, pool._max_dormant_frames, pool.DEVICE_CAPACITY
+        a.search_expansion, a.min_search_wh = tu.search_expansion, tu.min_search_wh
+        self.__dict__["_native"] = (a, dev)
+        return a
+
+    def _step_native(self, features, detections):
+        """``_step_lean`` with the frame's 5 (13 with refinement) launches behind one binding call: same kernels, same
+        arguments, same single synchronisation.  Host time to enqueue a frame with refinement: 43 us instead of 110
+        (measure/debug/loop_host_split.py) — but a frame is a serial chain (host work before the first launch -> GPU
+        chain -> record -> host bookkeeping) and ``_step_lean`` already enqueues its later launches WHILE the head runs,
+        whereas this form prepares every argument before its one call, so the first kernel starts ~20 us later: 0.165
+        vs 0.14 ms per frame without refinement, 0.23 vs 0.19 with.  Kept opt-in (``loop.native_frame = True``) for hosts
+        where Python time is scarcer than it is on the benchmark box; covered by the closed-loop tests."""
+        emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
+        dev = detections.bbox.device
+        a = self._native_state(dev)
+        # thresholds may be changed between frames (bench.py does): cheap to refresh
+        a.track_thresh, a.start_thresh, a.resume_thresh = solver.track_thresh, solver.start_thresh, solver.resume_track_thresh
+        fe = emm.feature_extractor.pooler_x
+        g = ops._geometry(features, tuple(fe.scales), emm.pad_pixels, dev)
+        C = g.C
+        a.feats, a.heights, a.widths, a.pad_cells, a.scales, a.num_levels, a.C = g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, C
+        mem = self.track_memory
+        n_trk = 0
+        tf = ti = None
+        keep = []                                   # tensors that must outlive the call's argument block
+        if mem is None:
+            pool.reset()                                                           # track_head.py:39-40
+        elif mem[0].numel() > 0:
+            z, sr, tb = mem
+            tb0 = tb[0]
+            n_trk = len(tb0)
+            tbb, srb = ops._chk(tb0.bbox, "template boxes", (n_trk, 4)), ops._chk(sr[0].bbox, "sr", (n_trk, 4))
+            zc = ops._chk(z, "template_features", (n_trk, C, emm.rz, emm.rz))
+            ids_t, lab_t = tb0.get_field("ids"), tb0.get_field("labels")
+            if not (ids_t.is_contiguous() and lab_t.is_contiguous() and ids_t.dtype is torch.int64 and lab_t.dtype is torch.int64):
+                ids_t, lab_t = ids_t.to(torch.int64).contiguous(), lab_t.to(torch.int64).contiguous()
+            keep += [tbb, srb, zc, ids_t, lab_t]
+            a.tpl_boxes, a.sr, a.templates = tbb.data_ptr(), srb.data_ptr(), zc.data_ptr()
+            a.trk_ids, a.trk_labels = ids_t.data_ptr(), lab_t.data_ptr()
+            blk = ops._param_block(emm.predictor.param_dict())
+            a.predictor_params = blk.a_pp
+            a.hann = ops.hann_window((emm.rx - emm.rz + 1) * ops.UP_SCALE, dev).data_ptr()
+            lib = ops.load_library()
+            a.head_ws = ops._workspace(dev, lib.smot_emm_track_ws_floats(n_trk, C, emm.rx, emm.rz), ops._stream(dev).value).data_ptr()
+            cw, ch = (0.0, 0.0) if emm.amodal else (float(tb0.size[0]), float(tb0.size[1]))
+            a.clip_w, a.clip_h = cw, ch
+            tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
+            p = tf.data_ptr()
+            a.trk_boxes, a.trk_conf = p, p + 16 * n_trk
+            a.ref_boxes, a.ref_scores = p + 20 * n_trk, p + 36 * n_trk
+            keep.append(tf)
+            a.refine = 0
+            if self.refine_tracks is not None:
+                box = self.refine_tracks.box
+                fx, pp_, cs, bp = box.feature_extractor, box.post_processor, box.predictor.cls_score, box.predictor.bbox_pred
+                a.refine, a.tracktor = 1, 1 if self.refine_tracks.tracktor else 0
+                a.fc6_w, a.fc6_b, a.fc7_w, a.fc7_b = (fx.fc6.weight.data_ptr(), fx.fc6.bias.data_ptr(),
+                                                      fx.fc7.weight.data_ptr(), fx.fc7.bias.data_ptr())
+                a.cls_w, a.cls_b, a.reg_w, a.reg_b = cs.weight.data_ptr(), cs.bias.data_ptr(), bp.weight.data_ptr(), bp.bias.data_ptr()
+                a.box_pooled, a.box_sampling_ratio = fx.pooler.output_size[0], fx.pooler.sampling_ratio
+                a.dim6, a.dim7, a.num_classes, a.reg_classes = fx.fc6.out_features, fx.fc7.out_features, cs.out_features, bp.out_features // 4
+                bc = pp_.box_coder
+                a.box_wx, a.box_wy, a.box_ww, a.box_wh = bc.weights
+                a.box_xform_clip = bc.bbox_xform_clip
+                if pp_.amodal_inference:
+                    a.clip_w = a.clip_h = 0.0       # (head and box head share the flag in the reference's cfg: INPUT.AMODAL)
+                need = int(lib.smot_box_refine_ws_floats(n_trk, C, a.box_pooled, a.dim6, a.dim7, a.num_classes, a.reg_classes))
+                a.refine_ws = ops._workspace(dev, need, ("refine", ops._stream(dev).value)).data_ptr()
+                ti = torch.empty((2 * n_trk,), dtype=torch.int64, device=dev)
+                a.ref_ids, a.ref_labels = ti.data_ptr(), ti.data_ptr() + 8 * n_trk
+                keep.append(ti)
+        a.n_trk = n_trk
+        seg = solver._segment(detections)
+        n_det = 0
+        if seg is not None:
+            db, dsc, did, dlab = seg
+            n_det = db.shape[0]
+            a.det_boxes, a.det_scores, a.det_ids = db.data_ptr(), dsc.data_ptr(), did.data_ptr()
+            a.det_labels = dlab.data_ptr() if dlab is not None else None
+            keep += [db, dsc, did, dlab]
+        a.n_det = n_det
+        M = n_det + n_trk
+        state = pool.device_state(dev)
+        ring = pool.host_record_ring(dev)
+        fbuf = torch.empty((10 * M,), dtype=torch.float32, device=dev)
+        ibuf = torch.empty((4 * M,), dtype=torch.int64, device=dev)
+        templates = torch.empty((M, C, emm.rz, emm.rz), dtype=torch.float32, device=dev)
+        sr_next = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        rec_host = ring.next()
+        fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
+        a.pool_state = state.data_ptr()
+        a.out_boxes, a.act_boxes, a.out_scores, a.act_scores = fp, fp + 16 * M, fp + 32 * M, fp + 36 * M
+        a.out_ids, a.out_labels, a.act_ids, a.act_labels = ip, ip + 8 * M, ip + 16 * M, ip + 24 * M
+        a.record = rec_host.data_ptr()
+        a.next_templates, a.next_sr = templates.data_ptr(), sr_next.data_ptr()
+        ops.track_frame(a, dev)
+        ring.record_event()
+        if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
+            hook = emm.__dict__.get("raw_output_hook")
+            if hook is not None:
+                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * n_trk:5 * n_trk])
+            if a.refine:
+                hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
+                if hook is not None:
+                    hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
+        ring.wait(rec_host)                                                        # the frame's one synchronisation
+        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next))
+
     @torch.no_grad()
     def forward(self, features, detections):
         if self._lean_ok(detections):
+            if self._native_ok(detections):
+                return self._step_native(features, detections)
             return self._step_lean(features, detections)
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38
         fast = getattr(self.solver, "_device_path", None)

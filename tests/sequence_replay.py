@@ -98,8 +98,9 @@ FLIP_MARGIN = 3e-6     # an arg-max of the reference whose best and second-best 
 
 
 def probe_tracker(emm):
-    """Record the raw output of the head (before refinement / solver) of every frame: wraps ``forward`` and
-    ``track_raw`` of the instance.  Returns a dict whose ``last`` entry is ``(boxes, scores)`` or None."""
+    """Record the raw output of the head (before refinement / solver) of every frame: wraps ``forward`` of the
+    instance and sets its ``raw_output_hook`` (called by ``track_raw`` and by the one-call frame).  Returns a dict whose
+    ``last`` entry is ``(boxes, scores)`` or None."""
     box = {"last": None}
     fwd = emm.forward
 
@@ -108,20 +109,17 @@ def probe_tracker(emm):
         box["last"] = (out[1][0].bbox.clone(), out[1][0].get_field("scores").clone())   # the solver bands scores in place
         return out
     emm.forward = forward
-    raw = getattr(emm, "track_raw", None)
-    if raw is not None:
-        def track_raw(*a, **k):
-            bb, conf = raw(*a, **k)
-            box["last"] = (bb.clone(), conf.clone())
-            return bb, conf
-        emm.track_raw = track_raw
+
+    def hook(bb, conf):
+        box["last"] = (bb.clone(), conf.clone())
+    emm.raw_output_hook = hook
     return box
 
 
 def probe_box_head(refine):
     """Record what the box head returns for the propagated tracks in every frame: wraps ``forward`` of
-    ``RefineTracks.box`` (boxes, box-head scores, ids) and, when it has one, ``refine_raw`` — the device-only form the
-    one-launch path calls (boxes, None, ids: its scores are averaged already)."""
+    ``RefineTracks.box`` (boxes, box-head scores, ids) and sets its ``raw_output_hook`` — called by the device-only forms
+    (boxes, None, ids: their scores are averaged already)."""
     rec = {"last": None}
     head = refine.box
     fwd = head.forward
@@ -131,13 +129,10 @@ def probe_box_head(refine):
         rec["last"] = (out[1][0].bbox.clone(), out[1][0].get_field("scores").clone(), out[1][0].get_field("ids").clone())
         return out
     head.forward = forward
-    raw = getattr(head, "refine_raw", None)
-    if raw is not None:
-        def refine_raw(*a, **k):
-            out = raw(*a, **k)
-            rec["last"] = (out[0].clone(), None, out[2].clone())
-            return out
-        head.refine_raw = refine_raw
+
+    def hook(bb, scores, ids, labels):
+        rec["last"] = (bb.clone(), None, ids.clone())
+    head.raw_output_hook = hook
     return rec
 
 
@@ -181,6 +176,8 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
         if probe is not None and has_trk:
             assert probe["last"] is not None, "the head did not run: " + ctx
             rb, rs = probe["last"][0].cpu().numpy(), probe["last"][1].cpu().numpy()
+            rs = np.where(rs > 1.0, rs - np.floor(rs), rs)      # (the one-call frame's hook sees the score buffer after the
+                                                                # solver banded it in place: + 1 per band)
             gb, gs, gid = golden[p + "trk_boxes"], golden[p + "trk_scores"], golden[p + "trk_ids"]
             assert rb.shape == gb.shape, "tracked rows %s vs %s: %s" % (rb.shape, gb.shape, ctx)
             err = np.abs(rb - gb).max(axis=1)

@@ -89,21 +89,24 @@ def _gpu_loop(name, lean):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("refine", False), ("refine", True)])
+@pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("plain", "python"), ("refine", False),
+                                       ("refine", True), ("refine", "python")])
 def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
-    """The real head in the loop, on the device: (i) general path, (ii) lean one-launch path, (iii) refinement on
-    (general and lean).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
+    """The real head in the loop, on the device: (i) general path, (ii) one-launch path behind ONE library call
+    (smot_track_frame_fwd), ("python") the same sequence composed in Python, (iii) refinement on (all three).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
     may sit one arg-max cell away only where the reference's own margin is below SR.FLIP_MARGIN (reported)."""
     golden = SR.load_golden(name)
     inp, emm, loop = _gpu_loop(name, lean)
     taken = {"lean": 0}
     if lean:
-        step = loop._step_lean
+        which = "_step_lean" if lean == "python" else "_step_native"
+        loop.native_frame = lean != "python"            # (the one-call frame is opt-in)
+        step = getattr(loop, which)
 
         def counted(*a, **k):
             taken["lean"] += 1
             return step(*a, **k)
-        loop._step_lean = counted
+        setattr(loop, which, counted)
     stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm),
                       box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
     print("closed loop %s lean=%s: %s" % (name, lean, stats))

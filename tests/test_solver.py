@@ -366,7 +366,8 @@ def test_one_launch_solver_edge_cases():
 
 
 @pytest.mark.gpu
-def test_lean_step_equals_general_path():
+@pytest.mark.parametrize("native", [True, False])
+def test_lean_step_equals_general_path(native):
     """TrackingLoop's lean per-frame step (raw tensors, masked template extraction before the synchronisation, lazy
     cache) against the general path (TrackHead / EMM modules, BoxLists, eager cache) on the same sequence with the
     real HIP head: outputs, track memory and pool must be identical frame by frame — including frames in which
@@ -388,8 +389,10 @@ def test_lean_step_equals_general_path():
     loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
     loops[1]._lean_ok = lambda d: False                     # general path
     lean_frames = []
-    real = loops[0]._step_lean
-    loops[0]._step_lean = lambda f, d: (lean_frames.append(1), real(f, d))[1]
+    loops[0].native_frame = native              # one library call per frame (smot_track_frame_fwd) / composed in Python
+    which = "_step_native" if native else "_step_lean"
+    real = getattr(loops[0], which)
+    setattr(loops[0], which, lambda f, d: (lean_frames.append(1), real(f, d))[1])
     shapes = gi.feature_shapes((1280, 704), 32)
     rs_f = np.random.RandomState(9)
     rs = [np.random.RandomState(5), np.random.RandomState(5)]
