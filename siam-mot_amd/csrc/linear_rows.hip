@@ -6,12 +6,13 @@
 // (hipBLASLt through torch) runs fc6 (K = 6272, N = 1024: 25.7 MB of weights) on 128 workgroups in 20 us; the layer is
 // WEIGHT STREAMING — every weight is used M times — so the job is to pull W through all 256 CUs at HBM speed.
 //
-//   * split-K: workgroup = (64 output neurons, one K slice), grid chosen for >= 2 workgroups per CU; four waves, each
-//     a 16-neuron tile; per step of 64 k a lane loads four float4 of its neuron's weights (256 contiguous bytes per
-//     neuron per step: whole lines) and the workgroup stages the x slice [rows][64 k] in LDS once for all four waves;
+//   * split-K: workgroup = (64 output neurons, one K slice), grid chosen for about two workgroups per CU; four waves,
+//     each a 16-neuron tile; per step of 64 k a lane loads four float4 of its neuron's weights (256 contiguous bytes
+//     per neuron per step: whole lines) and the workgroup stages the x slice [rows][64 k] in LDS once for all four
+//     waves; the loads of up to four steps (the usual slice) are all issued before the first use;
 //   * the products run on v_mfma_f32_16x16x4_f32 (exact fp32 multiply-add, D[neuron][row]): A = weights, B = x^T read
 //     back from LDS as float4 (element j of a lane's float4 is the operand of the j-th MFMA, for A and B alike, so no
-//     shuffles); the next step's loads are in flight while the current one multiplies;
+//     shuffles);
 //   * the partial sums of the K slices are written out and a second, tiny launch adds them in slice order (+ bias,
 //     ReLU): deterministic, and the kernel boundary is the cross-XCD visibility point (no atomics).
 // Rows: up to 64 (1..4 row tiles of 16); K must be a multiple of 4 (the wrapper falls back to the library otherwise).
@@ -30,7 +31,11 @@ linear_rows_partial_kernel(const float* __restrict__ x, int M, int K, const floa
                            const float* __restrict__ W2, int N1, int kslice, float* __restrict__ part) {
     // (W2 != nullptr: two layers on the same input side by side — neurons [0, N1) are rows of W, [N1, N) rows of W2:
     // cls_score | bbox_pred in one launch)
-    __shared__ __attribute__((aligned(16))) float xs[2][MT * 16][LR_XS];
+    // A workgroup lives for a few microseconds, so its loads must not be a chain of round trips: the slice is walked
+    // in "quads" of QS steps and ALL loads of a quad — QS x 4 float4 of weights per lane, the x chunks of its steps —
+    // are issued before the first use (one HBM latency per quad; the usual slice is one quad).
+    constexpr int QS = MT <= 2 ? 4 : 2;          // steps per quad (LDS: QS x MT*16 x 68 floats)
+    __shared__ __attribute__((aligned(16))) float xs[QS][MT * 16][LR_XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = blockIdx.x, s = blockIdx.y;
     const int k_begin = s * kslice, k_end = min(K, k_begin + kslice);
@@ -44,54 +49,61 @@ linear_rows_partial_kernel(const float* __restrict__ x, int M, int K, const floa
     f32x4 acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float4 wreg[4], xreg[MT];
-    auto fetch = [&](int k0) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int k0 = k_begin; k0 < k_end; k0 += QS * LR_KS) {
+        // every load is UNCONDITIONAL at a clamped in-bounds address (a predicated load is a branch with its own wait:
+        // eight serial round trips); out-of-range elements are zeroed in registers afterwards
+        float4 xreg[QS][MT], wreg[QS][4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int k = k0 + 16 * h + 4 * kq;
-            wreg[h] = (n_ok && k < k_end) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int u = 0; u < QS; ++u)
 #pragma unroll
-        for (int q = 0; q < MT; ++q) {
-            const int r = xr + 16 * q, k = k0 + xk;
-            xreg[q] = (r < M && k < k_end) ? *reinterpret_cast<const float4*>(x + (size_t)r * K + k)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto stash = [&](int buf) {
+            for (int q = 0; q < MT; ++q) {
+                const int r = min(xr + 16 * q, M - 1), k = min(k0 + u * LR_KS + xk, K - 4);
+                xreg[u][q] = *reinterpret_cast<const float4*>(x + (size_t)r * K + k);
+            }
 #pragma unroll
-        for (int q = 0; q < MT; ++q) *reinterpret_cast<float4*>(&xs[buf][xr + 16 * q][xk]) = xreg[q];
-    };
-    const int nsteps = (k_end - k_begin + LR_KS - 1) / LR_KS;
-    if (nsteps > 0) {
-        fetch(k_begin);
-        float4 wcur[4] = {wreg[0], wreg[1], wreg[2], wreg[3]};
-        stash(0);
-        __syncthreads();
-        for (int st = 0; st < nsteps; ++st) {
-            const int buf = st & 1;
-            if (st + 1 < nsteps) fetch(k_begin + (st + 1) * LR_KS);           // next step's loads in flight
+        for (int u = 0; u < QS; ++u)
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
-                const float a4[4] = {wcur[h].x, wcur[h].y, wcur[h].z, wcur[h].w};
-                float4 b4[MT];
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    b4[t] = *reinterpret_cast<const float4*>(&xs[buf][t * 16 + (lane & 15)][16 * h + 4 * kq]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < MT; ++t) {
-                        const float b = j == 0 ? b4[t].x : (j == 1 ? b4[t].y : (j == 2 ? b4[t].z : b4[t].w));
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b, acc[t], 0, 0, 0);
-                    }
+                const int k = min(k0 + u * LR_KS + 16 * h + 4 * kq, K - 4);
+                wreg[u][h] = *reinterpret_cast<const float4*>(wrow + k);
             }
-            if (st + 1 < nsteps) {
-                stash(buf ^ 1);                  // the other buffer: its readers passed the barrier of the previous step
+        __builtin_amdgcn_sched_barrier(0);               // all loads of the quad are in flight before anything waits
 #pragma unroll
-                for (int h = 0; h < 4; ++h) wcur[h] = wreg[h];
+        for (int u = 0; u < QS; ++u) {
+#pragma unroll
+            for (int q = 0; q < MT; ++q)
+                if (!(xr + 16 * q < M && k0 + u * LR_KS + xk < k_end)) xreg[u][q] = zero4;
+#pragma unroll
+            for (int h = 0; h < 4; ++h)
+                if (!(n_ok && k0 + u * LR_KS + 16 * h + 4 * kq < k_end)) wreg[u][h] = zero4;
+        }
+        if (k0 != k_begin) __syncthreads();              // the previous quad's readers are done with xs
+#pragma unroll
+        for (int u = 0; u < QS; ++u)
+#pragma unroll
+            for (int q = 0; q < MT; ++q) *reinterpret_cast<float4*>(&xs[u][xr + 16 * q][xk]) = xreg[u][q];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+            if (k0 + u * LR_KS < k_end) {                    // workgroup-uniform
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const float a4[4] = {wreg[u][h].x, wreg[u][h].y, wreg[u][h].z, wreg[u][h].w};
+                    float4 b4[MT];
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        b4[t] = *reinterpret_cast<const float4*>(&xs[u][t * 16 + (lane & 15)][16 * h + 4 * kq]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t) {
+                            const float b = j == 0 ? b4[t].x : (j == 1 ? b4[t].y : (j == 2 ? b4[t].z : b4[t].w));
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b, acc[t], 0, 0, 0);
+                        }
+                }
             }
-            __syncthreads();
         }
     }
     // D[neuron = 4 * (lane >> 4) + r][row = lane & 15 (+ 16 t)] -> part[s][nb][row][neuron]
@@ -115,12 +127,13 @@ linear_rows_reduce_kernel(const float* __restrict__ part, int S, int nblk, int r
     const float* __restrict__ p = part + ((size_t)nb * rows_pad + m) * LR_NB + nl;
     const size_t stride = (size_t)nblk * rows_pad * LR_NB;         // between K slices
     float v = 0.0f;
-    for (int s0 = 0; s0 < S; s0 += 8) {                            // eight independent loads, then the ordered adds
-        float t[8];
+    for (int s0 = 0; s0 < S; s0 += 32) {                           // 32 independent loads (one round trip), ordered adds
+        float t[32];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = (s0 + q < S) ? p[(size_t)(s0 + q) * stride] : 0.0f;
+        for (int q = 0; q < 32; ++q) t[q] = p[(size_t)min(s0 + q, S - 1) * stride];     // unconditional (clamped): see above
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < 8; ++q)
+        for (int q = 0; q < 32; ++q)
             if (s0 + q < S) v = add_rn(v, t[q]);
     }
     const float* __restrict__ bsel = (bias2 != nullptr && n >= N1) ? bias2 + (n - N1) : (bias != nullptr ? bias + n : nullptr);
