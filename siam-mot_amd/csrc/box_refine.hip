@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(BR_MAXN) box_refine_post_kernel(BoxRefineArgs 
     float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
     long long id = -1;
     if (i < N) {
-        lab = (int)A.labels[i];
+        lab = min(max((int)A.labels[i], 0), A.K - 1);        // (memory safety: a label outside [0, K) would index past the row)
         id = A.ids[i];
         const float* row = A.logits + (size_t)i * A.ldo;
         // F.softmax(class_logits, -1): max, exp of the difference, sum in class order, divide

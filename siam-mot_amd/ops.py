@@ -932,9 +932,6 @@ def box_refine_post(head_out, num_classes, reg_classes, boxes, labels, ids, trac
     return out_boxes, out_scores, out_ids, out_labels
 
 
-_lin_ws = {}
-
-
 def box_refine(features, scales, pooled, sampling_ratio, boxes, labels, ids, track_conf, layers, weights, xform_clip,
                clip_wh, tracktor=False):
     """``smot_box_refine_fwd``: 7x7 pooler -> fc6 -> fc7 -> cls_score | bbox_pred -> post-processing of N <= 64
@@ -955,9 +952,7 @@ def box_refine(features, scales, pooled, sampling_ratio, boxes, labels, ids, tra
     if w6.shape[1] != C * pooled * pooled or w7.shape[1] != w6.shape[0] or wc.shape[1] != w7.shape[0] or wr.shape[1] != w7.shape[0]:
         raise RuntimeError("siammot_amd.box_refine: layer shapes do not chain")
     need = int(lib.smot_box_refine_ws_floats(N, C, int(pooled), w6.shape[0], w7.shape[0], K, KR))
-    ws = _lin_ws.get(dev)
-    if ws is None or ws.numel() < need:
-        ws = _lin_ws[dev] = torch.empty((max(need, 1 << 20),), dtype=_F32, device=dev)
+    ws = _workspace(dev, need, ("box_refine", _stream(dev).value))        # per (device, stream): streams run concurrently
     out_boxes = torch.empty((N, 4), dtype=_F32, device=dev)
     out_scores = torch.empty((N,), dtype=_F32, device=dev)
     out_ids = torch.empty((N,), dtype=torch.int64, device=dev)
@@ -997,9 +992,7 @@ def linear_rows(x, weight, bias=None, relu=False, out=None):
     if y.stride(1) != 1 or y.shape[0] != M or y.shape[1] < N:
         raise RuntimeError("siammot_amd.linear_rows: out must be a row-major [M, >=N] view")
     need = int(lib.smot_linear_rows_ws_floats(M, K, N))
-    ws = _lin_ws.get(x.device)
-    if ws is None or ws.numel() < need:
-        ws = _lin_ws[x.device] = torch.empty((max(need, 1 << 20),), dtype=_F32, device=x.device)
+    ws = _workspace(x.device, need, ("linear_rows", _stream(x.device).value))
     with _Launch(x, weight, y) as ln:
         rc = lib.smot_linear_rows_fwd(_ptr(x), M, K, _ptr(weight), _ptr(bias), N, int(bool(relu)), _ptr(ws), _ptr(y),
                                       y.stride(0), ln.stream)
