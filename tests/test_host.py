@@ -247,3 +247,37 @@ def test_wait_host_record_polls_then_falls_back_to_the_event():
     never = torch.zeros(16, dtype=torch.int32)
     with pytest.raises(RuntimeError):
         ops.wait_host_record(never, Ev(never, 0), spins=50)
+
+
+def test_frame_args_buffer_matches_the_header_struct():
+    """``ops.FrameArgs`` packs ``smot_frame_args`` by hand (one struct.pack_into per frame): its field order, the
+    pointers-then-ints-then-floats grouping and the total size must be exactly the C struct of include/smot_emm.h — a
+    drift would corrupt every argument behind it without any error."""
+    import re
+    import siammot_amd.ops as ops
+    src = open(os.path.join(ROOT, "include", "smot_emm.h")).read()
+    body = src[src.index("typedef struct smot_frame_args {"):src.index("} smot_frame_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        kind = "ptr" if "*" in decl else ("int" if re.match(r"int\b", decl) else ("float" if re.match(r"float\b", decl) else None))
+        assert kind is not None, decl
+        names = re.sub(r"^(const\s+)?(float|int64_t|int)\s*(const\s*)?\**\s*(const\s*)?\**", "", decl) if kind == "ptr" else decl.split(None, 1)[1]
+        for n in names.split(","):
+            fields.append((n.strip().lstrip("*").strip(), kind))
+    assert [n for n, k in fields if k == "ptr"] == list(ops._FRAME_PTRS)
+    assert [n for n, k in fields if k == "int"] == list(ops._FRAME_INTS)
+    assert [n for n, k in fields if k == "float"] == list(ops._FRAME_FLOATS)
+    kinds = [k for _, k in fields]
+    assert kinds == sorted(kinds, key={"ptr": 0, "int": 1, "float": 2}.get)         # grouped: no padding inside
+    assert ops.FrameArgs._FMT.size == 8 * len(ops._FRAME_PTRS) + 4 * (len(ops._FRAME_INTS) + len(ops._FRAME_FLOATS))
+    a = ops.FrameArgs()
+    a.n_trk, a.clip_w, a.det_labels = 7, 1280.0, None
+    a.pack()
+    import struct
+    vals = ops.FrameArgs._FMT.unpack_from(a._buf, 0)
+    assert vals[len(ops._FRAME_PTRS) + ops._FRAME_INTS.index("n_trk")] == 7
+    assert vals[len(ops._FRAME_PTRS) + len(ops._FRAME_INTS) + ops._FRAME_FLOATS.index("clip_w")] == 1280.0
