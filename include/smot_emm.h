@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 7
+#define SMOT_ABI_VERSION 8
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -48,6 +48,12 @@ int smot_build_info(void);
 /* Measurement library only: set one A/B or ablation switch by its SMOT_* name (csrc/knobs.h), value spelled as
  * the environment variable would be.  The environment itself is read once, when the library is loaded. */
 int smot_debug_set_knob(const char* name, const char* value);
+/* Measurement library only: smot_sr_xcorr_fused_fwd (Rx = 30, Rz = 15, sampling_ratio = 2) WITH an order hint (see
+ * smot_emm_track_fwd below), for phase traces and A/B runs of that kernel alone. */
+int smot_debug_sr_xcorr_fused_hint_fwd(const float* const* feats, const int* heights, const int* widths,
+                                       const int* pad_cells, const float* scales, int num_levels, int C,
+                                       const float* boxes, const float* sr, const float* templates, int N,
+                                       float* resp, const float* order_hint, smot_stream_t stream);
 #endif
 
 /* Message describing the last non-zero return on the calling thread ("" if none). */
@@ -283,7 +289,23 @@ int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* m
  *
  * smot_emm_extract_cache_fwd replaces EMM.extract_cache (EMM/track_core.py:81-98): template pooling
  *   on the un-padded maps (boxes pick level and roi) + search regions for the next frame.
+ *
+ * order_hint (optional, may be NULL everywhere): a scheduling side channel between the two halves, no part of the
+ *   reference's interface and without influence on any result.  The pooling + correlation kernel of
+ *   smot_emm_track_fwd balances the chip by handing its workgroups the rois in cost order (wide search windows
+ *   first); ranking them costs every workgroup ~3 us of start-up latency.  The extraction that CREATES those rois
+ *   can rank them once: given a buffer of smot_emm_order_hint_floats(N, rz, sampling_ratio) floats (32-byte
+ *   aligned; 0 = this shape / count writes no hint: pass NULL), smot_emm_extract_cache[_masked]_fwd writes
+ *   SMOT_HINT_FLOATS floats per roi — {search region x1,y1,x2,y2, FPN level (int32 bits), roi index (int32 bits),
+ *   0, 0}, entry k = the roi of rank k — and smot_emm_track_fwd given that buffer TOGETHER WITH exactly the `boxes`
+ *   and `sr` of the same extraction (same N, same row order, same maps geometry) reads one entry per workgroup
+ *   instead of ranking.  A hint from any other boxes gives wrong results (the entries' search regions are used as
+ *   they stand; indices are clamped, so nothing is read out of range): callers that re-order, merge or edit the
+ *   track memory pass NULL.  For the masked form the hint covers the first *n_valid rows.
  */
+#define SMOT_HINT_FLOATS 8
+long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio);
+
 long long smot_emm_track_ws_floats(int N, int C, int rx, int rz);
 
 int smot_emm_track_fwd(const float* const* feats, const int* heights, const int* widths,
@@ -294,13 +316,14 @@ int smot_emm_track_fwd(const float* const* feats, const int* heights, const int*
                        const float* hann, int up, float pad_pixels,
                        float one_minus_sigma, float sigma, int use_centerness,
                        float clip_w, float clip_h,
-                       float* ws, float* bb, float* conf, int64_t* idx, smot_stream_t stream);
+                       float* ws, float* bb, float* conf, int64_t* idx, const float* order_hint,
+                       smot_stream_t stream);
 
 int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,
                                const float* scales, int num_levels, int C,
                                const float* boxes, int N, int rz, int sampling_ratio,
                                float pad_pixels, float search_expansion, float min_search_wh,
-                               float* templates, float* sr, smot_stream_t stream);
+                               float* templates, float* sr, float* order_hint, smot_stream_t stream);
 
 /* EMM.extract_cache over a CAPACITY of boxes of which the first *n_valid (device int32, e.g. &record[1] of
  * smot_track_solve_fwd) are real: rows >= *n_valid are skipped on the device, their outputs stay unwritten.  Lets
@@ -310,7 +333,8 @@ int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heig
                                       const float* scales, int num_levels, int C,
                                       const float* boxes, int capacity, const int* n_valid, int rz,
                                       int sampling_ratio, float pad_pixels, float search_expansion,
-                                      float min_search_wh, float* templates, float* sr, smot_stream_t stream);
+                                      float min_search_wh, float* templates, float* sr, float* order_hint,
+                                      smot_stream_t stream);
 
 /*
  * Box-head post-processing of the propagated tracks + the score average of _refine_tracks, one launch, no host sync.
@@ -451,6 +475,7 @@ typedef struct smot_frame_args {
     const float* tpl_boxes;      /* [n_trk,4] */
     const float* sr;             /* [n_trk,4] */
     const float* templates;      /* [n_trk,C,rz,rz] */
+    const float* order_hint;     /* order hint of exactly these rows (smot_emm_track_fwd) or NULL */
     const int64_t* trk_ids;      /* [n_trk] */
     const int64_t* trk_labels;   /* [n_trk] */
     /* head */
@@ -477,6 +502,7 @@ typedef struct smot_frame_args {
     /* next frame's memory (capacity n_det + n_trk rows; the first pool_state[4] are written) */
     float* next_templates;
     float* next_sr;
+    float* next_order_hint;      /* smot_emm_order_hint_floats(n_det + n_trk, rz, sampling_ratio) floats or NULL */
     /* sizes and scalars */
     int num_levels, C, n_trk, n_det;
     int rx, rz, sampling_ratio, gn_groups, up, use_centerness;

@@ -43,7 +43,7 @@ const KnobName kKnobNames[] = {
     {"SMOT_DECODE_SPLIT", &Knobs::decode_split}, {"SMOT_XCORR_VARIANT", &Knobs::xcorr_variant},
     {"SMOT_DECODE_2PASS", &Knobs::decode_two_pass}, {"SMOT_FUSED_GEN", &Knobs::fused_gen},
     {"SMOT_TOWER_OCT", &Knobs::tower_oct},
-    {"SMOT_FUSED_ORDER", &Knobs::fused_order},
+    {"SMOT_FUSED_ORDER", &Knobs::fused_order},   {"SMOT_NO_HINT", &Knobs::no_hint},
     {"SMOT_FUSED_ABL", &Knobs::fused_abl},
     {"SMOT_WINO_ABL", &Knobs::wino_abl},
     {"SMOT_TOWER_ABL", &Knobs::tower_abl},

@@ -22,7 +22,12 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
 unsigned* decode_tickets(float* cand_ws, int N, int Ho);
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
-                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, hipStream_t st);
+                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, float* order_hint,
+                         hipStream_t st);
+int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
+                        const float* scales, int num_levels, int C, const float* boxes, const float* sr,
+                        const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
+                        hipStream_t st);
 }  // namespace smot
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
@@ -41,7 +46,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
                                   float gn_eps, const float* hann, int up, float pad_pixels,
                                   float one_minus_sigma, float sigma, int use_centerness, float clip_w,
                                   float clip_h, float* ws, float* bb, float* conf, int64_t* idx,
-                                  smot_stream_t stream) {
+                                  const float* order_hint, smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && C > 0 && rz > 0 && rx >= rz, "emm_track: bad sizes N=%d C=%d rx=%d rz=%d", N, C, rx, rz);
     if (N == 0) return SMOT_OK;
@@ -57,8 +62,8 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     const bool no_fuse = knobs().no_fuse;             // A/B: measurement library only (constant false otherwise)
     if (rx == 30 && rz == 15 && sampling_ratio == 2 && !no_fuse) {
         // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
-        rc = smot_sr_xcorr_fused_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
-                                     rx, rz, sampling_ratio, resp, nullptr, stream);
+        rc = sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
+                                 nullptr, order_hint, (hipStream_t)stream);
         if (rc) return rc;
     } else {
         rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,
@@ -91,7 +96,8 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
 extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,
                                           const float* scales, int num_levels, int C, const float* boxes, int N,
                                           int rz, int sampling_ratio, float pad_pixels, float search_expansion,
-                                          float min_search_wh, float* templates, float* sr, smot_stream_t stream) {
+                                          float min_search_wh, float* templates, float* sr, float* order_hint,
+                                          smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache: bad sizes");
     if (N == 0) return SMOT_OK;
@@ -100,7 +106,7 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
         const float half_e = (float)((double)search_expansion / 2.0);
         const float two_e = (float)((double)search_expansion * 2.0);
         return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, N, rz, pad_pixels, half_e,
-                                    two_e, min_search_wh, templates, sr, nullptr, (hipStream_t)stream);
+                                    two_e, min_search_wh, templates, sr, nullptr, order_hint, (hipStream_t)stream);
     }
     int zero_pad[SMOT_MAX_LEVELS] = {0};
     int rc = smot_roi_align_levels_fwd(feats, heights, widths, zero_pad, scales, num_levels, C, boxes, boxes, N, rz, rz,
@@ -117,7 +123,8 @@ extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, cons
                                                  const float* scales, int num_levels, int C, const float* boxes,
                                                  int capacity, const int* n_valid, int rz, int sampling_ratio,
                                                  float pad_pixels, float search_expansion, float min_search_wh,
-                                                 float* templates, float* sr, smot_stream_t stream) {
+                                                 float* templates, float* sr, float* order_hint,
+                                                 smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(capacity >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache_masked: bad sizes");
     SMOT_REQUIRE(n_valid != nullptr, "emm_extract_cache_masked: null count pointer");
@@ -130,7 +137,7 @@ extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, cons
     const float half_e = (float)((double)search_expansion / 2.0);
     const float two_e = (float)((double)search_expansion * 2.0);
     return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, capacity, rz, pad_pixels, half_e,
-                                two_e, min_search_wh, templates, sr, n_valid, (hipStream_t)stream);
+                                two_e, min_search_wh, templates, sr, n_valid, order_hint, (hipStream_t)stream);
 }
 
 
@@ -152,7 +159,7 @@ extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stre
                                 a->sr, a->templates, a->n_trk, a->rx, a->rz, a->sampling_ratio, a->predictor_params,
                                 a->gn_groups, a->gn_eps, a->hann, a->up, a->pad_pixels, a->one_minus_sigma, a->sigma,
                                 a->use_centerness, a->clip_w, a->clip_h, a->head_ws, a->trk_boxes, a->trk_conf, nullptr,
-                                stream);
+                                a->order_hint, stream);
         if (rc) return rc;
         trk_boxes = a->trk_boxes;
         trk_scores = a->trk_conf;
@@ -182,5 +189,5 @@ extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stre
     return smot_emm_extract_cache_masked_fwd(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->act_boxes,
                                              a->n_det + a->n_trk, a->pool_state + 4, a->rz, a->sampling_ratio,
                                              a->pad_pixels, a->search_expansion, a->min_search_wh, a->next_templates,
-                                             a->next_sr, stream);
+                                             a->next_sr, a->next_order_hint, stream);
 }

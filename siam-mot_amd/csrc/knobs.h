@@ -28,6 +28,8 @@ struct Knobs {
     int fused_gen = 0;       // SMOT_FUSED_GEN     : 0 = current fused pooling kernel, 2 = round-1 kernel
     int fused_order = 0;     // SMOT_FUSED_ORDER   : workgroup -> roi assignment of the pooling kernels (0 = default,
                              //                      1..3 = cost-sorted forms, 4 = grid order; sr_xcorr.hip fx_assign)
+    int no_hint = 0;         // SMOT_NO_HINT       : 1 = the pooling + correlation kernel ignores the order hint and ranks
+                             //                      its rois itself, 2 = the extraction does not write one either
     int tower_oct = 0;       // SMOT_TOWER_OCT     : 16-channel tiles per Winograd workgroup (0 = default, 1 or 2)
     // timing ablations: WRONG results, measurement builds only
     int fused_abl = 0;       // SMOT_FUSED_ABL

@@ -44,7 +44,12 @@ struct SrOut {
                           // a CAPACITY when the count is still on the device — smot_emm_extract_cache_masked_fwd)
     int order;            // workgroup -> (roi, channel group) assignment: 0 = grid order, 1..3 = cost-sorted forms
                           // (fx_assign below; the measurement library can select any, SMOT_FUSED_ORDER)
+    float* hint_out;      // pool-only kernel: write the cost-sorted roi list of the NEXT frame's search regions here
+                          // (fx_write_hint below; [R] entries of SMOT_HINT_FLOATS floats) or nullptr
+    const float* hint_in; // pooling + correlation kernel: such a list for ITS rois (written by the extraction that made
+                          // them), read instead of ranking the rois again in every workgroup; or nullptr
 };
+constexpr int HINT_FLOATS = SMOT_HINT_FLOATS;     // {search region x1,y1,x2,y2, FPN level, roi index, 0, 0}
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
 // addressing form (one address VGPR per load instead of a 64-bit pair — 120 loads are in flight).
@@ -323,6 +328,74 @@ __device__ __forceinline__ float rl_f(float v, int lane_const) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const));
 }
 
+// update_boxes_in_pad_images + extend_bbox (track_utils.py:62-85,109-135) for one box: the next frame's search region.
+__device__ __forceinline__ float4 search_region_of(float b0, float b1, float b2, float b3, const SrOut& S) {
+    const float bx1 = add_rn(b0, S.pad), by1 = add_rn(b1, S.pad);
+    const float bx2 = add_rn(b2, S.pad), by2 = add_rn(b3, S.pad);
+    const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
+    const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
+    const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
+    return make_float4(sub_rn(bx1, w_ext), sub_rn(by1, h_ext), add_rn(bx2, w_ext), add_rn(by2, h_ext));
+}
+
+// The pooling + correlation kernel of the NEXT frame ranks its rois by cost class in every one of its workgroups
+// (fx_assign below: ~6.5 k cycles at the head of each, two vector-memory round trips on lines all CUs want at once).
+// The extraction that creates those rois knows everything the ranking needs one frame earlier: one wave of one extra
+// workgroup of the template-pooling launch ranks them ONCE and writes the sorted list — entry k = the roi of rank k
+// with its search region and FPN level — so that a consumer workgroup needs one scalar load of its own entry.
+// Same classes and the same order as fx_assign order 1 (class descending, roi ascending); the consumer's results do
+// not depend on it (any permutation of the rois is a valid assignment).
+__device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float* __restrict__ boxes, const SrOut& S,
+                                              int NT, int lane) {
+    if (NT > 256) return;                                      // (the consumer keeps grid order beyond 256 rois)
+    const int nv = (S.n_valid != nullptr) ? min(*S.n_valid, NT) : NT;
+    unsigned long long mask[4][3];
+    int cnt[3] = {0, 0, 0};
+    float4 srb[4];
+    int lv[4], cl[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int t = lane + 64 * p;
+        cl[p] = -1;
+        lv[p] = 0;
+        srb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (64 * p < nv && t < nv) {
+            const float4 b4 = *reinterpret_cast<const float4*>(boxes + (size_t)t * 4);
+            int lvl = 0;
+            if (P.num_levels > 1) lvl = map_level(boxes + (size_t)t * 4, P.k_min, P.k_max);
+            float scale = P.scale[0];
+#pragma unroll
+            for (int l = 1; l < SMOT_MAX_LEVELS; ++l) scale = (lvl == l) ? P.scale[l] : scale;
+            srb[p] = search_region_of(b4.x, b4.y, b4.z, b4.w, S);
+            lv[p] = lvl;
+            const float ww = (srb[p].z - srb[p].x) * scale;                              // window width in cells
+            cl[p] = ww <= 30.0f ? 0 : (ww <= 62.0f ? 1 : 2);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            mask[p][c] = __ballot(cl[p] == c);
+            cnt[c] += __popcll(mask[p][c]);
+        }
+    }
+    const int base[3] = {cnt[2] + cnt[1], cnt[2], 0};
+    int before[3] = {0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (cl[p] >= 0) {
+            const int c = cl[p];
+            const unsigned long long mk = c == 2 ? mask[p][2] : (c == 1 ? mask[p][1] : mask[p][0]);
+            const int bf = c == 2 ? before[2] : (c == 1 ? before[1] : before[0]);
+            const int bs = c == 2 ? base[2] : (c == 1 ? base[1] : base[0]);
+            const int rank = bs + bf + __popcll(mk & ((1ull << lane) - 1ull));
+            float4* o = reinterpret_cast<float4*>(S.hint_out + (size_t)rank * HINT_FLOATS);
+            o[0] = srb[p];
+            o[1] = make_float4(__int_as_float(lv[p]), __int_as_float(lane + 64 * p), 0.f, 0.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) before[c] += __popcll(mask[p][c]);
+    }
+}
+
 // Which (roi, channel group) a workgroup takes.  The grid is (rois, channel groups) and the hardware dispatches
 // workgroups in linear order (x fastest), L and L + 256 onto the same CU while the launch fits the chip; a roi whose
 // window is wider than 32 columns costs about twice a narrow one (two row blocks per plane), so the order in which
@@ -339,14 +412,35 @@ __device__ __forceinline__ float rl_f(float v, int lane_const) {
 // workgroup's own roi loads — a second dependent memory round trip — are then not needed).
 __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __restrict__ sr,
                                           const float* __restrict__ boxes, const int* __restrict__ n_valid, int order,
-                                          int lane, int* n_out, int* cg_out, float4* roi_out, int* lvl_out) {
-    const int NT = gridDim.x, ny = gridDim.y;
-    int n = blockIdx.x, cg = blockIdx.y;
+                                          int by, int ny, const float* __restrict__ hint, int lane, int* n_out,
+                                          int* cg_out, float4* roi_out, int* lvl_out) {
+    // (by, ny): the workgroup's row and the number of rows of the (roi, channel group) grid — blockIdx.y / gridDim.y
+    // less the hint row of an extraction launch
+    const int NT = gridDim.x;
+    int n = blockIdx.x, cg = by;
     *n_out = n;
     *cg_out = cg;
     if (order == 0 || NT > 256 || NT < 2) return false;
+    const int T = NT * ny, L = by * NT + blockIdx.x;
+    if (hint != nullptr && order == 1 && n_valid == nullptr) {
+        // the list was made when the rois were (fx_write_hint): one scalar load of this workgroup's entry
+        const int k = L / ny;
+        *cg_out = L - k * ny;
+        // through the constant address space: a wave-uniform address there is a scalar load (one s_load_dwordx8 per
+        // wave through the scalar cache; as a plain global pointer hipcc issues vector loads — it cannot see that
+        // nothing writes the list during this launch)
+        typedef int v8i_t __attribute__((ext_vector_type(8)));
+        const v8i_t e = *reinterpret_cast<const __attribute__((address_space(4))) v8i_t*>(
+            reinterpret_cast<unsigned long long>(hint) + (unsigned long long)k * (HINT_FLOATS * 4));
+        roi_out->x = __int_as_float(e[0]);
+        roi_out->y = __int_as_float(e[1]);
+        roi_out->z = __int_as_float(e[2]);
+        roi_out->w = __int_as_float(e[3]);
+        *lvl_out = min(max(e[4], 0), P.num_levels - 1);        // (a stale list must not index out of range)
+        *n_out = min(max(e[5], 0), NT - 1);
+        return true;
+    }
     const int nv = (n_valid != nullptr) ? min(*n_valid, NT) : NT;
-    const int T = NT * ny, L = blockIdx.y * NT + blockIdx.x;
     constexpr int SLOTS = 256;                       // CUs: one workgroup each per dispatch round
     int i = L;
     if (order == 2) {
@@ -494,16 +588,28 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // Also measured and dropped for the 33..64-column windows that set the makespan: three 10-row blocks per plane with
     // the next block's row loads issued before the current block's gathers (96 VGPRs, two workgroups per CU):
     // bit-identical, 17.0 instead of 16.75 us at 30 rois, 12.9 instead of 12.3 at 16 (profiles/r02_fused_pipelined_wide.jsonl).
-    const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, lane, &n_assigned, &cg_assigned,
-                                    &roi_assigned, &lvl_assigned);
+    int grid_row = blockIdx.y, grid_rows = gridDim.y;
+    if constexpr (!XCORR) {
+        if (S.hint_out != nullptr) {                 // extraction launch with one extra row in front: the hint writer
+            if (grid_row == 0) {
+                if (blockIdx.x == 0 && wave == 0) fx_write_hint(P, boxes, S, gridDim.x, lane);
+                return;
+            }
+            grid_row -= 1;
+            grid_rows -= 1;
+        }
+    }
+    const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, grid_row, grid_rows,
+                                    XCORR ? S.hint_in : nullptr, lane, &n_assigned, &cg_assigned, &roi_assigned,
+                                    &lvl_assigned);
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
     const int cgrp = __builtin_amdgcn_readfirstlane(cg_assigned);
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
     // (trace rows are indexed by the item, not by the workgroup that happened to take it)
 #define FX_TRACE(SLOT)                                                                      \
     if (S.trace && tid == 0)                                                                \
-        S.trace[((size_t)n * gridDim.y + cgrp) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
-    if (S.trace && tid == 0) S.trace[((size_t)n * gridDim.y + cgrp) * 8 + 0] = t_start;
+        S.trace[((size_t)n * grid_rows + cgrp) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    if (S.trace && tid == 0) S.trace[((size_t)n * grid_rows + cgrp) * 8 + 0] = t_start;
     FX_TRACE(5)                                   // after the assignment
 
     float roi0 = roi_assigned.x, roi1 = roi_assigned.y, roi2 = roi_assigned.z, roi3 = roi_assigned.w;
@@ -520,15 +626,11 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     lvl = __builtin_amdgcn_readfirstlane(lvl);
     if (levels_out != nullptr && cgrp == 0 && tid == 0) levels_out[n] = lvl;
     if (!XCORR && S.sr != nullptr && cgrp == 0 && tid == 0) {
-        const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
-        const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
-        const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
-        const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
-        const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
-        S.sr[n * 4 + 0] = sub_rn(bx1, w_ext);
-        S.sr[n * 4 + 1] = sub_rn(by1, h_ext);
-        S.sr[n * 4 + 2] = add_rn(bx2, w_ext);
-        S.sr[n * 4 + 3] = add_rn(by2, h_ext);
+        const float4 o = search_region_of(roi[0], roi[1], roi[2], roi[3], S);
+        S.sr[n * 4 + 0] = o.x;
+        S.sr[n * 4 + 1] = o.y;
+        S.sr[n * 4 + 2] = o.z;
+        S.sr[n * 4 + 3] = o.w;
     }
     const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
     const float scale = P.scale[lvl];
@@ -862,6 +964,12 @@ static inline int fused_order() {          // SMOT_FUSED_ORDER: 0 = default, 1..
     const int k = knobs().fused_order;
     return k == 0 ? FX_ORDER_DEFAULT : (k == 4 ? 0 : k);
 }
+// An order hint is written / honoured for this many rois (fx_write_hint / fx_assign: one wave ranks up to 256 rois; the
+// list has the default order's form; the measurement library's generation-2 kernel knows nothing of it).
+static inline bool order_hint_rois(int N, bool consumer) {
+    if (knobs().fused_gen == 2 || knobs().no_hint >= (consumer ? 1 : 2)) return false;      // (constant false: product)
+    return N >= 2 && N <= 256 && fused_order() == 1;
+}
 template <int RX, bool XCORR>
 static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C, const float* rois, const float* boxes,
                          const float* z, float* resp, float* out, int32_t* levels_out, const SrOut& S) {
@@ -880,7 +988,7 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order()};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order(), nullptr, nullptr};
     if (out_size == 30) {
         launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     } else if (out_size == 7) {        // the box head's 7x7 pooler (box_head.py:46, roi_heads.py:60-84): same kernel
@@ -894,18 +1002,61 @@ int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, co
 
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
-                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, hipStream_t st) {
+                         float two_e, float min_wh, float* templates, float* sr, const int* n_valid, float* order_hint,
+                         hipStream_t st) {
     (void)rz;
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "emm_extract_cache");
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
-    dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order()};
+    if (!order_hint_rois(N, false)) order_hint = nullptr;
+    SMOT_REQUIRE(order_hint == nullptr || ((((uintptr_t)order_hint) & 31) == 0 && (((uintptr_t)boxes) & 15) == 0),
+                 "emm_extract_cache: the order hint must be 32-byte aligned (and the boxes 16-byte aligned)");
+    // with a hint to write: one extra row of workgroups in front, of which the first ranks the rois (fx_write_hint)
+    dim3 grid(N, (C + FX_CH - 1) / FX_CH + (order_hint != nullptr ? 1 : 0));
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order(), order_hint, nullptr};
     launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
     return check_launch("emm_extract_cache");
 }
+
+// Pooling + correlation with an optional order hint for its rois (smot_emm_track_fwd; the stand-alone operator
+// smot_sr_xcorr_fused_fwd passes none).
+int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
+                        const float* scales, int num_levels, int C, const float* boxes, const float* sr,
+                        const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
+                        hipStream_t st) {
+    LevelParams P;
+    const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
+    if (rc) return rc;
+    if (!order_hint_rois(N, true)) order_hint = nullptr;
+    SMOT_REQUIRE(order_hint == nullptr || (((uintptr_t)order_hint) & 31) == 0,
+                 "sr_xcorr_fused: the order hint must be 32-byte aligned");
+    dim3 grid(N, (C + FX_CH - 1) / FX_CH);
+    timer_mark(0, 0, st);
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint};
+    launch_fused<30, true>(grid, st, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
+    timer_mark(0, 1, st);
+    return check_launch("sr_xcorr_fused");
+}
 }  // namespace smot
+
+#ifdef SMOT_DEBUG
+// measurement library only: the stand-alone pooling + correlation launch WITH an order hint (phase traces / A/B runs of
+// the kernel alone; the product passes hints through smot_emm_track_fwd)
+extern "C" int smot_debug_sr_xcorr_fused_hint_fwd(const float* const* feats, const int* heights, const int* widths,
+                                                  const int* pad_cells, const float* scales, int num_levels, int C,
+                                                  const float* boxes, const float* sr, const float* templates, int N,
+                                                  float* resp, const float* order_hint, smot_stream_t stream) {
+    return smot::sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
+                                     resp, nullptr, order_hint, (hipStream_t)stream);
+}
+#endif
+
+extern "C" long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio) {
+    using namespace smot;
+    if (!(rz == 15 && sampling_ratio == 2) || knobs().roi_generic || !order_hint_rois(N, false)) return 0;
+    return (long long)N * HINT_FLOATS;
+}
 
 extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
                                        const int* pad_cells, const float* scales, int num_levels, int C,
@@ -921,13 +1072,6 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     }
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_fused: null pointer");
-    LevelParams P;
-    const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
-    if (rc) return rc;
-    dim3 grid(N, (C + FX_CH - 1) / FX_CH);
-    timer_mark(0, 0, (hipStream_t)stream);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order()};
-    launch_fused<30, true>(grid, (hipStream_t)stream, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
-    timer_mark(0, 1, (hipStream_t)stream);
-    return check_launch("sr_xcorr_fused");
+    return sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
+                               x_debug, nullptr, (hipStream_t)stream);
 }

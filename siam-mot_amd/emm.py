@@ -125,8 +125,31 @@ class EMMPredictor(nn.Module):
         return logits[:, 0:2], logits[:, 2:3], logits[:, 3:7]
 
 
+class OrderHint(object):
+    """The scheduling hint ``extract_cache`` leaves on its search-region BoxList for the next ``forward`` (include/smot_emm.h,
+    ``order_hint``): the cost-sorted list of exactly these rois, written by the extraction launch.  Valid only for the very
+    tensors it was made from — ``lookup`` checks identity and in-place versions; any copy, merge (dormant tracks joining
+    the memory) or edit of the boxes silently drops it and the head ranks the rois itself, with the same results."""
+    __slots__ = ("data", "boxes", "boxes_version", "sr", "sr_version", "scales")
+
+    def __init__(self, data, boxes, sr, scales):
+        self.data, self.boxes, self.sr, self.scales = data, boxes, sr, scales
+        self.boxes_version, self.sr_version = boxes._version, sr._version
+
+    @staticmethod
+    def lookup(sr_boxlist, boxes, sr, scales):
+        h = sr_boxlist.__dict__.get("order_hint")
+        if (h is not None and h.sr is sr and h.boxes is boxes and h.scales == scales
+                and sr._version == h.sr_version and boxes._version == h.boxes_version
+                and h.data.shape[0] == boxes.shape[0]):
+            return h.data
+        return None
+
+
 class EMM(nn.Module):
     """Drop-in for the reference ``EMM`` (EMM/track_core.py:14-98)."""
+
+    use_order_hint = True      # extract_cache leaves an ``OrderHint`` for the next forward (False: never asks for one)
 
     def __init__(self, cfg, track_utils):
         super(EMM, self).__init__()
@@ -152,69 +175,81 @@ class EMM(nn.Module):
                                              pr.gn_eps)
         params, scales, sampling_ratio, gn_groups, gn_eps = st
         # one library call: pooling -> xcorr -> predictor -> decode (+ the clamp of clip_to_image)
-        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, sr[0].bbox if len(sr) == 1 else cat([b.bbox for b in sr], dim=0),
+        one = len(sr) == 1
+        sr_bbox = sr[0].bbox if one else cat([b.bbox for b in sr], dim=0)
+        hint = OrderHint.lookup(sr[0], boxes[0].bbox, sr_bbox, scales) if one else None
+        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, sr_bbox,
                                     template_features, params, self.rx, self.rz, scales, sampling_ratio,
                                     self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
                                     clip_wh=None if self.amodal else boxes[0].size,
-                                    gn_groups=gn_groups, gn_eps=gn_eps)
+                                    gn_groups=gn_groups, gn_eps=gn_eps, order_hint=hint)
         track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
         return {}, track_result, {}
 
-    def track_raw(self, features, boxes, sr, template_features, image_wh):
+    def track_raw(self, features, boxes, sr, template_features, image_wh, sr_boxlist=None):
         """The inference branch of ``forward`` on raw tensors: template boxes ``[N,4]``, search regions ``[N,4]``,
         templates ``[N,C,rz,rz]`` -> (boxes ``[N,4]``, scores ``[N]``), clamped to the image unless amodal.  No
-        BoxList in or out — the tracking loop's per-frame fast path (track_head.TrackingLoop)."""
+        BoxList in or out — the tracking loop's per-frame fast path (track_head.TrackingLoop).  ``sr_boxlist``: the
+        BoxList ``sr`` came from (it may carry the extraction's order hint)."""
         st = self.__dict__.get("_static")
         if st is None:
             fe, pr = self.feature_extractor.pooler_x, self.predictor
             st = self.__dict__["_static"] = (pr.param_dict(), tuple(fe.scales), fe.sampling_ratio, pr.gn_groups,
                                              pr.gn_eps)
         params, scales, sampling_ratio, gn_groups, gn_eps = st
+        hint = OrderHint.lookup(sr_boxlist, boxes, sr, scales) if sr_boxlist is not None else None
         out = ops.emm_track(features, boxes, sr, template_features, params, self.rx, self.rz, scales, sampling_ratio,
                             self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
-                            clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps)
+                            clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps,
+                            order_hint=hint)
         hook = self.__dict__.get("raw_output_hook")          # tests / probes: the head's output before refinement / solver
         if hook is not None:
             hook(out[0], out[1])
         return out
+
+    def _template_pooler(self):
+        sz = self.__dict__.get("_static_z")
+        if sz is None:                   # (submodule lookups go through nn.Module.__getattr__: once)
+            fz = self.feature_extractor.pooler_z
+            sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
+        return sz
 
     def extract_cache(self, features, detection):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""
         detection = [detection]
         tu = self.track_utils
         det = detection[0]
-        sz = self.__dict__.get("_static_z")
-        if sz is None:
-            fz = self.feature_extractor.pooler_z
-            sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
-        x, sr_bbox = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1],
-                                           tu.pad_pixels, tu.search_expansion, tu.min_search_wh)
-        return self.wrap_cache(x, sr_bbox, det)
+        sz = self._template_pooler()
+        r = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
+                                  tu.min_search_wh, hint=self.use_order_hint)
+        return self.wrap_cache(r[0], r[1], det, r[2] if len(r) > 2 else None)
 
-    def wrap_cache(self, x, sr_bbox, det):
-        """(templates, search-region boxes) of ``det``'s rows -> the reference's cache tuple."""
+    def wrap_cache(self, x, sr_bbox, det, hint=None):
+        """(templates, search-region boxes) of ``det``'s rows -> the reference's cache tuple.  ``hint``: the order
+        hint the extraction wrote for exactly these rows (``[len(det), HINT_FLOATS]``) or None."""
         tu = self.track_utils
         w, h = det.size
         sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
         for field in det.fields():
             sr.add_field(field, det.get_field(field))
+        if hint is not None:
+            sr.order_hint = OrderHint(hint, det.bbox, sr_bbox, self._template_pooler()[0])
         return x, [sr], [det]
 
-    def extract_cache_rows(self, features, boxes, n_valid):
+    def extract_cache_rows(self, features, boxes, n_valid, hint=False):
         """``extract_cache`` on a CAPACITY of boxes ``[M,4]`` whose number of real rows is still on the device
         (``n_valid``: int32 tensor, 1 element — the solver kernel's count): launch only, rows beyond the count are
-        skipped by the kernel.  Returns capacity-sized ``(templates [M,C,rz,rz], sr [M,4])``; the caller slices
-        them once the count is on the host (``wrap_cache``).  Lets the tracking loop enqueue the template
-        extraction BEFORE its one synchronisation of the frame."""
+        skipped by the kernel.  Returns capacity-sized ``(templates [M,C,rz,rz], sr [M,4])``; the caller slices them
+        once the count is on the host (``wrap_cache``).  Lets the tracking loop enqueue the template extraction BEFORE
+        its one synchronisation of the frame.  ``hint=True`` appends the order hint ``[M,8]`` (or None) of the valid
+        rows; the tracking loop does not ask for it: carrying the hint through a frame costs 3-5 us of host work on the
+        loop's serial chain and saves the head 0.4-1.5 us at 30-100 tracks (measure/loop_hint_ab.py)."""
         tu = self.track_utils
-        sz = self.__dict__.get("_static_z")
-        if sz is None:
-            fz = self.feature_extractor.pooler_z
-            sz = self.__dict__["_static_z"] = (tuple(fz.scales), fz.sampling_ratio)
+        sz = self._template_pooler()
         if not (self.rz == 15 and sz[1] == 2):
             return None                                    # no masked kernel for this shape family: caller falls back
         return ops.emm_extract_cache(features, boxes, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
-                                     tu.min_search_wh, n_valid=n_valid)
+                                     tu.min_search_wh, n_valid=n_valid, hint=hint and self.use_order_hint)
 
 
 def wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=False):

@@ -19,6 +19,8 @@ synchronisation, they are overwritten by the next replay.
 """
 import torch
 
+from .emm import OrderHint
+
 
 def capture(fn, warmup=2, device=None):
     """Run ``fn()`` ``warmup`` times eagerly on a side stream, then capture one call into a graph.
@@ -50,6 +52,13 @@ class FramePairRing(object):
         self.sr0 = sr[0].__class__(self.sr0_bbox, sr[0].size, mode=sr[0].mode)
         for field in sr[0].fields():
             self.sr0.add_field(field, sr[0].get_field(field))
+        # the extraction's order hint (emm.OrderHint) chains through the ring like the memory it describes — only when
+        # the memory handed in was made from the very detections every step extracts from (the hint names rows of them)
+        h = sr[0].__dict__.get("order_hint")
+        self.hint0 = None
+        if h is not None and h.boxes is d[0].bbox and d[0].bbox is detections.bbox and h.sr is sr[0].bbox:
+            self.hint0 = h.data.clone()
+            self.sr0.order_hint = OrderHint(self.hint0, d[0].bbox, self.sr0_bbox, h.scales)
         self.results = None
         self.graph, _ = capture(self._revolution)
 
@@ -62,6 +71,9 @@ class FramePairRing(object):
             z, sr, d = self.emm.extract_cache(f, self.det)
         self.z0.copy_(z)                        # close the ring: the next revolution starts from this memory
         self.sr0_bbox.copy_(sr[0].bbox)
+        if self.hint0 is not None:
+            self.hint0.copy_(sr[0].order_hint.data)
+            self.sr0.order_hint.sr_version = self.sr0_bbox._version      # (this copy is the hint's own update)
         self.results = results
         return results
 

@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -61,11 +61,12 @@ _SIGNATURES = {
     "smot_kernel_timer_end": (ctypes.c_int, [_i, _vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
-                                          _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp]),
+                                          _vp, _i, _f, _vp, _i, _f, _f, _f, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "smot_emm_order_hint_floats": (ctypes.c_longlong, [_i, _i, _i]),
     "smot_emm_extract_cache_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _f, _f, _f,
-                                                  _vp, _vp, _vp]),
+                                                  _vp, _vp, _vp, _vp]),
     "smot_emm_extract_cache_masked_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _f, _f, _f,
-                                                         _vp, _vp, _vp]),
+                                                         _vp, _vp, _vp, _vp]),
     "smot_box_refine_post_max_rows": (ctypes.c_int, []),
     "smot_box_refine_post_fwd": (ctypes.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _f, _f, _i,
                                                 _vp, _vp, _vp, _vp, _vp]),
@@ -84,6 +85,7 @@ _SIGNATURES = {
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 _DEBUG_SIGNATURES = {
     "smot_debug_set_knob": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    "smot_debug_sr_xcorr_fused_hint_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
 }
 DEBUG_EXPORTED_SYMBOLS = tuple(_DEBUG_SIGNATURES.keys())
 
@@ -116,7 +118,8 @@ def _open(path, signatures):
 
 _KNOB_DEFAULTS = {"SMOT_NO_FUSE": "0", "SMOT_ROI_GENERIC": "0", "SMOT_TOWER_DIRECT": "0", "SMOT_TOWER_WIDE": "0",
                   "SMOT_DECODE_SPLIT": "0", "SMOT_XCORR_VARIANT": "default", "SMOT_DECODE_2PASS": "0",
-                  "SMOT_FUSED_GEN": "0", "SMOT_TOWER_OCT": "0", "SMOT_FUSED_ORDER": "0", "SMOT_FUSED_ABL": "0", "SMOT_WINO_ABL": "0",
+                  "SMOT_FUSED_GEN": "0", "SMOT_TOWER_OCT": "0", "SMOT_FUSED_ORDER": "0", "SMOT_NO_HINT": "0", "SMOT_FUSED_ABL": "0",
+                  "SMOT_WINO_ABL": "0",
                   "SMOT_TOWER_ABL": "0"}
 
 
@@ -141,10 +144,12 @@ def debug_library(**knobs):
     try:
         set_all(_KNOB_DEFAULTS)
         set_all(knobs)
+        _hint_floats.clear()                        # (answers of the library that depend on its switches)
         yield dbg
     finally:
         set_all(_KNOB_DEFAULTS)
         _lib = prev
+        _hint_floats.clear()
 
 
 def _check(rc, what):
@@ -565,8 +570,12 @@ def _chk(t, name, shape):
 
 def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_ratio, pad_pixels,
               sigma=0.4, use_centerness=True, clip_wh=None, gn_groups=32, gn_eps=1e-5, return_index=False,
-              winograd=True):
-    """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``)."""
+              winograd=True, order_hint=None):
+    """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``).
+
+    ``order_hint``: the ``[N, HINT_FLOATS]`` tensor ``emm_extract_cache(..., hint=True)`` returned TOGETHER WITH exactly
+    these ``boxes`` / ``sr`` (include/smot_emm.h: a scheduling side channel; a hint of other boxes gives wrong results —
+    ``siammot_amd.emm.EMM`` checks tensor identity and versions before it passes one), or None."""
     lib = _lib or load_library()
     if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
         _dev_f32(boxes, "boxes")                 # raises: no CPU path
@@ -590,6 +599,10 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     bb = torch.empty((N, 4), dtype=_F32, device=dev)
     conf = torch.empty((N,), dtype=_F32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
+    if order_hint is not None and (tuple(order_hint.shape) != (N, HINT_FLOATS) or order_hint.device != dev
+                                   or order_hint.dtype is not _F32 or not order_hint.is_contiguous()):
+        raise RuntimeError("siammot_amd.emm_track: order_hint must be the contiguous fp32 [%d, %d] tensor of the "
+                           "extraction that made these boxes" % (N, HINT_FLOATS))
     cur = torch.cuda.current_device()           # kernels launch on the CURRENT device: make it the tensors' device
     if cur != dev.index:
         torch.cuda.set_device(dev.index)
@@ -601,7 +614,8 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
                                 float(clip_wh[0]) if clip_wh is not None else 0.0,
                                 float(clip_wh[1]) if clip_wh is not None else 0.0,
                                 work.data_ptr(), bb.data_ptr(), conf.data_ptr(),
-                                idx.data_ptr() if idx is not None else None, stream)
+                                idx.data_ptr() if idx is not None else None,
+                                order_hint.data_ptr() if order_hint is not None else None, stream)
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
@@ -610,9 +624,26 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     return (bb, conf, idx) if return_index else (bb, conf)
 
 
+HINT_FLOATS = 8                      # SMOT_HINT_FLOATS (include/smot_emm.h)
+_hint_floats = {}
+
+
+def order_hint_floats(N, rz, sampling_ratio):
+    """``smot_emm_order_hint_floats``: size of the order hint the extraction writes for ``N`` boxes (0 = none)."""
+    key = (N, rz, sampling_ratio)
+    v = _hint_floats.get(key)
+    if v is None:
+        if len(_hint_floats) > 1024:
+            _hint_floats.clear()
+        v = _hint_floats[key] = int((_lib or load_library()).smot_emm_order_hint_floats(N, rz, sampling_ratio))
+    return v
+
+
 def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
-                      n_valid=None):
-    """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``).
+                      n_valid=None, hint=False):
+    """``EMM.extract_cache`` in one library call → (templates ``[N,C,rz,rz]``, sr ``[N,4]``); with ``hint=True`` →
+    (templates, sr, order hint ``[N, HINT_FLOATS]`` or None when this shape / count writes none): the list the next
+    frame's ``emm_track(..., order_hint=)`` reads instead of ranking these search regions in every workgroup.
 
     ``n_valid``: a device int32 tensor (1 element) holding the number of REAL rows among ``boxes`` (a capacity): rows
     beyond it are skipped on the device and their outputs stay unwritten — the call can be enqueued before the
@@ -625,7 +656,13 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
     N, C = boxes.shape[0], g.C
     boxes = _chk(boxes, "boxes", (N, 4))
     templates = torch.empty((N, C, rz, rz), dtype=_F32, device=dev)
-    sr = torch.empty((N, 4), dtype=_F32, device=dev)
+    oh = None
+    if hint and boxes.data_ptr() % 16 == 0 and order_hint_floats(N, rz, sampling_ratio) > 0:
+        both = torch.empty((N * (HINT_FLOATS + 4),), dtype=_F32, device=dev)       # one allocation: hint | sr
+        oh = both[:N * HINT_FLOATS].view(N, HINT_FLOATS)
+        sr = both[N * HINT_FLOATS:].view(N, 4)
+    else:
+        sr = torch.empty((N, 4), dtype=_F32, device=dev)
     cur = torch.cuda.current_device()
     if cur != dev.index:
         torch.cuda.set_device(dev.index)
@@ -633,18 +670,20 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
         if n_valid is None:
             rc = lib.smot_emm_extract_cache_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
                                                 rz, sampling_ratio, pad_pixels, search_expansion, min_search_wh,
-                                                templates.data_ptr(), sr.data_ptr(), _stream(dev))
+                                                templates.data_ptr(), sr.data_ptr(),
+                                                oh.data_ptr() if oh is not None else None, _stream(dev))
         else:
             rc = lib.smot_emm_extract_cache_masked_fwd(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, C, boxes.data_ptr(), N,
                                                        n_valid.data_ptr(), rz, sampling_ratio, pad_pixels,
                                                        search_expansion, min_search_wh, templates.data_ptr(),
-                                                       sr.data_ptr(), _stream(dev))
+                                                       sr.data_ptr(), oh.data_ptr() if oh is not None else None,
+                                                       _stream(dev))
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
     if rc:
         _check(rc, "emm_extract_cache")
-    return templates, sr
+    return (templates, sr, oh) if hint else (templates, sr)
 
 
 TIMER_XCORR, TIMER_TOWER = 0, 1
@@ -1008,13 +1047,14 @@ def box_refine_post_max_rows():
     return (_lib or load_library()).smot_box_refine_post_max_rows()
 
 
-_FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "tpl_boxes", "sr", "templates", "trk_ids", "trk_labels",
+_FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "tpl_boxes", "sr", "templates", "order_hint",
+               "trk_ids", "trk_labels",
                "predictor_params", "hann", "head_ws", "trk_boxes", "trk_conf",
                "fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "reg_w", "reg_b", "refine_ws",
                "ref_boxes", "ref_scores", "ref_ids", "ref_labels",
                "det_boxes", "det_scores", "det_ids", "det_labels", "pool_state",
                "out_boxes", "out_scores", "out_ids", "out_labels", "act_boxes", "act_ids", "act_labels", "act_scores",
-               "record", "next_templates", "next_sr")
+               "record", "next_templates", "next_sr", "next_order_hint")
 _FRAME_INTS = ("num_levels", "C", "n_trk", "n_det", "rx", "rz", "sampling_ratio", "gn_groups", "up", "use_centerness",
                "refine", "box_pooled", "box_sampling_ratio", "dim6", "dim7", "num_classes", "reg_classes", "tracktor",
                "max_dormant_frames", "pool_capacity")
@@ -1024,7 +1064,7 @@ _FRAME_FLOATS = ("gn_eps", "pad_pixels", "one_minus_sigma", "sigma", "clip_w", "
 
 
 class FrameArgs(object):
-    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 44 pointers, 20 ints, 17 floats, in the header's
+    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 46 pointers, 20 ints, 17 floats, in the header's
     order.  Fields are plain Python attributes (``__slots__``); ``pack()`` writes all of them with one ``struct.pack_into``
     (a ctypes.Structure costs ~0.4 us per field assignment — 30 us per frame for this block)."""
     __slots__ = _FRAME_PTRS + _FRAME_INTS + _FRAME_FLOATS + ("_buf", "_addr")

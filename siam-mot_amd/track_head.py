@@ -19,6 +19,7 @@ import copy
 import torch
 
 from . import ops
+from .emm import OrderHint
 from .structures import cat_boxlist
 
 
@@ -47,13 +48,19 @@ class TrackHead(torch.nn.Module):
         self.track_pool.reset()
 
     def get_track_memory(self, features, tracks, precomputed=None):                # track_head.py:54-75
-        """``precomputed``: capacity-sized ``(templates, sr boxes)`` of the solver's active rows, extracted by a
-        launch that was enqueued before the frame's synchronisation (``EMM.extract_cache_rows``)."""
+        """``precomputed``: capacity-sized ``(templates, sr boxes[, order hint, the boxes tensor they were made from])``
+        of the solver's active rows, extracted by a launch that was enqueued before the frame's synchronisation
+        (``EMM.extract_cache_rows``)."""
         assert len(tracks) == 1
         active_tracks = self._get_track_targets(tracks[0])
         if precomputed is not None and len(active_tracks) > 0:
             a = len(active_tracks)
-            track_memory = self.tracker.wrap_cache(precomputed[0][:a], precomputed[1][:a], active_tracks)
+            hint = None                   # the hint describes rows 0..a-1 of the tensor the extraction read
+            if (len(precomputed) > 3 and precomputed[2] is not None
+                    and precomputed[3].data_ptr() == active_tracks.bbox.data_ptr()):
+                hint = precomputed[2][:a]
+            track_memory = self.tracker.wrap_cache(precomputed[0][:a], precomputed[1][:a], active_tracks,
+                                                   *(() if hint is None else (hint,)))
             track_memory = self._update_memory_with_dormant_track(track_memory)
             self.track_pool.update_cache(track_memory)
             return track_memory
@@ -152,7 +159,7 @@ class TrackingLoop(torch.nn.Module):
             z, sr, tb = mem
             tb0 = tb[0]
             if z.numel() > 0:
-                bb, conf = emm.track_raw(features, tb0.bbox, sr[0].bbox, z, tb0.size)
+                bb, conf = emm.track_raw(features, tb0.bbox, sr[0].bbox, z, tb0.size, sr[0])
                 trk = (bb, conf, tb0.get_field("ids"), tb0.get_field("labels"))
                 if self.refine_tracks is not None:                                 # roi_heads.py:43-44,60-84, on the device
                     trk = self.refine_tracks.refine_raw(features, bb, conf, trk[2], trk[3], tb0.size)
@@ -196,7 +203,8 @@ class TrackingLoop(torch.nn.Module):
             # no active row (the reference's empty memory) or no masked kernel for this pooler shape: general code
             self.track_memory = self.track.get_track_memory(features, [out])
             return out
-        memory = emm.wrap_cache(pre[0][:A], pre[1][:A], act)
+        # (the extraction ranked exactly the rows of `act` — the first A of act_boxes — for the next frame's head)
+        memory = emm.wrap_cache(pre[0][:A], pre[1][:A], act, pre[2][:A] if len(pre) > 2 and pre[2] is not None else None)
         if pool._dormant_ids:
             memory = self.track._update_memory_with_dormant_track(memory)
         pool.note_memory(memory, getattr(memory[2][0], "host_ids", act.host_ids))
@@ -262,6 +270,7 @@ class TrackingLoop(torch.nn.Module):
         n_trk = 0
         tf = ti = None
         keep = []                                   # tensors that must outlive the call's argument block
+        a.order_hint = None
         if mem is None:
             pool.reset()                                                           # track_head.py:39-40
         elif mem[0].numel() > 0:
@@ -269,6 +278,10 @@ class TrackingLoop(torch.nn.Module):
             tb0 = tb[0]
             n_trk = len(tb0)
             tbb, srb = ops._chk(tb0.bbox, "template boxes", (n_trk, 4)), ops._chk(sr[0].bbox, "sr", (n_trk, 4))
+            fe_scales = emm.__dict__["_static"][1] if "_static" in emm.__dict__ else tuple(fe.scales)
+            hint = OrderHint.lookup(sr[0], tb0.bbox, sr[0].bbox, fe_scales)
+            a.order_hint = hint.data_ptr() if hint is not None else None
+            keep.append(hint)
             zc = ops._chk(z, "template_features", (n_trk, C, emm.rz, emm.rz))
             ids_t, lab_t = tb0.get_field("ids"), tb0.get_field("labels")
             if not (ids_t.is_contiguous() and lab_t.is_contiguous() and ids_t.dtype is torch.int64 and lab_t.dtype is torch.int64):
@@ -325,6 +338,7 @@ class TrackingLoop(torch.nn.Module):
         ibuf = torch.empty((4 * M,), dtype=torch.int64, device=dev)
         templates = torch.empty((M, C, emm.rz, emm.rz), dtype=torch.float32, device=dev)
         sr_next = torch.empty((M, 4), dtype=torch.float32, device=dev)
+        a.next_order_hint = None      # (not asked for in the loop: see EMM.extract_cache_rows)
         rec_host = ring.next()
         fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
         a.pool_state = state.data_ptr()
@@ -361,6 +375,8 @@ class TrackingLoop(torch.nn.Module):
             # the capacity with the count still on the device — the GPU never waits for the host inside a frame
             rows = getattr(self.track.tracker, "extract_cache_rows", None)
             pre = rows(features, h.act_boxes, h.count) if rows is not None else None
+            if pre is not None:
+                pre = tuple(pre) + (h.act_boxes,)
             out = self.solver.solve_finish(h)                                      # the frame's one synchronisation
             self.track_memory = self.track.get_track_memory(features, [out], precomputed=pre)
             return out

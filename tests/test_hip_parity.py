@@ -956,6 +956,104 @@ def test_cost_sorted_workgroup_assignment_is_a_bijection(ops, n):
     assert torch.equal(sorted_[2], sorted_[0]) and torch.equal(sorted_[4], sorted_[0][:max(n - 3, 0)])
 
 
+@pytest.mark.parametrize("n", [2, 30, 65, 130, 256, 257])
+def test_order_hint_lists_the_rois_in_cost_order_and_changes_nothing(ops, n):
+    """The extraction's order hint (include/smot_emm.h ``order_hint``; sr_xcorr.hip fx_write_hint): one entry per roi — a
+    permutation — carrying that roi's search region and FPN level bit for bit, wide windows first; the head fed the
+    hint returns exactly what it returns without (boxes, scores, arg-max cells); the masked extraction's hint covers
+    the valid rows; beyond 256 rois there is none."""
+    rs = np.random.RandomState(1700 + n)
+    g = torch.Generator().manual_seed(n)
+    C = 32
+    feats = tuple(torch.randn((1, C, 704 // s, 1280 // s), generator=g).to(DEV) for s in (4, 8, 16, 32))
+    wh = np.exp(rs.uniform(np.log(20), np.log(500), (n, 1))) * np.array([[1.0, 1.7]])
+    xy = rs.uniform(0, 1, (n, 2)) * np.maximum(np.array([1280.0, 704.0]) - wh, 1.0)
+    boxes_np = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    boxes = _d(boxes_np)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    z, sr, hint = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0, hint=True)
+    z0, sr0 = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0)
+    assert torch.equal(z, z0) and torch.equal(sr, sr0)              # the extra row of workgroups changes no output
+    if n > 256:
+        assert hint is None and ops.order_hint_floats(n, 15, 2) == 0
+        return
+    assert tuple(hint.shape) == (n, ops.HINT_FLOATS) and ops.order_hint_floats(n, 15, 2) == n * ops.HINT_FLOATS
+    h = hint.cpu()
+    meta = h[:, 4:].contiguous().view(torch.int32)
+    idx, lvl = meta[:, 1].long(), meta[:, 0].long()
+    assert sorted(idx.tolist()) == list(range(n))
+    assert torch.equal(h[:, :4], sr.cpu()[idx])
+    _, want_lvl = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2, return_levels=True)   # (vs the oracle: elsewhere)
+    assert torch.equal(lvl, want_lvl.cpu()[idx].long())
+    assert int(meta[:, 2:].abs().max()) == 0
+    sc = torch.tensor(scales)[lvl]
+    cls = ((h[:, 2] - h[:, 0]) * sc > 30.0).int() + ((h[:, 2] - h[:, 0]) * sc > 62.0).int()
+    key = (-cls.long()) * 1000 + idx                                  # class descending, roi ascending
+    assert torch.equal(key, key.sort().values)
+    params = {k: _d(v) for k, v in gi.predictor_params(rs, C, boxes_np).items()}
+
+    def head(hh):
+        return ops.emm_track(feats, boxes, sr, z, params, 30, 15, scales, 2, 512, clip_wh=(1280, 704),
+                             return_index=True, order_hint=hh)
+    plain, hinted = head(None), head(hint)
+    for a, b in zip(plain, hinted):
+        assert torch.equal(a, b)
+    if n >= 6:
+        nv = n - 3
+        mz, msr, mh = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0,
+                                            n_valid=torch.tensor([nv], dtype=torch.int32, device=DEV), hint=True)
+        mi = mh[:nv].cpu()[:, 4:].contiguous().view(torch.int32)[:, 1].long()
+        assert sorted(mi.tolist()) == list(range(nv)) and torch.equal(mh[:nv, :4].cpu(), sr.cpu()[mi])
+        out = ops.emm_track(feats, boxes[:nv], msr[:nv], mz[:nv], params, 30, 15, scales, 2, 512, clip_wh=(1280, 704),
+                            return_index=True, order_hint=mh[:nv])
+        for a, b in zip(plain, out):
+            assert torch.equal(a[:nv], b)
+    with pytest.raises(RuntimeError):
+        head(hint[:n - 1])
+
+
+def test_order_hint_is_dropped_when_the_memory_it_describes_changes(ops):
+    """``EMM.extract_cache`` leaves the hint on its search-region BoxList; ``EMM.forward`` passes it only for the very
+    tensors it was made from: an in-place edit, a copy or a merged memory falls back to ranking in the kernel — checked
+    through the results (a stale hint WOULD change them: its entries carry the old search regions)."""
+    from siammot_amd.emm import OrderHint
+    from siammot_amd.structures import BoxList, cat_boxlist
+    case = dict(gi.EMM_CASES["default"], channels=32)
+    rs = np.random.RandomState(5)
+    shapes = gi.feature_shapes(case["image_wh"], 32)
+    feats = tuple(_d(rs.standard_normal(s).astype(np.float32)) for s in shapes)
+    boxes = np.array(case["boxes"][:6], dtype=np.float32)
+    emm = _build_emm(case)
+    emm.predictor.load_state_dict({k: _t(v) for k, v in gi.predictor_params(rs, 32, boxes).items()})
+
+    def dets(b):
+        d = BoxList(_d(b), case["image_wh"], mode="xyxy")
+        d.add_field("ids", torch.arange(len(b), device=DEV))
+        d.add_field("labels", torch.ones(len(b), dtype=torch.int64, device=DEV))
+        return d
+    scales = tuple(emm.feature_extractor.pooler_x.scales)
+    with torch.no_grad():
+        z, sr, d = emm.extract_cache(feats, dets(boxes))
+        assert OrderHint.lookup(sr[0], d[0].bbox, sr[0].bbox, scales) is not None
+        _, res, _ = emm(feats, d, sr, template_features=z)
+        want = ops.emm_track(feats, d[0].bbox, sr[0].bbox, z, emm.predictor.param_dict(), emm.rx, emm.rz, scales, 2,
+                             emm.pad_pixels, sigma=emm.sigma, use_centerness=emm.use_centerness, clip_wh=case["image_wh"])
+        assert torch.equal(res[0].bbox, want[0]) and torch.equal(res[0].get_field("scores"), want[1])
+        # in-place edit of the search regions: the hint's copy of them is stale
+        sr[0].bbox[:, 2:] += 24.0
+        assert OrderHint.lookup(sr[0], d[0].bbox, sr[0].bbox, scales) is None
+        _, res, _ = emm(feats, d, sr, template_features=z)
+        want = ops.emm_track(feats, d[0].bbox, sr[0].bbox, z, emm.predictor.param_dict(), emm.rx, emm.rz, scales, 2,
+                             emm.pad_pixels, sigma=emm.sigma, use_centerness=emm.use_centerness, clip_wh=case["image_wh"])
+        assert torch.equal(res[0].bbox, want[0]) and torch.equal(res[0].get_field("scores"), want[1])
+        # a merged memory (dormant tracks joining): new tensors, no hint
+        z2, sr2, d2 = emm.extract_cache(feats, dets(boxes[::-1].copy()))
+        merged_sr, merged_d = cat_boxlist([sr2[0], sr[0]]), cat_boxlist([d2[0], d[0]])
+        assert OrderHint.lookup(merged_sr, merged_d.bbox, merged_sr.bbox, scales) is None
+        # another BoxList around the same search regions but other template boxes
+        assert OrderHint.lookup(sr2[0], d[0].bbox, sr2[0].bbox, scales) is None
+
+
 def test_fused_pooling_odd_channel_counts_and_wide_windows(ops):
     """Channel counts that leave plane pairs / workgroups half empty (C = 5, 9, 12), and windows wider than a wave
     (chunked path): against the oracle, and the fused response against the stand-alone composition."""
@@ -1063,6 +1161,7 @@ def test_frame_pair_ring_graph_replays_the_eager_loop(ops):
             eager.append((res[0].bbox.clone(), res[0].get_field("scores").clone()))
             st = emm.extract_cache(feats[k % 3], det)
         ring = FramePairRing(emm, feats, det, state)
+        assert ring.hint0 is not None             # the order hint chains through the ring with the memory
         # (the capture itself ran warm-up revolutions: reset the ring's memory to the starting state)
         ring.z0.copy_(state[0])
         ring.sr0_bbox.copy_(state[1][0].bbox)
