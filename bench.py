@@ -242,7 +242,7 @@ def hipgraph_loop_throughput(emm, feats, det, state, steps):
             "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
 
 
-def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
+def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None):
     """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
     the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
     cycle, ONE host sync) -> EMM.extract_cache + track memory.  Fixed track count: the n boxes sit on a
@@ -305,14 +305,17 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False):
     # the detector's output of two alternating frames, resident on the device before the loop (synthesising it is
     # not tracker work); every frame gets a fresh BoxList and its own score tensor (the solver bands scores in place)
     pre = [(boxes + float(j), torch.full((n,), -1, dtype=torch.int64, device=dev),
-            torch.ones(n, dtype=torch.int64, device=dev), torch.full((n,), 0.9, device=dev)) for j in range(2)]
+            torch.ones(n, dtype=torch.int64, device=dev)) for j in range(2)]
+    fresh_scores = list(torch.full((steps + 31, n), 0.9, device=dev).unbind(0))   # one row per frame, made before the loop
+    if native is not None:
+        loop.native_frame = bool(native)
 
     def dets(k):
-        b, ids, labels, scores = pre[k & 1]
+        b, ids, labels = pre[k & 1]
         d = BoxList(b, image_wh, mode="xyxy")
         d.add_field("ids", ids)
         d.add_field("labels", labels)
-        d.add_field("scores", scores.clone())
+        d.add_field("scores", fresh_scores.pop())
         return d
     out = loop(feats[0], dets(0))                     # frame 0: the n detections start n tracks
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n

@@ -450,7 +450,7 @@ int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_
                          int* record, smot_stream_t stream);
 
 /*
- * One tracking frame behind ONE call: the launches of smot_emm_track_fwd (3) [+ smot_box_refine_fwd (8)] +
+ * One tracking frame behind ONE call (or two): the launches of smot_emm_track_fwd (3) [+ smot_box_refine_fwd (8)] +
  * smot_track_solve_fwd (1) + smot_emm_extract_cache_masked_fwd (1) enqueued back to back on `stream`.
  *
  * Replaces the inference branch of CombinedROIHeads.forward from `self.track(...)` on
@@ -461,41 +461,49 @@ int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_
  * stage are the inputs of the next (the propagated boxes / scores feed the refinement or the solver, the solver's
  * act_boxes and pool_state[4] feed the masked template extraction).  n_trk == 0 skips the head and the refinement
  * (first frame, or an empty memory); refine == 0 skips the refinement (the solver then applies trk_score_bias = 1).
- * The host reads `record` (pinned host memory) as with smot_track_solve_fwd.  Plain C struct: no padding surprises —
- * pointers first, then 32-bit fields.
+ * `stages` selects what this call enqueues (0 = everything): a frame is a serial chain — host work before the first
+ * launch, the kernels, the record, host bookkeeping — so a caller whose argument preparation is not free calls once
+ * with SMOT_STAGE_HEAD as soon as the head's arguments stand (fields of later stages are not read) and a second time
+ * with the remaining stages while the head runs (siammot_amd.track_head.TrackingLoop does).
+ * The host reads `record` (pinned host memory) as with smot_track_solve_fwd.  Plain C struct: pointers first, then
+ * 32-bit fields, no padding; inside each group the fields that change from frame to frame are contiguous (a binding
+ * that keeps the block between frames rewrites two short ranges per call).
  */
+#define SMOT_STAGE_HEAD 1
+#define SMOT_STAGE_REFINE 2
+#define SMOT_STAGE_SOLVE 4
+#define SMOT_STAGE_EXTRACT 8
 typedef struct smot_frame_args {
-    /* FPN levels (HOST arrays of num_levels entries, as in smot_roi_align_levels_fwd) */
+    /* ---- fixed while the video's geometry and the model stand ---- */
+    /* FPN levels (HOST arrays of num_levels entries, as in smot_roi_align_levels_fwd; the entries of `feats` are
+     * this frame's maps — the array itself can stay where it is) */
     const float* const* feats;
     const int* heights;
     const int* widths;
     const int* pad_cells;        /* search-region pooling (virtual padding) */
     const float* scales;
-    /* track memory of the previous frame */
-    const float* tpl_boxes;      /* [n_trk,4] */
+    const float* const* predictor_params;   /* HOST array of 13 device pointers (smot_emm_track_fwd) */
+    const float* hann;
+    const float* fc6_w; const float* fc6_b; const float* fc7_w; const float* fc7_b;   /* box head (refine != 0) */
+    const float* cls_w; const float* cls_b; const float* reg_w; const float* reg_b;
+    int* pool_state;
+    /* ---- this frame: the head (SMOT_STAGE_HEAD reads up to trk_conf) ---- */
+    float* head_ws;              /* smot_emm_track_ws_floats(n_trk, C, rx, rz) */
+    const float* tpl_boxes;      /* [n_trk,4] track memory of the previous frame */
     const float* sr;             /* [n_trk,4] */
     const float* templates;      /* [n_trk,C,rz,rz] */
     const float* order_hint;     /* order hint of exactly these rows (smot_emm_track_fwd) or NULL */
     const int64_t* trk_ids;      /* [n_trk] */
     const int64_t* trk_labels;   /* [n_trk] */
-    /* head */
-    const float* const* predictor_params;   /* HOST array of 13 device pointers (smot_emm_track_fwd) */
-    const float* hann;
-    float* head_ws;              /* smot_emm_track_ws_floats(n_trk, C, rx, rz) */
     float* trk_boxes;            /* [n_trk,4] out: propagated boxes */
     float* trk_conf;             /* [n_trk]   out: matching scores */
-    /* box-head refinement (refine != 0) */
-    const float* fc6_w; const float* fc6_b; const float* fc7_w; const float* fc7_b;
-    const float* cls_w; const float* cls_b; const float* reg_w; const float* reg_b;
+    /* ---- this frame: refinement, detections, solver, next memory ---- */
     float* refine_ws;            /* smot_box_refine_ws_floats(...) */
     float* ref_boxes;            /* [n_trk,4] out */
     float* ref_scores;           /* [n_trk]   out */
     int64_t* ref_ids;            /* [n_trk]   out */
     int64_t* ref_labels;         /* [n_trk]   out */
-    /* this frame's detections */
     const float* det_boxes; float* det_scores; const int64_t* det_ids; const int64_t* det_labels;
-    /* solver */
-    int* pool_state;
     float* out_boxes; float* out_scores; int64_t* out_ids; int64_t* out_labels;
     float* act_boxes; int64_t* act_ids; int64_t* act_labels; float* act_scores;
     int* record;
@@ -503,15 +511,16 @@ typedef struct smot_frame_args {
     float* next_templates;
     float* next_sr;
     float* next_order_hint;      /* smot_emm_order_hint_floats(n_det + n_trk, rz, sampling_ratio) floats or NULL */
-    /* sizes and scalars */
-    int num_levels, C, n_trk, n_det;
+    /* ---- sizes and scalars: per frame first ---- */
+    int n_trk, stages, n_det;
+    int num_levels, C;
     int rx, rz, sampling_ratio, gn_groups, up, use_centerness;
     int refine, box_pooled, box_sampling_ratio, dim6, dim7, num_classes, reg_classes, tracktor;
     int max_dormant_frames, pool_capacity;
+    float track_thresh, start_thresh, resume_thresh;
     float gn_eps, pad_pixels, one_minus_sigma, sigma, clip_w, clip_h;
     float box_wx, box_wy, box_ww, box_wh, box_xform_clip;
-    float track_thresh, start_thresh, resume_thresh, nms_thresh;
-    float search_expansion, min_search_wh;
+    float nms_thresh, search_expansion, min_search_wh;
 } smot_frame_args;
 
 int smot_track_frame_fwd(const smot_frame_args* args, smot_stream_t stream);

@@ -146,33 +146,41 @@ extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, cons
 extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(a != nullptr, "track_frame: null argument block");
-    SMOT_REQUIRE(a->n_trk >= 0 && a->n_det >= 0 && a->n_trk + a->n_det > 0, "track_frame: n_trk=%d n_det=%d", a->n_trk,
-                 a->n_det);
+    const int stages = a->stages == 0 ? (SMOT_STAGE_HEAD | SMOT_STAGE_REFINE | SMOT_STAGE_SOLVE | SMOT_STAGE_EXTRACT) : a->stages;
+    SMOT_REQUIRE(a->n_trk >= 0, "track_frame: n_trk=%d", a->n_trk);
     int rc;
-    const float* trk_boxes = nullptr;
-    float* trk_scores = nullptr;
-    const int64_t* trk_ids = nullptr;
-    const int64_t* trk_labels = nullptr;
-    float bias = 1.0f;
-    if (a->n_trk > 0) {
+    if ((stages & SMOT_STAGE_HEAD) && a->n_trk > 0) {
         rc = smot_emm_track_fwd(a->feats, a->heights, a->widths, a->pad_cells, a->scales, a->num_levels, a->C, a->tpl_boxes,
                                 a->sr, a->templates, a->n_trk, a->rx, a->rz, a->sampling_ratio, a->predictor_params,
                                 a->gn_groups, a->gn_eps, a->hann, a->up, a->pad_pixels, a->one_minus_sigma, a->sigma,
                                 a->use_centerness, a->clip_w, a->clip_h, a->head_ws, a->trk_boxes, a->trk_conf, nullptr,
                                 a->order_hint, stream);
         if (rc) return rc;
+    }
+    if (!(stages & (SMOT_STAGE_REFINE | SMOT_STAGE_SOLVE | SMOT_STAGE_EXTRACT))) return SMOT_OK;
+    SMOT_REQUIRE(a->n_det >= 0 && a->n_trk + a->n_det > 0, "track_frame: n_trk=%d n_det=%d", a->n_trk, a->n_det);
+    // what the solver reads as its track segment: the head's output, or the refinement's (refine != 0)
+    const float* trk_boxes = nullptr;
+    float* trk_scores = nullptr;
+    const int64_t* trk_ids = nullptr;
+    const int64_t* trk_labels = nullptr;
+    float bias = 1.0f;
+    if (a->n_trk > 0) {
         trk_boxes = a->trk_boxes;
         trk_scores = a->trk_conf;
         trk_ids = a->trk_ids;
         trk_labels = a->trk_labels;
         if (a->refine) {
-            rc = smot_box_refine_fwd(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->box_pooled,
-                                     a->box_sampling_ratio, a->trk_boxes, a->trk_labels, a->trk_ids, a->trk_conf, a->n_trk,
-                                     a->fc6_w, a->fc6_b, a->dim6, a->fc7_w, a->fc7_b, a->dim7, a->cls_w, a->cls_b,
-                                     a->num_classes, a->reg_w, a->reg_b, a->reg_classes, a->box_wx, a->box_wy, a->box_ww,
-                                     a->box_wh, a->box_xform_clip, a->clip_w, a->clip_h, a->tracktor, a->refine_ws,
-                                     a->ref_boxes, a->ref_scores, a->ref_ids, a->ref_labels, stream);
-            if (rc) return rc;
+            if (stages & SMOT_STAGE_REFINE) {
+                rc = smot_box_refine_fwd(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->box_pooled,
+                                         a->box_sampling_ratio, a->trk_boxes, a->trk_labels, a->trk_ids, a->trk_conf,
+                                         a->n_trk, a->fc6_w, a->fc6_b, a->dim6, a->fc7_w, a->fc7_b, a->dim7, a->cls_w,
+                                         a->cls_b, a->num_classes, a->reg_w, a->reg_b, a->reg_classes, a->box_wx,
+                                         a->box_wy, a->box_ww, a->box_wh, a->box_xform_clip, a->clip_w, a->clip_h,
+                                         a->tracktor, a->refine_ws, a->ref_boxes, a->ref_scores, a->ref_ids,
+                                         a->ref_labels, stream);
+                if (rc) return rc;
+            }
             trk_boxes = a->ref_boxes;
             trk_scores = a->ref_scores;
             trk_ids = a->ref_ids;
@@ -180,12 +188,15 @@ extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stre
             bias = 0.0f;                       // the refined scores are in the (1, 2] band already
         }
     }
-    rc = smot_track_solve_fwd(a->det_boxes, a->det_scores, a->det_ids, a->det_labels, a->n_det, trk_boxes, trk_scores,
-                              trk_ids, trk_labels, a->n_trk, bias, a->track_thresh, a->start_thresh, a->resume_thresh,
-                              a->nms_thresh, a->max_dormant_frames, a->pool_state, a->pool_capacity, a->out_boxes,
-                              a->out_scores, a->out_ids, a->out_labels, a->act_boxes, a->act_ids, a->act_labels,
-                              a->act_scores, a->record, stream);
-    if (rc) return rc;
+    if (stages & SMOT_STAGE_SOLVE) {
+        rc = smot_track_solve_fwd(a->det_boxes, a->det_scores, a->det_ids, a->det_labels, a->n_det, trk_boxes, trk_scores,
+                                  trk_ids, trk_labels, a->n_trk, bias, a->track_thresh, a->start_thresh, a->resume_thresh,
+                                  a->nms_thresh, a->max_dormant_frames, a->pool_state, a->pool_capacity, a->out_boxes,
+                                  a->out_scores, a->out_ids, a->out_labels, a->act_boxes, a->act_ids, a->act_labels,
+                                  a->act_scores, a->record, stream);
+        if (rc) return rc;
+    }
+    if (!(stages & SMOT_STAGE_EXTRACT)) return SMOT_OK;
     return smot_emm_extract_cache_masked_fwd(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->act_boxes,
                                              a->n_det + a->n_trk, a->pool_state + 4, a->rz, a->sampling_ratio,
                                              a->pad_pixels, a->search_expansion, a->min_search_wh, a->next_templates,

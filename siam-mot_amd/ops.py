@@ -502,6 +502,19 @@ def _geometry(features, scales, pad_pixels, device):
     return g
 
 
+def _geometry_refresh(g, features, device):
+    """The per-frame part of ``_geometry`` for a caller that keeps ``g``: same shapes, fp32, contiguous, on ``device`` ->
+    the pointer array is refilled and True is returned; anything else returns False (the caller takes the full path,
+    which raises or rebuilds)."""
+    fp, shapes = g.fp, g.shapes
+    for l in range(g.L):
+        f = features[l]
+        if f.shape != shapes[l] or not (f.is_cuda and f.dtype is _F32 and f.is_contiguous()) or f.device != device:
+            return False
+        fp[l] = f.data_ptr()
+    return True
+
+
 def _same_device(device, *named):
     for name, t in named:
         if t.device != device:
@@ -804,6 +817,7 @@ class HostRecordRing(object):
         n = 8 + 4 * track_solve_max_boxes() + 3 * pool_capacity
         self.dev = dev
         self.bufs = [torch.zeros((n,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.views = [b.numpy() for b in self.bufs]          # the same memory as numpy arrays (cheap element access)
         self.in_flight = [False, False]
         self.k = 0
         self.event = torch.cuda.Event()
@@ -814,21 +828,36 @@ class HostRecordRing(object):
             torch.cuda.current_stream(self.dev).synchronize()
             self.in_flight = [False, False]
         rec = self.bufs[self.k]
-        rec[3] = 0                    # the kernel stores the frame index (>= 1) here last: the host's completion flag
+        self.views[self.k][3] = 0     # the kernel stores the frame index (>= 1) here last: the host's completion flag
         self.in_flight[self.k] = True
         return rec
+
+    def view(self, rec):
+        """The numpy view of one of this ring's buffers."""
+        return self.views[0] if rec is self.bufs[0] else self.views[1]
 
     def record_event(self):
         """Record this ring's event on the device's current stream (behind the solver launch)."""
         self.event.record(torch.cuda.current_stream(self.dev))
         return self.event
 
-    def wait(self, rec):
-        """The frame's one synchronisation: poll the completion word of ``rec``, event fallback."""
-        wait_host_record(rec, self.event)
-        for i, b in enumerate(self.bufs):
-            if b is rec:
-                self.in_flight[i] = False
+    def wait(self, rec, event=True):
+        """The frame's one synchronisation: poll the completion word of ``rec``; if it does not show up, fall back to the
+        event recorded behind the launch (``record_event``) or — ``event=False``, nothing was recorded — to draining the
+        stream (a kernel fault would otherwise spin for ever)."""
+        i = 0 if rec is self.bufs[0] else 1
+        flag = self.views[i]
+        for _ in range(20000):
+            if flag[3] != 0:
+                break
+        else:
+            if event:
+                self.event.synchronize()
+            else:
+                torch.cuda.current_stream(self.dev).synchronize()
+            if flag[3] == 0:
+                raise RuntimeError("siammot_amd.track_solve: the solver kernel finished without completing its record")
+        self.in_flight[i] = False
 
 
 def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity,
@@ -851,13 +880,7 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
             segs.append((0, 0, 0, 0, 0))
             continue
         b, s_, i_, l_ = seg
-        if not (b.is_cuda and b.dtype is _F32 and b.is_contiguous() and s_.dtype is _F32 and s_.is_contiguous()
-                and i_.dtype is torch.int64 and i_.is_contiguous()):
-            raise RuntimeError("siammot_amd.track_solve: boxes/scores must be contiguous fp32 and ids int64 device tensors")
-        if b.device != dev:
-            raise RuntimeError("siammot_amd.track_solve: boxes live on %s, the pool state on %s" % (b.device, dev))
-        if l_ is not None and not (l_.dtype is torch.int64 and l_.is_contiguous() and l_.device == dev):
-            raise RuntimeError("siammot_amd.track_solve: labels must be a contiguous int64 tensor on the boxes' device")
+        _check_segment(b, s_, i_, l_, dev)
         segs.append((b.data_ptr(), s_.data_ptr(), i_.data_ptr(), l_.data_ptr() if l_ is not None else 0, b.shape[0]))
     M = segs[0][4] + segs[1][4]
     nrec = 8 + 4 * M + 3 * pool_capacity
@@ -1047,28 +1070,39 @@ def box_refine_post_max_rows():
     return (_lib or load_library()).smot_box_refine_post_max_rows()
 
 
-_FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "tpl_boxes", "sr", "templates", "order_hint",
-               "trk_ids", "trk_labels",
-               "predictor_params", "hann", "head_ws", "trk_boxes", "trk_conf",
-               "fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "reg_w", "reg_b", "refine_ws",
-               "ref_boxes", "ref_scores", "ref_ids", "ref_labels",
-               "det_boxes", "det_scores", "det_ids", "det_labels", "pool_state",
+_FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "predictor_params", "hann",
+               "fc6_w", "fc6_b", "fc7_w", "fc7_b", "cls_w", "cls_b", "reg_w", "reg_b", "pool_state",
+               # this frame: the head
+               "head_ws", "tpl_boxes", "sr", "templates", "order_hint", "trk_ids", "trk_labels", "trk_boxes", "trk_conf",
+               # this frame: refinement, detections, solver, next memory
+               "refine_ws", "ref_boxes", "ref_scores", "ref_ids", "ref_labels",
+               "det_boxes", "det_scores", "det_ids", "det_labels",
                "out_boxes", "out_scores", "out_ids", "out_labels", "act_boxes", "act_ids", "act_labels", "act_scores",
                "record", "next_templates", "next_sr", "next_order_hint")
-_FRAME_INTS = ("num_levels", "C", "n_trk", "n_det", "rx", "rz", "sampling_ratio", "gn_groups", "up", "use_centerness",
-               "refine", "box_pooled", "box_sampling_ratio", "dim6", "dim7", "num_classes", "reg_classes", "tracktor",
-               "max_dormant_frames", "pool_capacity")
-_FRAME_FLOATS = ("gn_eps", "pad_pixels", "one_minus_sigma", "sigma", "clip_w", "clip_h",
-                 "box_wx", "box_wy", "box_ww", "box_wh", "box_xform_clip",
-                 "track_thresh", "start_thresh", "resume_thresh", "nms_thresh", "search_expansion", "min_search_wh")
+_FRAME_INTS = ("n_trk", "stages", "n_det", "num_levels", "C", "rx", "rz", "sampling_ratio", "gn_groups", "up",
+               "use_centerness", "refine", "box_pooled", "box_sampling_ratio", "dim6", "dim7", "num_classes", "reg_classes",
+               "tracktor", "max_dormant_frames", "pool_capacity")
+_FRAME_FLOATS = ("track_thresh", "start_thresh", "resume_thresh", "gn_eps", "pad_pixels", "one_minus_sigma", "sigma",
+                 "clip_w", "clip_h", "box_wx", "box_wy", "box_ww", "box_wh", "box_xform_clip",
+                 "nms_thresh", "search_expansion", "min_search_wh")
+STAGE_HEAD, STAGE_REFINE, STAGE_SOLVE, STAGE_EXTRACT = 1, 2, 4, 8
 
 
 class FrameArgs(object):
-    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 46 pointers, 20 ints, 17 floats, in the header's
+    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 46 pointers, 21 ints, 17 floats, in the header's
     order.  Fields are plain Python attributes (``__slots__``); ``pack()`` writes all of them with one ``struct.pack_into``
-    (a ctypes.Structure costs ~0.4 us per field assignment — 30 us per frame for this block)."""
+    (a ctypes.Structure costs ~0.4 us per field assignment).  The fields that change from frame to frame are contiguous
+    inside each group: ``poke_head`` / ``poke_rest`` rewrite only those ranges of a block that was packed once."""
     __slots__ = _FRAME_PTRS + _FRAME_INTS + _FRAME_FLOATS + ("_buf", "_addr")
     _FMT = struct.Struct("<%dQ%di%df" % (len(_FRAME_PTRS), len(_FRAME_INTS), len(_FRAME_FLOATS)))
+    _HEAD0, _HEAD1 = _FRAME_PTRS.index("head_ws"), _FRAME_PTRS.index("trk_conf") + 1
+    _REST1 = len(_FRAME_PTRS)
+    _INT0 = 8 * len(_FRAME_PTRS)
+    _FLT0 = _INT0 + 4 * len(_FRAME_INTS)
+    _HEAD_FMT = struct.Struct("<%dQ" % (_HEAD1 - _HEAD0))
+    _REST_FMT = struct.Struct("<%dQ" % (_REST1 - _HEAD1))
+    _II = struct.Struct("<ii")
+    _FFF = struct.Struct("<fff")
 
     def __init__(self):
         for n in _FRAME_PTRS + _FRAME_INTS:
@@ -1084,21 +1118,63 @@ class FrameArgs(object):
                             *[float(g(n)) for n in _FRAME_FLOATS])
         return self._addr
 
+    def poke_head(self, ptrs, n_trk, stages):
+        """Rewrite the head's per-frame pointers (``head_ws`` .. ``trk_conf``, in that order; None = NULL) and
+        ``n_trk``, ``stages``."""
+        self._HEAD_FMT.pack_into(self._buf, 8 * self._HEAD0, *ptrs)
+        self._II.pack_into(self._buf, self._INT0, n_trk, stages)
+        return self._addr
 
-def track_frame(args, dev):
+    def poke_rest(self, ptrs, stages, n_det, thresholds):
+        """Rewrite the per-frame pointers behind the head's (``refine_ws`` .. ``next_order_hint``), ``stages``,
+        ``n_det`` and the three solver thresholds."""
+        self._REST_FMT.pack_into(self._buf, 8 * self._HEAD1, *ptrs)
+        self._II.pack_into(self._buf, self._INT0 + 4, stages, n_det)
+        self._FFF.pack_into(self._buf, self._FLT0, *thresholds)
+        return self._addr
+
+
+def track_frame(args, dev, addr=None):
     """``smot_track_frame_fwd``: head [+ box-head refinement] + solver + masked template extraction of ONE tracking frame
-    enqueued by one call (``args``: a filled ``FrameArgs``).  Launch only."""
+    (the stages ``args.stages`` selects) enqueued by one call.  ``args``: a filled ``FrameArgs``, packed here unless the
+    caller packed / poked it already and passes the block's address.  Launch only."""
     lib = _lib or load_library()
     cur = torch.cuda.current_device()
     if cur != dev.index:
         torch.cuda.set_device(dev.index)
     try:
-        rc = lib.smot_track_frame_fwd(args.pack(), _stream(dev))
+        rc = lib.smot_track_frame_fwd(args.pack() if addr is None else addr, _stream(dev))
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
     if rc:
         _check(rc, "track_frame")
+
+
+def track_frame_addr(lib, addr, dev, stream):
+    """``smot_track_frame_fwd`` on a block the caller keeps packed (``FrameArgs.poke_head`` / ``poke_rest``)."""
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+        try:
+            rc = lib.smot_track_frame_fwd(addr, stream)
+        finally:
+            torch.cuda.set_device(cur)
+    else:
+        rc = lib.smot_track_frame_fwd(addr, stream)
+    if rc:
+        _check(rc, "track_frame")
+
+
+def _check_segment(b, s_, i_, l_, dev):
+    """The solver's input contract for one segment (boxes, scores, ids, labels or None)."""
+    if not (b.is_cuda and b.dtype is _F32 and b.is_contiguous() and s_.dtype is _F32 and s_.is_contiguous()
+            and i_.dtype is torch.int64 and i_.is_contiguous()):
+        raise RuntimeError("siammot_amd.track_solve: boxes/scores must be contiguous fp32 and ids int64 device tensors")
+    if b.device != dev:
+        raise RuntimeError("siammot_amd.track_solve: boxes live on %s, the pool state on %s" % (b.device, dev))
+    if l_ is not None and not (l_.dtype is torch.int64 and l_.is_contiguous() and l_.device == dev):
+        raise RuntimeError("siammot_amd.track_solve: labels must be a contiguous int64 tensor on the boxes' device")
 
 
 def track_solve_max_boxes():

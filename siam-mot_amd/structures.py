@@ -32,6 +32,14 @@ class BoxList(object):
         self.mode = mode
         self.extra_fields = {}
 
+    @classmethod
+    def _wrap(cls, bbox, image_size, mode, fields):
+        """Internal constructor for tensors this package produced itself (fp32 ``[N,4]`` already): no conversion, no
+        checks; ``fields`` becomes the field dict (insertion order = field order)."""
+        o = cls.__new__(cls)
+        o.bbox, o.size, o.mode, o.extra_fields = bbox, image_size, mode, fields
+        return o
+
     # ---- fields -------------------------------------------------------------------
     def add_field(self, field, field_data):
         self.extra_fields[field] = field_data

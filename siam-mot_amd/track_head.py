@@ -20,7 +20,7 @@ import torch
 
 from . import ops
 from .emm import OrderHint
-from .structures import cat_boxlist
+from .structures import BoxList, cat_boxlist
 
 
 class TrackHead(torch.nn.Module):
@@ -110,6 +110,12 @@ class TrackHead(torch.nn.Module):
         return target[torch.tensor(rows, dtype=torch.int64, device=ids.device)]
 
 
+class _FramePlan(object):
+    """What ``TrackingLoop._frame_plan`` keeps between frames (see there)."""
+    __slots__ = ("dev", "emm", "solver", "pool", "refine", "g", "scales", "params", "hann", "rz", "rx", "C", "amodal",
+                 "ws_need", "lib", "args", "box_params", "box_ptrs", "box_amodal", "image_wh", "a_pp", "state")
+
+
 class TrackingLoop(torch.nn.Module):
     """One tracking step per frame: ``forward(features, detections) -> BoxList`` with track ids."""
 
@@ -124,24 +130,45 @@ class TrackingLoop(torch.nn.Module):
         self.track_memory = None
         self.track.reset_track_pool()
 
+    def __setattr__(self, name, value):
+        if name in ("track", "solver", "refine_tracks"):                 # what the per-frame caches below were built from
+            self.__dict__.pop("_lean_static", None)
+            self.__dict__.pop("_plan", None)
+        super(TrackingLoop, self).__setattr__(name, value)
+
     def _lean_ok(self, detections):
         """The per-frame fast path applies: this repository's EMM head, no box-head refinement or one with a
         device-only form (``refine_raw``), the one-launch solver, device tensors."""
-        if not hasattr(self.track.tracker, "track_raw"):
+        st = self.__dict__.get("_lean_static")
+        if st is None:                    # (submodule lookups go through nn.Module.__getattr__: once)
+            emm, solver = self.track.tracker, self.solver
+            st = self.__dict__["_lean_static"] = (emm, solver, hasattr(emm, "track_raw"),
+                                                  getattr(solver, "_device_path", None) is not None,
+                                                  ops.track_solve_max_boxes(), self.refine_tracks, {})
+        emm, solver, has_raw, has_device_path, max_boxes, refine, refine_ok = st
+        if not (has_raw and has_device_path):
             return False
-        if self.refine_tracks is not None:
-            mem = self.track_memory
-            ok = getattr(self.refine_tracks, "raw_ok", None)
-            if ok is None or (mem is not None and len(mem[2][0]) > 0 and not ok(len(mem[2][0]))):
-                return False
-        fast = getattr(self.solver, "_device_path", None)
-        if fast is None or not detections.bbox.is_cuda or self.track.tracker.rz != 15:
-            return False
-        if detections.mode != "xyxy" or not set(detections.fields()) <= self.solver._KERNEL_FIELDS:
-            return False                     # other box modes / extra fields: the general path keeps them
         mem = self.track_memory
-        n = len(detections) + (len(mem[2][0]) if mem is not None else 0)
-        return self.solver.nms_mask_fn is ops.nms_keep_mask and 0 < n <= ops.track_solve_max_boxes()
+        n_mem = len(mem[2][0]) if mem is not None else 0
+        if refine is not None and n_mem > 0:
+            # (what a box head can do for n rows follows from its layer shapes: asked once per row count)
+            r = refine_ok.get(n_mem)
+            if r is None:
+                ok = getattr(refine, "raw_ok", None)
+                one = getattr(getattr(refine, "box", None), "one_call_ok", None)
+                r = refine_ok[n_mem] = (ok is not None and bool(ok(n_mem)), one is not None and bool(one(n_mem)))
+            if not r[0]:
+                return False
+        elif refine is not None and getattr(refine, "raw_ok", None) is None:
+            return False
+        if not detections.bbox.is_cuda or emm.rz != 15 or detections.mode != "xyxy":
+            return False
+        kernel_fields = solver._KERNEL_FIELDS
+        for f in detections.fields():
+            if f not in kernel_fields:
+                return False                 # extra fields: the general path keeps them
+        n = len(detections) + n_mem
+        return solver.nms_mask_fn is ops.nms_keep_mask and 0 < n <= max_boxes
 
     def _step_lean(self, features, detections):
         """One frame with the minimum of host work between the launches: raw tensors into ``ops.emm_track``, the
@@ -178,25 +205,39 @@ class TrackingLoop(torch.nn.Module):
         ring.wait(rec_host)                                                        # the frame's one synchronisation
         return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre)
 
-    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre):
-        """After the record arrived: mirror the pool, slice the outputs, build the next track memory."""
-        emm, pool = self.track.tracker, self.solver.track_pool
-        ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
-        act_boxes = ab.view(M, 4)
-        rec = rec_host.numpy()[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
+    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None):
+        """After the record arrived: mirror the pool, slice the outputs, build the next track memory.  This is host work on
+        the frame's serial chain: ten strided views straight off the two output buffers (no intermediate splits), the
+        record through the ring's numpy view, BoxLists of this package's own class without re-validation."""
+        if P is not None:
+            emm, pool = P.emm, P.pool
+        else:
+            emm, pool = self.track.tracker, self.solver.track_pool
+        ring = pool._ring
+        view = ring.view(rec_host) if ring is not None and (rec_host is ring.bufs[0] or rec_host is ring.bufs[1]) else rec_host.numpy()
+        rec = view[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
         pool._mirror(rec, M)
-        oi, ol, ai, al = ibuf.split((M, M, M, M))
-        cls = detections.__class__
-        out = cls(ob.view(M, 4)[:K], detections.size, mode="xyxy")
-        out.add_field("ids", oi[:K])
-        out.add_field("scores", osc[:K])
-        out.add_field("labels", ol[:K])
+        cls, size = detections.__class__, detections.size
+        st = torch.as_strided
+        # fbuf = out_boxes [4M] | act_boxes [4M] | out_scores [M] | act_scores [M]; ibuf = out_ids | out_labels | act_ids | act_labels
+        ob, oi, osc, ol = st(fbuf, (K, 4), (4, 1), 0), st(ibuf, (K,), (1,), 0), st(fbuf, (K,), (1,), 8 * M), st(ibuf, (K,), (1,), M)
+        ab, ai, asc, al = (st(fbuf, (A, 4), (4, 1), 4 * M), st(ibuf, (A,), (1,), 2 * M), st(fbuf, (A,), (1,), 9 * M),
+                           st(ibuf, (A,), (1,), 3 * M))
+        own = cls is BoxList
+        if own:
+            out = BoxList._wrap(ob, size, "xyxy", {"ids": oi, "scores": osc, "labels": ol})
+            act = BoxList._wrap(ab, size, "xyxy", {"ids": ai, "scores": asc, "labels": al})
+        else:
+            out = cls(ob, size, mode="xyxy")
+            out.add_field("ids", oi)
+            out.add_field("scores", osc)
+            out.add_field("labels", ol)
+            act = cls(ab, size, mode="xyxy")
+            act.add_field("ids", ai)
+            act.add_field("scores", asc)
+            act.add_field("labels", al)
         out.host_ids = rec[8 + M:8 + M + K]
-        act = cls(act_boxes[:A], detections.size, mode="xyxy")
-        act.add_field("ids", ai[:A])
-        act.add_field("scores", asc[:A])
-        act.add_field("labels", al[:A])
         act.host_ids = rec[8 + 2 * M:8 + 2 * M + A].tolist()
         out.active_rows = act
         if A == 0 or pre is None:
@@ -204,150 +245,185 @@ class TrackingLoop(torch.nn.Module):
             self.track_memory = self.track.get_track_memory(features, [out])
             return out
         # (the extraction ranked exactly the rows of `act` — the first A of act_boxes — for the next frame's head)
-        memory = emm.wrap_cache(pre[0][:A], pre[1][:A], act, pre[2][:A] if len(pre) > 2 and pre[2] is not None else None)
+        hint = pre[2].narrow(0, 0, A) if len(pre) > 2 and pre[2] is not None else None
+        zv, srv = pre[0].narrow(0, 0, A), pre[1].narrow(0, 0, A)
+        if own and hint is None:
+            pad2 = emm.track_utils.pad_pixels * 2                                  # = EMM.wrap_cache
+            sr = BoxList._wrap(srv, [int(size[0] + pad2), int(size[1] + pad2)], "xyxy", dict(act.extra_fields))
+            memory = (zv, [sr], [act])
+        else:
+            memory = emm.wrap_cache(zv, srv, act, hint)
         if pool._dormant_ids:
             memory = self.track._update_memory_with_dormant_track(memory)
         pool.note_memory(memory, getattr(memory[2][0], "host_ids", act.host_ids))
-        self.track_memory = memory
-        return out
+        self.__dict__["track_memory"] = memory
+        self.__dict__["_own_memory"] = memory          # built here from this package's own kernels' outputs: the next
+        return out                                     # frame's head takes its tensors without re-checking them
 
-    # ---- the same frame behind ONE library call ------------------------------------------------------------------------
+    # ---- the same frame through the frame entry point: two calls on a block that stays packed -------------------------
     def _native_ok(self, detections):
         """``smot_track_frame_fwd`` applies: the one-launch path's conditions, the 15x15 template pooler's masked kernel
         and — with refinement — a box head whose whole chain fits ``smot_box_refine_fwd``."""
-        if not self.__dict__.get("native_frame", False):
-            return False              # opt-in (``loop.native_frame = True``): see _step_native
-        emm = self.track.tracker
-        fz = emm.feature_extractor.pooler_z
-        if not (emm.rz == 15 and fz.sampling_ratio == 2):
-            return False
-        mem = self.track_memory
-        n_trk = len(mem[2][0]) if mem is not None and mem[0].numel() > 0 else 0
-        if self.refine_tracks is not None and n_trk > 0:
-            box = getattr(self.refine_tracks, "box", None)
-            ok = getattr(box, "one_call_ok", None)
-            if ok is None or not ok(n_trk):
+        if not self.__dict__.get("native_frame", True):
+            return False              # (``loop.native_frame = False``: the Python-composed form, _step_lean)
+        P = self.__dict__.get("_plan")
+        if P is None:
+            emm = self.track.tracker
+            fz = emm.feature_extractor.pooler_z
+            if not (emm.rz == 15 and fz.sampling_ratio == 2):
                 return False
+        st = self.__dict__.get("_lean_static")
+        if st is not None and st[5] is not None:                         # with refinement: the box head's whole chain must
+            mem = self.track_memory                                      # fit smot_box_refine_fwd (asked by _lean_ok)
+            if mem is not None and mem[0].numel() > 0:
+                r = st[6].get(len(mem[2][0]))
+                if r is None or not r[1]:
+                    return False
+        elif st is None and self.refine_tracks is not None:
+            return False
         return True
 
-    def _native_state(self, dev):
-        """The argument block of ``smot_track_frame_fwd`` with everything that does not change from frame to frame."""
-        st = self.__dict__.get("_native")
-        if st is not None and st[1] == dev:
-            return st[0]
+    def _frame_plan(self, dev, features):
+        """Everything of a frame's argument block that stands while the video's geometry and the model stand: packed once
+        (``ops.FrameArgs``), re-packed when a feature shape, a weight pointer or the device changes."""
+        P = self.__dict__.get("_plan")
+        if P is not None and P.dev == dev and ops._geometry_refresh(P.g, features, dev):
+            return P
         emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
         tu = emm.track_utils
-        a = ops.FrameArgs()
         fe, pr = emm.feature_extractor.pooler_x, emm.predictor
+        P = _FramePlan()
+        P.dev, P.emm, P.solver, P.pool, P.refine = dev, emm, solver, pool, self.refine_tracks
+        P.g = g = ops._geometry(features, tuple(fe.scales), emm.pad_pixels, dev)       # validates (raises) and caches
+        P.scales = tuple(fe.scales)
+        P.params = pr.param_dict()
+        P.hann = ops.hann_window((emm.rx - emm.rz + 1) * ops.UP_SCALE, dev)
+        P.rz, P.rx, P.C, P.amodal = emm.rz, emm.rx, g.C, emm.amodal
+        P.ws_need, P.lib = {}, ops.load_library()
+        a = P.args = ops.FrameArgs()
+        a.feats, a.heights, a.widths, a.pad_cells, a.scales, a.num_levels, a.C = g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, g.C
+        a.hann = P.hann.data_ptr()
         a.rx, a.rz, a.sampling_ratio = emm.rx, emm.rz, fe.sampling_ratio
         a.gn_groups, a.gn_eps, a.up = pr.gn_groups, pr.gn_eps, ops.UP_SCALE
         a.use_centerness = 1 if emm.use_centerness else 0
         a.pad_pixels, a.one_minus_sigma, a.sigma = emm.pad_pixels, 1 - emm.sigma, emm.sigma
-        a.track_thresh, a.start_thresh, a.resume_thresh = solver.track_thresh, solver.start_thresh, solver.resume_track_thresh
         a.nms_thresh, a.max_dormant_frames, a.pool_capacity = solver.NMS_THRESH, pool._max_dormant_frames, pool.DEVICE_CAPACITY
         a.search_expansion, a.min_search_wh = tu.search_expansion, tu.min_search_wh
-        self.__dict__["_native"] = (a, dev)
-        return a
+        P.box_params, P.box_ptrs = None, None
+        if self.refine_tracks is not None:
+            box = self.refine_tracks.box
+            fx, pp_, cs, bp = box.feature_extractor, box.post_processor, box.predictor.cls_score, box.predictor.bbox_pred
+            P.box_params = (fx.fc6.weight, fx.fc6.bias, fx.fc7.weight, fx.fc7.bias, cs.weight, cs.bias, bp.weight, bp.bias)
+            a.refine, a.tracktor = 1, 1 if self.refine_tracks.tracktor else 0
+            a.box_pooled, a.box_sampling_ratio = fx.pooler.output_size[0], fx.pooler.sampling_ratio
+            a.dim6, a.dim7, a.num_classes, a.reg_classes = fx.fc6.out_features, fx.fc7.out_features, cs.out_features, bp.out_features // 4
+            bc = pp_.box_coder
+            a.box_wx, a.box_wy, a.box_ww, a.box_wh = bc.weights
+            a.box_xform_clip = bc.bbox_xform_clip
+            P.box_amodal = bool(pp_.amodal_inference)
+        P.image_wh = None
+        P.a_pp = None
+        P.state = None
+        self.__dict__["_plan"] = P
+        return P
 
     def _step_native(self, features, detections):
-        """``_step_lean`` with the frame's 5 (13 with refinement) launches behind one binding call: same kernels, same
-        arguments, same single synchronisation.  Host time to enqueue a frame with refinement: 43 us instead of 110
-        (measure/debug/loop_host_split.py) — but a frame is a serial chain (host work before the first launch -> GPU
-        chain -> record -> host bookkeeping) and ``_step_lean`` already enqueues its later launches WHILE the head runs,
-        whereas this form prepares every argument before its one call, so the first kernel starts ~20 us later: 0.165
-        vs 0.14 ms per frame without refinement, 0.23 vs 0.19 with.  Kept opt-in (``loop.native_frame = True``) for hosts
-        where Python time is scarcer than it is on the benchmark box; covered by the closed-loop tests."""
-        emm, solver, pool = self.track.tracker, self.solver, self.solver.track_pool
+        """``_step_lean`` through ``smot_track_frame_fwd``: same kernels, same arguments, same single synchronisation, two
+        binding calls per frame on an argument block that is packed once per video (``_frame_plan``) and of which only two
+        short ranges are rewritten per call.  A frame is a serial chain — host work before the first launch, the GPU chain,
+        the record, host bookkeeping — so the FIRST call (stage HEAD) goes out as soon as the head's nine pointers stand,
+        and the detections' segment, the output buffers and the remaining stages' call are prepared while the head runs.
+        (The first version of this path prepared all 80 fields before ONE call: the first kernel started 20 us later than
+        in the Python-composed form and the frame was slower, 0.165 vs 0.14 ms.)"""
         dev = detections.bbox.device
-        a = self._native_state(dev)
-        # thresholds may be changed between frames (bench.py does): cheap to refresh
-        a.track_thresh, a.start_thresh, a.resume_thresh = solver.track_thresh, solver.start_thresh, solver.resume_track_thresh
-        fe = emm.feature_extractor.pooler_x
-        g = ops._geometry(features, tuple(fe.scales), emm.pad_pixels, dev)
-        C = g.C
-        a.feats, a.heights, a.widths, a.pad_cells, a.scales, a.num_levels, a.C = g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, C
+        P = self._frame_plan(dev, features)
+        a, emm, solver, pool = P.args, P.emm, P.solver, P.pool
+        blk = ops._param_block(P.params)           # revalidated per frame (a dozen attribute reads): load_state_dict / .to()
         mem = self.track_memory
-        n_trk = 0
-        tf = ti = None
-        keep = []                                   # tensors that must outlive the call's argument block
-        a.order_hint = None
         if mem is None:
             pool.reset()                                                           # track_head.py:39-40
-        elif mem[0].numel() > 0:
+        size = detections.size
+        repack = False
+        if blk.a_pp != P.a_pp:
+            a.predictor_params, P.a_pp, repack = blk.a_pp, blk.a_pp, True
+        if size != P.image_wh:
+            P.image_wh = size
+            cw, ch = (0.0, 0.0) if P.amodal else (float(size[0]), float(size[1]))
+            if P.box_params is not None and P.box_amodal:
+                cw = ch = 0.0                   # (head and box head share the flag in the reference's cfg: INPUT.AMODAL)
+            a.clip_w, a.clip_h, repack = cw, ch, True
+        if P.box_params is not None:
+            ptrs = tuple([p_.data_ptr() for p_ in P.box_params])
+            if ptrs != P.box_ptrs:
+                P.box_ptrs = ptrs
+                a.fc6_w, a.fc6_b, a.fc7_w, a.fc7_b, a.cls_w, a.cls_b, a.reg_w, a.reg_b = ptrs
+                repack = True
+        state = pool.device_state(dev)
+        if state is not P.state:
+            P.state, a.pool_state, repack = state, state.data_ptr(), True
+        if repack:
+            a.pack()
+        n_trk = 0
+        tf = ti = None
+        stream = ops._stream(dev)
+        if mem is not None and mem[0].numel() > 0:
             z, sr, tb = mem
-            tb0 = tb[0]
-            n_trk = len(tb0)
-            tbb, srb = ops._chk(tb0.bbox, "template boxes", (n_trk, 4)), ops._chk(sr[0].bbox, "sr", (n_trk, 4))
-            fe_scales = emm.__dict__["_static"][1] if "_static" in emm.__dict__ else tuple(fe.scales)
-            hint = OrderHint.lookup(sr[0], tb0.bbox, sr[0].bbox, fe_scales)
-            a.order_hint = hint.data_ptr() if hint is not None else None
-            keep.append(hint)
-            zc = ops._chk(z, "template_features", (n_trk, C, emm.rz, emm.rz))
+            tb0, sr0 = tb[0], sr[0]
+            tbb, srb = tb0.bbox, sr0.bbox
+            n_trk = tbb.shape[0]
             ids_t, lab_t = tb0.get_field("ids"), tb0.get_field("labels")
-            if not (ids_t.is_contiguous() and lab_t.is_contiguous() and ids_t.dtype is torch.int64 and lab_t.dtype is torch.int64):
-                ids_t, lab_t = ids_t.to(torch.int64).contiguous(), lab_t.to(torch.int64).contiguous()
-            keep += [tbb, srb, zc, ids_t, lab_t]
-            a.tpl_boxes, a.sr, a.templates = tbb.data_ptr(), srb.data_ptr(), zc.data_ptr()
-            a.trk_ids, a.trk_labels = ids_t.data_ptr(), lab_t.data_ptr()
-            blk = ops._param_block(emm.predictor.param_dict())
-            a.predictor_params = blk.a_pp
-            a.hann = ops.hann_window((emm.rx - emm.rz + 1) * ops.UP_SCALE, dev).data_ptr()
-            lib = ops.load_library()
-            a.head_ws = ops._workspace(dev, lib.smot_emm_track_ws_floats(n_trk, C, emm.rx, emm.rz), ops._stream(dev).value).data_ptr()
-            cw, ch = (0.0, 0.0) if emm.amodal else (float(tb0.size[0]), float(tb0.size[1]))
-            a.clip_w, a.clip_h = cw, ch
+            if mem is not self.__dict__.get("_own_memory"):      # a memory this loop did not build itself: full checks
+                tbb, srb = ops._chk(tbb, "template boxes", (n_trk, 4)), ops._chk(srb, "sr", (n_trk, 4))
+                z = ops._chk(z, "template_features", (n_trk, P.C, P.rz, P.rz))
+                if not (ids_t.is_contiguous() and lab_t.is_contiguous() and ids_t.dtype is torch.int64 and lab_t.dtype is torch.int64):
+                    ids_t, lab_t = ids_t.to(torch.int64).contiguous(), lab_t.to(torch.int64).contiguous()
+                ops._same_device(dev, ("template boxes", tbb), ("sr", srb), ("template_features", z), ("ids", ids_t),
+                                 ("labels", lab_t))
+            hint = OrderHint.lookup(sr0, tb0.bbox, sr0.bbox, P.scales) if "order_hint" in sr0.__dict__ else None
+            need = P.ws_need.get(n_trk)
+            if need is None:
+                need = P.ws_need[n_trk] = (
+                    int(P.lib.smot_emm_track_ws_floats(n_trk, P.C, P.rx, P.rz)),
+                    int(P.lib.smot_box_refine_ws_floats(n_trk, P.C, a.box_pooled, a.dim6, a.dim7, a.num_classes, a.reg_classes))
+                    if a.refine else 0)
             tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = tf.data_ptr()
-            a.trk_boxes, a.trk_conf = p, p + 16 * n_trk
-            a.ref_boxes, a.ref_scores = p + 20 * n_trk, p + 36 * n_trk
-            keep.append(tf)
-            a.refine = 0
-            if self.refine_tracks is not None:
-                box = self.refine_tracks.box
-                fx, pp_, cs, bp = box.feature_extractor, box.post_processor, box.predictor.cls_score, box.predictor.bbox_pred
-                a.refine, a.tracktor = 1, 1 if self.refine_tracks.tracktor else 0
-                a.fc6_w, a.fc6_b, a.fc7_w, a.fc7_b = (fx.fc6.weight.data_ptr(), fx.fc6.bias.data_ptr(),
-                                                      fx.fc7.weight.data_ptr(), fx.fc7.bias.data_ptr())
-                a.cls_w, a.cls_b, a.reg_w, a.reg_b = cs.weight.data_ptr(), cs.bias.data_ptr(), bp.weight.data_ptr(), bp.bias.data_ptr()
-                a.box_pooled, a.box_sampling_ratio = fx.pooler.output_size[0], fx.pooler.sampling_ratio
-                a.dim6, a.dim7, a.num_classes, a.reg_classes = fx.fc6.out_features, fx.fc7.out_features, cs.out_features, bp.out_features // 4
-                bc = pp_.box_coder
-                a.box_wx, a.box_wy, a.box_ww, a.box_wh = bc.weights
-                a.box_xform_clip = bc.bbox_xform_clip
-                if pp_.amodal_inference:
-                    a.clip_w = a.clip_h = 0.0       # (head and box head share the flag in the reference's cfg: INPUT.AMODAL)
-                need = int(lib.smot_box_refine_ws_floats(n_trk, C, a.box_pooled, a.dim6, a.dim7, a.num_classes, a.reg_classes))
-                a.refine_ws = ops._workspace(dev, need, ("refine", ops._stream(dev).value)).data_ptr()
-                ti = torch.empty((2 * n_trk,), dtype=torch.int64, device=dev)
-                a.ref_ids, a.ref_labels = ti.data_ptr(), ti.data_ptr() + 8 * n_trk
-                keep.append(ti)
-        a.n_trk = n_trk
+            addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), tbb.data_ptr(), srb.data_ptr(),
+                                z.data_ptr(), hint.data_ptr() if hint is not None else 0, ids_t.data_ptr(),
+                                lab_t.data_ptr(), p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
+            ops.track_frame_addr(P.lib, addr, dev, stream)                         # the head is running from here on
+        # ---- while the head runs: detections, output buffers, the remaining stages --------------------------------------
         seg = solver._segment(detections)
         n_det = 0
+        d0 = d1 = d2 = d3 = 0
         if seg is not None:
             db, dsc, did, dlab = seg
+            ops._check_segment(db, dsc, did, dlab, dev)
             n_det = db.shape[0]
-            a.det_boxes, a.det_scores, a.det_ids = db.data_ptr(), dsc.data_ptr(), did.data_ptr()
-            a.det_labels = dlab.data_ptr() if dlab is not None else None
-            keep += [db, dsc, did, dlab]
-        a.n_det = n_det
+            d0, d1, d2, d3 = db.data_ptr(), dsc.data_ptr(), did.data_ptr(), (dlab.data_ptr() if dlab is not None else 0)
         M = n_det + n_trk
-        state = pool.device_state(dev)
         ring = pool.host_record_ring(dev)
         fbuf = torch.empty((10 * M,), dtype=torch.float32, device=dev)
         ibuf = torch.empty((4 * M,), dtype=torch.int64, device=dev)
-        templates = torch.empty((M, C, emm.rz, emm.rz), dtype=torch.float32, device=dev)
+        templates = torch.empty((M, P.C, P.rz, P.rz), dtype=torch.float32, device=dev)
         sr_next = torch.empty((M, 4), dtype=torch.float32, device=dev)
-        a.next_order_hint = None      # (not asked for in the loop: see EMM.extract_cache_rows)
         rec_host = ring.next()
         fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
-        a.pool_state = state.data_ptr()
-        a.out_boxes, a.act_boxes, a.out_scores, a.act_scores = fp, fp + 16 * M, fp + 32 * M, fp + 36 * M
-        a.out_ids, a.out_labels, a.act_ids, a.act_labels = ip, ip + 8 * M, ip + 16 * M, ip + 24 * M
-        a.record = rec_host.data_ptr()
-        a.next_templates, a.next_sr = templates.data_ptr(), sr_next.data_ptr()
-        ops.track_frame(a, dev)
-        ring.record_event()
+        rw = r0 = r1 = r2 = r3 = 0
+        stages = ops.STAGE_SOLVE | ops.STAGE_EXTRACT
+        if n_trk > 0:
+            if a.refine:
+                ti = torch.empty((2 * n_trk,), dtype=torch.int64, device=dev)
+                p = tf.data_ptr()
+                rw = ops._workspace(dev, need[1], ("refine", stream.value)).data_ptr()
+                r0, r1, r2, r3 = p + 20 * n_trk, p + 36 * n_trk, ti.data_ptr(), ti.data_ptr() + 8 * n_trk
+                stages |= ops.STAGE_REFINE
+        addr = a.poke_rest((rw, r0, r1, r2, r3, d0, d1, d2, d3,
+                            fp, fp + 32 * M, ip, ip + 8 * M,                       # out_boxes, out_scores, out_ids, out_labels
+                            fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,    # act_boxes, act_ids, act_labels, act_scores
+                            rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), 0),
+                           stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh))
+        ops.track_frame_addr(P.lib, addr, dev, stream)
         if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
             hook = emm.__dict__.get("raw_output_hook")
             if hook is not None:
@@ -356,8 +432,8 @@ class TrackingLoop(torch.nn.Module):
                 hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
                 if hook is not None:
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
-        ring.wait(rec_host)                                                        # the frame's one synchronisation
-        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next))
+        ring.wait(rec_host, event=False)                                           # the frame's one synchronisation
+        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P)
 
     @torch.no_grad()
     def forward(self, features, detections):
