@@ -36,12 +36,45 @@ struct BoxRefineArgs {
     float* out_scores;       // [N]
     long long* out_ids;      // [N]
     long long* out_labels;   // [N]
+    // the head's output still as the K-slice partial sums of linear_rows_partial_kernel (logits == nullptr): S slices of
+    // [rows_pad][64] (one neuron block: ldo <= 64), summed here in slice order + bias — the arithmetic of
+    // linear_rows_reduce_kernel, one launch fewer
+    const float* part;
+    int S, rows_pad;
+    const float* cls_b;      // [K] or nullptr
+    const float* reg_b;      // [4*KR] or nullptr
 };
+constexpr int BR_PART_ROWS = 64, BR_PART_COLS = 64;
 
+template <bool PART>
 __global__ void __launch_bounds__(BR_MAXN) box_refine_post_kernel(BoxRefineArgs A, int N) {
     __shared__ int slab[BR_MAXN];
     __shared__ float sdet[BR_MAXN];
+    __shared__ float head[PART ? BR_PART_ROWS * BR_PART_COLS : 1];
     const int i = threadIdx.x;
+    if constexpr (PART) {
+        // thread = (row, column) of the head's output: S independent loads (one round trip), ordered adds, bias
+        const size_t stride = (size_t)A.rows_pad * 64;                       // between K slices (one neuron block)
+        for (int e = threadIdx.x; e < N * A.ldo; e += BR_MAXN) {
+            const int m = e / A.ldo, n = e - m * A.ldo;
+            const float* __restrict__ p = A.part + (size_t)m * 64 + n;
+            float v = 0.0f;
+            for (int s0 = 0; s0 < A.S; s0 += 32) {
+                float t[32];
+#pragma unroll
+                for (int q = 0; q < 32; ++q) t[q] = p[(size_t)min(s0 + q, A.S - 1) * stride];      // unconditional (clamped)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 32; ++q)
+                    if (s0 + q < A.S) v = add_rn(v, t[q]);
+            }
+            const float* bsel = n >= A.K ? (A.reg_b != nullptr ? A.reg_b + (n - A.K) : nullptr)
+                                         : (A.cls_b != nullptr ? A.cls_b + n : nullptr);
+            if (bsel != nullptr) v = add_rn(v, *bsel);
+            head[e] = v;
+        }
+        __syncthreads();
+    }
     int lab = 0;
     float det = 0.0f;
     float bx1 = 0.f, by1 = 0.f, bx2 = 0.f, by2 = 0.f;
@@ -49,7 +82,7 @@ __global__ void __launch_bounds__(BR_MAXN) box_refine_post_kernel(BoxRefineArgs 
     if (i < N) {
         lab = min(max((int)A.labels[i], 0), A.K - 1);        // (memory safety: a label outside [0, K) would index past the row)
         id = A.ids[i];
-        const float* row = A.logits + (size_t)i * A.ldo;
+        const float* row = PART ? head + i * A.ldo : A.logits + (size_t)i * A.ldo;
         // F.softmax(class_logits, -1): max, exp of the difference, sum in class order, divide
         float m = row[0];
         for (int k = 1; k < A.K; ++k) m = fmaxf(m, row[k]);
@@ -144,7 +177,10 @@ extern "C" int smot_box_refine_post_fwd(const float* head_out, int ld, int num_c
     A.out_scores = out_scores;
     A.out_ids = (long long*)out_ids;
     A.out_labels = (long long*)out_labels;
-    hipLaunchKernelGGL(box_refine_post_kernel, dim3(1), dim3(BR_MAXN), 0, (hipStream_t)stream, A, N);
+    A.part = nullptr;
+    A.S = A.rows_pad = 0;
+    A.cls_b = A.reg_b = nullptr;
+    hipLaunchKernelGGL(box_refine_post_kernel<false>, dim3(1), dim3(BR_MAXN), 0, (hipStream_t)stream, A, N);
     return check_launch("box_refine_post");
 }
 
@@ -160,6 +196,9 @@ int launch_linear_rows(const float* x, int M, int K, const float* W, const float
                        float* y, int ldy, hipStream_t st);                                              // linear_rows.hip
 int launch_linear_rows2(const float* x, int M, int K, const float* W, const float* bias, int N1, const float* W2,
                         const float* bias2, int N2, int relu, float* ws, float* y, int ldy, hipStream_t st);
+void linear_rows_layout(int M, int K, int N, int* S, int* nblk, int* rows_pad);
+int launch_linear_rows_chain(const float* x, int M, int K, const float* WA, const float* bA, int NA, int reluA, float* ws_a,
+                             const float* WB, int N1, const float* WB2, int N2, float* ws_b, hipStream_t st, int* rc);
 }
 extern "C" long long smot_linear_rows_ws_floats(int M, int K, int N);
 
@@ -172,9 +211,9 @@ extern "C" long long smot_box_refine_ws_floats(int N, int C, int pooled, int dim
     long long g = smot_linear_rows_ws_floats(N, K0, dim6);
     const long long g7 = smot_linear_rows_ws_floats(N, dim6, dim7), gh = smot_linear_rows_ws_floats(N, dim7, num_classes + 4 * reg_classes);
     if (g7 > g) g = g7;
-    if (gh > g) g = gh;
+    // (the head's K-slice sums have a region of their own: the head reads fc7's slices while it writes its own)
     return (long long)(br_align4((size_t)N * K0) + br_align4((size_t)N * dim6) + br_align4((size_t)N * dim7) +
-                       br_align4((size_t)N * NH)) + g;
+                       br_align4((size_t)N * NH)) + (long long)br_align4((size_t)g) + gh;
 }
 
 extern "C" int smot_box_refine_fwd(const float* const* feats, const int* heights, const int* widths, const float* scales,
@@ -208,13 +247,65 @@ extern "C" int smot_box_refine_fwd(const float* const* feats, const int* heights
     float* h7 = h6 + br_align4((size_t)N * dim6);
     float* ho = h7 + br_align4((size_t)N * dim7);
     float* gw = ho + br_align4((size_t)N * NH);
+    long long g67 = smot_linear_rows_ws_floats(N, K0, dim6);
+    const long long g7 = smot_linear_rows_ws_floats(N, dim6, dim7);
+    if (g7 > g67) g67 = g7;
+    float* gh = gw + br_align4((size_t)g67);                                                  // the head's K-slice sums
     rc = launch_roi_pool_separable(P, C, boxes, boxes, N, pooled, x0, nullptr, st);          // Pooler: level of the roi itself
     if (rc) return rc;
     if ((rc = launch_linear_rows(x0, N, K0, fc6_w, fc6_b, dim6, 1, gw, h6, dim6, st))) return rc;
-    if ((rc = launch_linear_rows(h6, N, dim6, fc7_w, fc7_b, dim7, 1, gw, h7, dim7, st))) return rc;
-    // cls_score | bbox_pred side by side in one launch pair
-    if ((rc = launch_linear_rows2(h7, N, dim7, cls_w, cls_b, num_classes, reg_w, reg_b, 4 * reg_classes, 0, gw, ho, NH, st)))
-        return rc;
-    return smot_box_refine_post_fwd(ho, NH, num_classes, reg_classes, boxes, labels, ids, track_conf, N, wx, wy, ww, wh,
-                                    xform_clip, clip_w, clip_h, tracktor, out_boxes, out_scores, out_ids, out_labels, stream);
+    // cls_score | bbox_pred side by side in one launch; their K-slice sums are added by the post-processing kernel while
+    // it loads (heads of up to 64 columns: one neuron block), otherwise by the usual reduction launch — and fc7's sums
+    // by the head's launch while IT loads (launch_linear_rows_chain): 6 launches instead of 8
+    int S = 0, nblk = 0, rows_pad = 0;
+    linear_rows_layout(N, dim7, NH, &S, &nblk, &rows_pad);
+    const bool in_post = nblk == 1 && NH <= BR_PART_COLS && N <= BR_PART_ROWS;
+    int chained = 0;
+    if (in_post) {
+        chained = launch_linear_rows_chain(h6, N, dim6, fc7_w, fc7_b, dim7, 1, gw, cls_w, num_classes, reg_w, 4 * reg_classes,
+                                           gh, st, &rc);
+        if (rc) return rc;
+    }
+    if (!chained) {
+        if ((rc = launch_linear_rows(h6, N, dim6, fc7_w, fc7_b, dim7, 1, gw, h7, dim7, st))) return rc;
+        if ((rc = launch_linear_rows2(h7, N, dim7, cls_w, cls_b, num_classes, reg_w, reg_b, 4 * reg_classes, 0, gh,
+                                      in_post ? nullptr : ho, NH, st)))
+            return rc;
+    }
+    if (!in_post)
+        return smot_box_refine_post_fwd(ho, NH, num_classes, reg_classes, boxes, labels, ids, track_conf, N, wx, wy, ww,
+                                        wh, xform_clip, clip_w, clip_h, tracktor, out_boxes, out_scores, out_ids,
+                                        out_labels, stream);
+    SMOT_REQUIRE(num_classes >= 2 && (reg_classes == num_classes || reg_classes == 2), "box_refine: bad head shape K=%d KR=%d",
+                 num_classes, reg_classes);
+    SMOT_REQUIRE(wx > 0.f && wy > 0.f && ww > 0.f && wh > 0.f, "box_refine: regression weights must be positive");
+    SMOT_REQUIRE(labels && ids && track_conf && out_boxes && out_scores && out_ids && out_labels, "box_refine: null pointer");
+    BoxRefineArgs A;
+    A.logits = nullptr;
+    A.ldo = NH;
+    A.K = num_classes;
+    A.KR = reg_classes;
+    A.boxes = boxes;
+    A.labels = (const long long*)labels;
+    A.ids = (const long long*)ids;
+    A.track_conf = track_conf;
+    A.wx = wx;
+    A.wy = wy;
+    A.ww = ww;
+    A.wh = wh;
+    A.xform_clip = xform_clip;
+    A.clip_w = clip_w;
+    A.clip_h = clip_h;
+    A.tracktor = tracktor;
+    A.out_boxes = out_boxes;
+    A.out_scores = out_scores;
+    A.out_ids = (long long*)out_ids;
+    A.out_labels = (long long*)out_labels;
+    A.part = gh;
+    A.S = S;
+    A.rows_pad = rows_pad;
+    A.cls_b = cls_b;
+    A.reg_b = reg_b;
+    hipLaunchKernelGGL(box_refine_post_kernel<true>, dim3(1), dim3(BR_MAXN), 0, st, A, N);
+    return check_launch("box_refine_post");
 }

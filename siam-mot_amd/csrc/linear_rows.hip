@@ -116,6 +116,105 @@ linear_rows_partial_kernel(const float* __restrict__ x, int M, int K, const floa
     }
 }
 
+// The same layer with its input still in the K-slice partial sums of the PREVIOUS layer (xp: SX slices of
+// [nblk_x][rows_pad][64], that layer's bias bx and ReLU applied here, in linear_rows_reduce_kernel's order: slices in
+// order, then the bias, then the ReLU): the previous layer's reduction launch disappears.  For layers whose own K slice is
+// one 64-k step (kslice == 64: the head behind fc7), so that a workgroup's x slice is exactly one neuron block of the
+// previous layer and the extra loads (SX per element instead of one) stay a single round trip.
+template <int MT>
+__global__ void __launch_bounds__(256)
+linear_rows_partial_xpart_kernel(const float* __restrict__ xp, int SX, int nblk_x, const float* __restrict__ bx, int relu_x,
+                                 int M, int K, const float* __restrict__ W, int N, const float* __restrict__ W2, int N1,
+                                 float* __restrict__ part) {
+    constexpr int SMAX = 16;                       // slices of the previous layer summed per load batch
+    __shared__ __attribute__((aligned(16))) float xs[MT * 16][LR_XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nb = blockIdx.x, s = blockIdx.y;
+    const int k0 = s * LR_KS;                      // this workgroup's 64 k = neuron block s of the previous layer
+    const int n = nb * LR_NB + wave * 16 + (lane & 15);
+    const int kq = lane >> 4;
+    const bool n_ok = n < N;
+    const int nc = min(n, N - 1);
+    const float* __restrict__ wrow = (W2 != nullptr && nc >= N1) ? W2 + (size_t)(nc - N1) * K : W + (size_t)nc * K;
+    const int xr = tid >> 4, xk = (tid & 15) * 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 wreg[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) wreg[h] = *reinterpret_cast<const float4*>(wrow + min(k0 + 16 * h + 4 * kq, K - 4));
+    const size_t xstride = (size_t)nblk_x * (MT * 16) * LR_NB;      // between the previous layer's K slices
+    float4 xsum[MT];
+#pragma unroll
+    for (int q = 0; q < MT; ++q) xsum[q] = zero4;
+    for (int s0 = 0; s0 < SX; s0 += SMAX) {
+        float4 t[MT][SMAX];
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j)
+                t[q][j] = *reinterpret_cast<const float4*>(xp + (size_t)min(s0 + j, SX - 1) * xstride +
+                                                           ((size_t)s * (MT * 16) + xr + 16 * q) * LR_NB + xk);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < MT; ++q)
+#pragma unroll
+            for (int j = 0; j < SMAX; ++j)
+                if (s0 + j < SX) {
+                    xsum[q].x = add_rn(xsum[q].x, t[q][j].x);
+                    xsum[q].y = add_rn(xsum[q].y, t[q][j].y);
+                    xsum[q].z = add_rn(xsum[q].z, t[q][j].z);
+                    xsum[q].w = add_rn(xsum[q].w, t[q][j].w);
+                }
+    }
+    float4 b4 = zero4;
+    if (bx != nullptr) b4 = *reinterpret_cast<const float4*>(bx + k0 + xk);
+#pragma unroll
+    for (int q = 0; q < MT; ++q) {
+        float4 v = xsum[q];
+        if (bx != nullptr) {
+            v.x = add_rn(v.x, b4.x);
+            v.y = add_rn(v.y, b4.y);
+            v.z = add_rn(v.z, b4.z);
+            v.w = add_rn(v.w, b4.w);
+        }
+        if (relu_x) {
+            v.x = fmaxf(v.x, 0.0f);
+            v.y = fmaxf(v.y, 0.0f);
+            v.z = fmaxf(v.z, 0.0f);
+            v.w = fmaxf(v.w, 0.0f);
+        }
+        if (!(xr + 16 * q < M)) v = zero4;
+        *reinterpret_cast<float4*>(&xs[xr + 16 * q][xk]) = v;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (!n_ok) wreg[h] = zero4;
+    __syncthreads();
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float a4[4] = {wreg[h].x, wreg[h].y, wreg[h].z, wreg[h].w};
+        float4 b4m[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) b4m[t] = *reinterpret_cast<const float4*>(&xs[t * 16 + (lane & 15)][16 * h + 4 * kq]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const float b = j == 0 ? b4m[t].x : (j == 1 ? b4m[t].y : (j == 2 ? b4m[t].z : b4m[t].w));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b, acc[t], 0, 0, 0);
+            }
+    }
+    float* __restrict__ p = part + ((size_t)(s * gridDim.x + nb) * (MT * 16)) * LR_NB;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int row = t * 16 + (lane & 15);
+        *reinterpret_cast<float4*>(p + (size_t)row * LR_NB + wave * 16 + 4 * (lane >> 4)) =
+            make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 linear_rows_reduce_kernel(const float* __restrict__ part, int S, int nblk, int rows_pad, int M, int N,
                           const float* __restrict__ bias, const float* __restrict__ bias2, int N1, int relu,
@@ -173,9 +272,49 @@ int launch_linear_rows2(const float* x, int M, int K, const float* W, const floa
         case 3: hipLaunchKernelGGL(linear_rows_partial_kernel<3>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
         default: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
     }
-    hipLaunchKernelGGL(linear_rows_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, (const float*)ws, P.S, P.nblk,
-                       P.mt * 16, M, N, bias, bias2, N1, relu, y, ldy);
+    // y == nullptr: the consumer adds the K slices itself while it loads (linear_rows_layout tells it where they are;
+    // box_refine_post_kernel does for cls_score | bbox_pred: one launch fewer on a chain of 3-4 us kernels)
+    if (y != nullptr)
+        hipLaunchKernelGGL(linear_rows_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, (const float*)ws, P.S,
+                           P.nblk, P.mt * 16, M, N, bias, bias2, N1, relu, y, ldy);
     return check_launch("linear_rows");
+}
+
+// Two layers back to back without the first one's reduction launch: layer A (x [M,K] -> NA, bias/ReLU applied by the
+// consumer) leaves its K-slice sums in ws_a, layer B (NA -> N1 | N2, two weight matrices side by side) reads them
+// (linear_rows_partial_xpart_kernel) and leaves ITS K-slice sums in ws_b for a consumer that adds them while loading
+// (box_refine_post_kernel).  Applies when layer B's K slice is one 64-k step; returns 0 when it does not (nothing is
+// launched: the caller uses the launch pairs).
+int launch_linear_rows_chain(const float* x, int M, int K, const float* WA, const float* bA, int NA, int reluA, float* ws_a,
+                             const float* WB, int N1, const float* WB2, int N2, float* ws_b, hipStream_t st, int* rc) {
+    const int NB = N1 + N2;
+    const LinearRowsPlan PA = linear_rows_plan(M, K, NA), PB = linear_rows_plan(M, NA, NB);
+    *rc = SMOT_OK;
+    if (!(PB.kslice == LR_KS && (NA % LR_NB) == 0 && PB.S == PA.nblk)) return 0;
+    dim3 ga(PA.nblk, PA.S), gb(PB.nblk, PB.S);
+    switch (PA.mt) {
+        case 1: hipLaunchKernelGGL(linear_rows_partial_kernel<1>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 2: hipLaunchKernelGGL(linear_rows_partial_kernel<2>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 3: hipLaunchKernelGGL(linear_rows_partial_kernel<3>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+    }
+    switch (PA.mt) {
+        case 1: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<1>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 2: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<2>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 3: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<3>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<4>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+    }
+    *rc = check_launch("linear_rows_chain");
+    return 1;
+}
+
+// Where launch_linear_rows2(..., y = nullptr) leaves the partial sums: element (row m, neuron n) of K slice s sits at
+// ws[(s * nblk + n / 64) * rows_pad * 64 + m * 64 + n % 64]; the layer's value is their sum IN SLICE ORDER, then + bias.
+void linear_rows_layout(int M, int K, int N, int* S, int* nblk, int* rows_pad) {
+    const LinearRowsPlan P = linear_rows_plan(M, K, N);
+    *S = P.S;
+    *nblk = P.nblk;
+    *rows_pad = P.mt * 16;
 }
 
 int launch_linear_rows(const float* x, int M, int K, const float* W, const float* bias, int N, int relu, float* ws,

@@ -194,6 +194,47 @@ def test_linear_rows_matches_the_library_gemm(M, K, N, relu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,dim6,dim7,classes", [(30, 1024, 1024, 2), (64, 1024, 1024, 2), (1, 1024, 1024, 2), (17, 128, 64, 3),
+                                                 (30, 96, 100, 2), (9, 256, 1024, 14), (30, 64, 128, 16)])
+def test_one_call_refinement_equals_the_stage_wise_composition_bitwise(n, dim6, dim7, classes):
+    """``smot_box_refine_fwd`` skips two reduction launches where the layer shapes allow (the head's launch adds fc7's K
+    slices while it loads, the post-processing kernel adds the head's): the slices are added in the order and with the
+    bias / ReLU placement of the reduction kernel, so the result must equal pooler -> linear_rows x 3 -> box_refine_post
+    bit for bit — at the yaml's 1024-1024 head, at 64 rows and one row, at widths where the chain applies with fewer
+    slices, where it does not (fc7 width not a multiple of 64), and at heads of 70 / 80 columns (more than one neuron
+    block: both reductions are launches again)."""
+    import siammot_amd.ops as ops
+    g = torch.Generator().manual_seed(n * 7 + dim7)
+    C, scales = 16, (0.25, 0.125, 0.0625, 0.03125)
+    feats = tuple(torch.randn((1, C, 352 // s_, 640 // s_), generator=g).cuda() for s_ in (1, 2, 4, 8))
+    xy = torch.rand((n, 2), generator=g) * torch.tensor([1000.0, 500.0])
+    wh = 20.0 + torch.rand((n, 2), generator=g) * 200.0
+    boxes = torch.cat((xy, xy + wh), 1).cuda()
+    labels = torch.randint(1, classes, (n,), generator=g).cuda()
+    ids = torch.arange(n).cuda()
+    conf = torch.rand((n,), generator=g).cuda()
+
+    def lin(o, i):
+        return (torch.randn((o, i), generator=g) / i ** 0.5).cuda(), torch.randn((o,), generator=g).mul(0.1).cuda()
+    w6, b6 = lin(dim6, C * 49)
+    w7, b7 = lin(dim7, dim6)
+    wc, bc = lin(classes, dim7)
+    wr, br = lin(4 * classes, dim7)
+    weights, clip = (10.0, 10.0, 5.0, 5.0), 4.135
+    one = ops.box_refine(feats, scales, 7, 2, boxes, labels, ids, conf, (w6, b6, w7, b7, wc, bc, wr, br), weights, clip,
+                         (1280, 704))
+    x = ops.roi_align_levels(feats, boxes, boxes, 7, scales, 2).reshape(n, -1)
+    h6 = ops.linear_rows(x, w6, b6, relu=True)
+    h7 = ops.linear_rows(h6, w7, b7, relu=True)
+    ho = torch.empty((n, 5 * classes), device="cuda")
+    ops.linear_rows(h7, wc, bc, out=ho[:, :classes])
+    ops.linear_rows(h7, wr, br, out=ho[:, classes:])
+    staged = ops.box_refine_post(ho, classes, classes, boxes, labels, ids, conf, weights, clip, (1280, 704))
+    for a, b in zip(one, staged):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 def test_tracking_loop_with_refine_tracks_runs_the_reference_order():
     """TrackingLoop(refine_tracks=RefineTracks(box head)): the propagated boxes go through the box head as proposals
     (roi_heads.py:43-45), come back with scores in the (1, 2] band, and the tracks keep their ids over frames."""
