@@ -327,7 +327,7 @@ int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, co
 
 /* EMM.extract_cache over a CAPACITY of boxes of which the first *n_valid (device int32, e.g. &record[1] of
  * smot_track_solve_fwd) are real: rows >= *n_valid are skipped on the device, their outputs stay unwritten.  Lets
- * the tracker enqueue the template extraction before the host has read the solver's counts (Rz = 15,
+ * the tracker enqueue the template extraction before the host has read the solver's counts (Rz = 15 or 7,
  * sampling_ratio = 2 only). */
 int smot_emm_extract_cache_masked_fwd(const float* const* feats, const int* heights, const int* widths,
                                       const float* scales, int num_levels, int C,

@@ -218,9 +218,13 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         F.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
     DC_TRACE(0)
     if (L.logits != nullptr) {
-        for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
-            const int ch = e / (Ho * Ho);
-            lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
+        // a band only touches its four source rows f-1..f+2 (clamped) of the seven planes: 28 * Ho logits, not 7 * Ho^2
+        // (at Ho = 29 the whole image was 23.5 KB per workgroup, 900 workgroups: 21 MB of loads for 2.9 MB of need)
+        for (int e = threadIdx.x; e < 28 * Ho; e += blockDim.x) {          // (ch, k, col)
+            const int ch = e / (4 * Ho), r = e - ch * 4 * Ho;
+            const int k = r / Ho, col = r - k * Ho;
+            const int row = clampi(f - 1 + k, 0, Ho - 1);
+            lg[ch * Ho * Ho + row * Ho + col] = L.get(n, ch, row * Ho + col, Ho * Ho);   // clamped duplicates: equal values
         }
     } else {
         // Ho == 16: a band only touches its four source rows f-1..f+2 (clamped): 7 x 4 x 16 = 448 logits, each the

@@ -101,7 +101,7 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache: bad sizes");
     if (N == 0) return SMOT_OK;
-    if (rz == 15 && sampling_ratio == 2 && !knobs().roi_generic) {
+    if ((rz == 15 || rz == 7) && sampling_ratio == 2 && !knobs().roi_generic) {
         // one launch: separable template pooling, with the search regions written by the same kernel
         const float half_e = (float)((double)search_expansion / 2.0);
         const float two_e = (float)((double)search_expansion * 2.0);
@@ -129,8 +129,8 @@ extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, cons
     SMOT_REQUIRE(capacity >= 0 && num_levels >= 1 && num_levels <= SMOT_MAX_LEVELS, "emm_extract_cache_masked: bad sizes");
     SMOT_REQUIRE(n_valid != nullptr, "emm_extract_cache_masked: null count pointer");
     if (capacity == 0) return SMOT_OK;
-    if (!(rz == 15 && sampling_ratio == 2)) {
-        set_error("emm_extract_cache_masked: only Rz=15, sampling_ratio=2 (got %d, %d); use smot_emm_extract_cache_fwd "
+    if (!((rz == 15 || rz == 7) && sampling_ratio == 2)) {
+        set_error("emm_extract_cache_masked: only Rz=15 or 7, sampling_ratio=2 (got %d, %d); use smot_emm_extract_cache_fwd "
                   "with the count on the host", rz, sampling_ratio);
         return SMOT_ERR_UNSUPPORTED;
     }

@@ -588,8 +588,18 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
 #undef SMOT_COMBINE
         return check_launch("predictor heads combine");
     }
-    // the reference's second shape family (Ho = 29) has a matrix-core kernel of its own; anything else: scalar
-    int rc = launch_tower_conv(resp, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits, zero_words, st);
+    // the reference's second shape family (Ho = 29): Winograd in 16 x 16 blocks when the packed filters are given, else
+    // a direct matrix-core kernel of its own; anything else: scalar
+    int rc = SMOT_ERR_UNSUPPORTED;
+    if (tower_packed != nullptr && !knobs().tower_direct) {
+        SMOT_REQUIRE(((uintptr_t)tower_packed & 15) == 0, "predictor: tower_packed must be 16-byte aligned");
+        timer_mark(1, 0, st);
+        rc = launch_tower_conv_wino(resp, tower_packed, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits,
+                                    zero_words, st);
+        timer_mark(1, 1, st);
+    }
+    if (rc == SMOT_ERR_UNSUPPORTED)
+        rc = launch_tower_conv(resp, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits, zero_words, st);
     if (rc == SMOT_OK) {
         if (zeroed) *zeroed = (zero_words != nullptr);
         return SMOT_OK;

@@ -1004,18 +1004,22 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
                          float two_e, float min_wh, float* templates, float* sr, const int* n_valid, float* order_hint,
                          hipStream_t st) {
-    (void)rz;
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "emm_extract_cache");
     if (rc) return rc;
     SMOT_REQUIRE(boxes && templates && sr, "emm_extract_cache: null pointer");
-    if (!order_hint_rois(N, false)) order_hint = nullptr;
+    if (!order_hint_rois(N, false) || rz != 15) order_hint = nullptr;     // (the hint's consumer is the 30/15 head)
     SMOT_REQUIRE(order_hint == nullptr || ((((uintptr_t)order_hint) & 31) == 0 && (((uintptr_t)boxes) & 15) == 0),
                  "emm_extract_cache: the order hint must be 32-byte aligned (and the boxes 16-byte aligned)");
     // with a hint to write: one extra row of workgroups in front, of which the first ranks the rois (fx_write_hint)
     dim3 grid(N, (C + FX_CH - 1) / FX_CH + (order_hint != nullptr ? 1 : 0));
     SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order(), order_hint, nullptr};
-    launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
+    if (rz == 7) {                 // the second yaml family's template (DLA_34_FPN_EMM_AOT.yaml:52-63): same kernel, 7x7 bins
+        SMOT_LAUNCH((sr_xcorr_fused9_kernel<7, 15, 2, false>), grid, dim3(512), 0, st, P, C, boxes, boxes, (const float*)nullptr,
+                    (float*)nullptr, templates, (int32_t*)nullptr, S);
+    } else {
+        launch_fused<15, false>(grid, st, P, C, boxes, boxes, nullptr, nullptr, templates, nullptr, S);
+    }
     return check_launch("emm_extract_cache");
 }
 

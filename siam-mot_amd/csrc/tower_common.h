@@ -42,5 +42,9 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int Ho, int cpg, float eps,
                       const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws, float* logits,
                       unsigned* zero_words, hipStream_t st);
+// tower_conv.hip: the same through the blocked Winograd kernel (needs the packed filters); SMOT_ERR_UNSUPPORTED otherwise
+int launch_tower_conv_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int Ho, int cpg,
+                           float eps, const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws,
+                           float* logits, unsigned* zero_words, hipStream_t st);
 
 }  // namespace smot

@@ -47,6 +47,121 @@ struct ConvGeom {
     static_assert(16 * PLANE <= 2 * BUF, "the head planes overlay the stage buffers");
 };
 
+// GroupNorm + affine + ReLU + fused partial heads of one (track, tower, 16-channel tile), from the convolution output in
+// the direct kernel's accumulator layout: acc[t][r] = channel oc0 + 4*kq + r at position 16*(wave + 4t) + xl.  Shared by
+// tower_conv_mfma_kernel (accumulators straight from its main loop) and tower_gn_heads_kernel (convolution output of
+// the blocked Winograd kernel, re-loaded).  sm: 16 zero-haloed planes + 128 floats of channel sums; every wave is past its
+// last use of sm when it gets here.  part_tile: where this tile's four partial head planes go.
+template <int HO>
+__device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], const int (&boff)[ConvGeom<HO>::NTW],
+                                               int my_tiles, const float (&hwv)[9], const TowerParams& P, int tower,
+                                               int oc0, int cpg, float eps, float* sm, float* chs,
+                                               float* __restrict__ dst, int tid, int lane, int wave, int kq, int xl) {
+    using G = ConvGeom<HO>;
+    // ---- GroupNorm (two-pass, fp32) + affine + ReLU -------------------------------------------------------------
+    // acc[t][r] = conv output of channel oc0 + 4*kq + r at position 16*(wave + 4t) + xl
+    bool valid[G::NTW];
+#pragma unroll
+    for (int t = 0; t < G::NTW; ++t)
+        valid[t] = (t < G::NTW - 1 || t < my_tiles) && (16 * (wave + 4 * t) + xl < G::HW);
+    const float inv_cnt = 1.0f / (float)(cpg * G::HW);
+    float mean[4], rstd[4];
+    {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < G::NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[r] += valid[t] ? acc[t][r] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[r] = group16_sum(s[r]);
+            if (xl == 0) chs[wave * 16 + 4 * kq + r] = s[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g0 = ((4 * kq + r) / cpg) * cpg;
+            float m = 0.0f;
+            for (int ch = g0; ch < g0 + cpg; ++ch) m += ((chs[ch] + chs[16 + ch]) + chs[32 + ch]) + chs[48 + ch];
+            mean[r] = m * inv_cnt;
+        }
+    }
+    {
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < G::NTW; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[t][r] - mean[r];
+                q[r] += valid[t] ? d * d : 0.0f;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            q[r] = group16_sum(q[r]);
+            if (xl == 0) chs[64 + wave * 16 + 4 * kq + r] = q[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g0 = ((4 * kq + r) / cpg) * cpg;
+            float v = 0.0f;
+            for (int ch = g0; ch < g0 + cpg; ++ch)
+                v += ((chs[64 + ch] + chs[80 + ch]) + chs[96 + ch]) + chs[112 + ch];
+            rstd[r] = 1.0f / sqrtf(v * inv_cnt + eps);
+        }
+    }
+    // ---- normalised tile -> zero-haloed LDS planes (over the stage buffers: every wave is past its last MFMA) -----
+    float* hp = sm;
+    // only the halo needs zeros (every interior cell is written below): 4 * (HO + 1) cells per plane instead of (HO + 2)^2
+    for (int e = tid; e < 16 * 4 * (HO + 1); e += 256) {
+        const int pl = e / (4 * (HO + 1)), c = e - pl * 4 * (HO + 1);
+        const int side = c / (HO + 1), k = c - side * (HO + 1);          // four runs of HO + 1 cells around the plane
+        const int y = side == 0 ? 0 : (side == 1 ? HO + 1 : (side == 2 ? 1 + k : k));
+        const int x = side == 0 ? k : (side == 1 ? 1 + k : (side == 2 ? 0 : HO + 1));
+        hp[pl * G::PLANE + y * G::PW + x] = 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oc = 4 * kq + r;
+        const float ga = P.gamma[tower][oc0 + oc], be = P.beta[tower][oc0 + oc];
+#pragma unroll
+        for (int t = 0; t < G::NTW; ++t)
+            if (valid[t]) {
+                const float v = (acc[t][r] - mean[r]) * rstd[r] * ga + be;
+                hp[oc * G::PLANE + (boff[t] - kq * G::PLANE) + G::PW + 1] = fmaxf(v, 0.0f);
+            }
+    }
+    __syncthreads();
+
+    // ---- fused partial heads: 16 channels x 9 taps -> 4 head outputs per position, 64 positions per group ---------
+    for (int g = wave; g < G::NGROUPS; g += 4) {
+        const int p = 64 * g + lane;
+        const int pc = min(p, G::HW - 1);
+        const int y = pc / HO, x = pc - y * HO;
+        const float* pl0 = hp + y * G::PW + x;
+        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+#define C_HEAD(ID)                                                                                               \
+    hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16],                                                    \
+                                              pl0[((ID) / 9) * G::PLANE + (((ID) % 9) / 3) * G::PW + ((ID) % 9) % 3], \
+                                              hacc, 4, (ID) % 16, 0);
+#define C_HEAD16(R)                                                                                              \
+    C_HEAD((R) * 16 + 0) C_HEAD((R) * 16 + 1) C_HEAD((R) * 16 + 2) C_HEAD((R) * 16 + 3) C_HEAD((R) * 16 + 4)        \
+    C_HEAD((R) * 16 + 5) C_HEAD((R) * 16 + 6) C_HEAD((R) * 16 + 7) C_HEAD((R) * 16 + 8) C_HEAD((R) * 16 + 9)        \
+    C_HEAD((R) * 16 + 10) C_HEAD((R) * 16 + 11) C_HEAD((R) * 16 + 12) C_HEAD((R) * 16 + 13)                       \
+    C_HEAD((R) * 16 + 14) C_HEAD((R) * 16 + 15)
+        C_HEAD16(0) C_HEAD16(1) C_HEAD16(2) C_HEAD16(3) C_HEAD16(4) C_HEAD16(5) C_HEAD16(6) C_HEAD16(7) C_HEAD16(8)
+#undef C_HEAD16
+#undef C_HEAD
+        if (p < G::HW) {
+            dst[0 * G::HW + p] = hacc[0];
+            dst[1 * G::HW + p] = hacc[1];
+            dst[2 * G::HW + p] = hacc[2];
+            dst[3 * G::HW + p] = hacc[3];
+        }
+    }
+}
+
 template <int HO>
 __global__ void __launch_bounds__(256, 2)
 tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg, float eps,
@@ -171,124 +286,79 @@ tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int
         __syncthreads();
     }
 
-    // ---- GroupNorm (two-pass, fp32) + affine + ReLU -------------------------------------------------------------
-    // acc[t][r] = conv output of channel oc0 + 4*kq + r at position 16*(wave + 4t) + xl
-    float* chs = sm + 2 * G::BUF;                     // [2][4 waves][16 channels]
-    bool valid[G::NTW];
-#pragma unroll
-    for (int t = 0; t < G::NTW; ++t)
-        valid[t] = (t < G::NTW - 1 || t < my_tiles) && (16 * (wave + 4 * t) + xl < G::HW);
-    const float inv_cnt = 1.0f / (float)(cpg * G::HW);
-    float mean[4], rstd[4];
     {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < G::NTW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[r] += valid[t] ? acc[t][r] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s[r] = group16_sum(s[r]);
-            if (xl == 0) chs[wave * 16 + 4 * kq + r] = s[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int g0 = ((4 * kq + r) / cpg) * cpg;
-            float m = 0.0f;
-            for (int ch = g0; ch < g0 + cpg; ++ch) m += ((chs[ch] + chs[16 + ch]) + chs[32 + ch]) + chs[48 + ch];
-            mean[r] = m * inv_cnt;
-        }
+        const int tiles = 2 * tiles_per_tower;
+        const int tile = tower * tiles_per_tower + (oc0 >> 4);
+        conv_tile_tail<HO>(acc, boff, my_tiles, hwv, P, tower, oc0, cpg, eps, sm, sm + 2 * G::BUF,
+                           part + ((size_t)n * tiles + tile) * 4 * G::HW, tid, lane, wave, kq, xl);
     }
-    {
-        float q[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < G::NTW; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = acc[t][r] - mean[r];
-                q[r] += valid[t] ? d * d : 0.0f;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            q[r] = group16_sum(q[r]);
-            if (xl == 0) chs[64 + wave * 16 + 4 * kq + r] = q[r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int g0 = ((4 * kq + r) / cpg) * cpg;
-            float v = 0.0f;
-            for (int ch = g0; ch < g0 + cpg; ++ch)
-                v += ((chs[64 + ch] + chs[80 + ch]) + chs[96 + ch]) + chs[112 + ch];
-            rstd[r] = 1.0f / sqrtf(v * inv_cnt + eps);
-        }
-    }
-    // ---- normalised tile -> zero-haloed LDS planes (over the stage buffers: every wave is past its last MFMA) -----
-    float* hp = sm;
-    for (int e = tid; e < 16 * G::PLANE; e += 256) hp[e] = 0.0f;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oc = 4 * kq + r;
-        const float ga = P.gamma[tower][oc0 + oc], be = P.beta[tower][oc0 + oc];
-#pragma unroll
-        for (int t = 0; t < G::NTW; ++t)
-            if (valid[t]) {
-                const float v = (acc[t][r] - mean[r]) * rstd[r] * ga + be;
-                hp[oc * G::PLANE + (boff[t] - kq * G::PLANE) + G::PW + 1] = fmaxf(v, 0.0f);
-            }
-    }
-    __syncthreads();
+}
 
-    // ---- fused partial heads: 16 channels x 9 taps -> 4 head outputs per position, 64 positions per group ---------
-    const int tiles = 2 * tiles_per_tower;
-    const int tile = tower * tiles_per_tower + (oc0 >> 4);
-    float* __restrict__ dst = part + ((size_t)n * tiles + tile) * 4 * G::HW;
-    for (int g = wave; g < G::NGROUPS; g += 4) {
-        const int p = 64 * g + lane;
-        const int pc = min(p, G::HW - 1);
-        const int y = pc / HO, x = pc - y * HO;
-        const float* pl0 = hp + y * G::PW + x;
-        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
-#define C_HEAD(ID)                                                                                               \
-    hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16],                                                    \
-                                              pl0[((ID) / 9) * G::PLANE + (((ID) % 9) / 3) * G::PW + ((ID) % 9) % 3], \
-                                              hacc, 4, (ID) % 16, 0);
-#define C_HEAD16(R)                                                                                              \
-    C_HEAD((R) * 16 + 0) C_HEAD((R) * 16 + 1) C_HEAD((R) * 16 + 2) C_HEAD((R) * 16 + 3) C_HEAD((R) * 16 + 4)        \
-    C_HEAD((R) * 16 + 5) C_HEAD((R) * 16 + 6) C_HEAD((R) * 16 + 7) C_HEAD((R) * 16 + 8) C_HEAD((R) * 16 + 9)        \
-    C_HEAD((R) * 16 + 10) C_HEAD((R) * 16 + 11) C_HEAD((R) * 16 + 12) C_HEAD((R) * 16 + 13)                       \
-    C_HEAD((R) * 16 + 14) C_HEAD((R) * 16 + 15)
-        C_HEAD16(0) C_HEAD16(1) C_HEAD16(2) C_HEAD16(3) C_HEAD16(4) C_HEAD16(5) C_HEAD16(6) C_HEAD16(7) C_HEAD16(8)
-#undef C_HEAD16
-#undef C_HEAD
-        if (p < G::HW) {
-            dst[0 * G::HW + p] = hacc[0];
-            dst[1 * G::HW + p] = hacc[1];
-            dst[2 * G::HW + p] = hacc[2];
-            dst[3 * G::HW + p] = hacc[3];
-        }
+// GroupNorm + ReLU + partial heads for a convolution output that is already in memory: conv [N][2C][HO*HO], written by
+// the blocked Winograd kernel (tower_wino.hip, BHO = HO).  workgroup = (track, tower, 16-channel tile) as above; the
+// tile's 16 planes are re-loaded in the accumulator layout of the direct kernel and go through the same tail.  The four
+// partial head planes of the tile are written over the tile's OWN first four convolution planes (nobody else reads
+// them; this workgroup has them in registers): part[(n*tiles + tile) * 16 * HW + o * HW + p], tile stride 16 * HW.
+template <int HO>
+__global__ void __launch_bounds__(256, 2)
+tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int C, int cpg, float eps) {
+    using G = ConvGeom<HO>;
+    extern __shared__ __attribute__((aligned(16))) float sm[];       // [16][PLANE] + [128]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kq = lane >> 4, xl = lane & 15;
+    const int tiles_per_tower = C >> 4;
+    const int n = blockIdx.x / (2 * tiles_per_tower);
+    const int rem = blockIdx.x - n * 2 * tiles_per_tower;
+    const int tower = rem / tiles_per_tower;
+    const int oc0 = (rem - tower * tiles_per_tower) * 16;
+    float hwv[9];
+    {
+        const int o = lane & 3, blk = lane >> 2;
+        const float* wsrc = (tower == 1) ? P.reg_w + (size_t)o * C * 9
+                                         : (o < 2 ? P.cls_w + (size_t)o * C * 9 : P.center_w);
+        const bool live = (tower == 1) || (o < 3);
+        wsrc += (size_t)oc0 * 9 + blk;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) hwv[r] = live ? wsrc[r * 16] : 0.0f;
     }
+    const int my_tiles = (G::NTILES - wave + 3) >> 2;
+    float* __restrict__ base = conv + ((size_t)n * 2 * C + (size_t)tower * C + oc0) * G::HW;     // the tile's 16 planes
+    int boff[G::NTW];
+    f32x4 acc[G::NTW];
+#pragma unroll
+    for (int t = 0; t < G::NTW; ++t) {
+        const int p = min(16 * (wave + 4 * t) + xl, G::HW - 1);
+        const int y = p / HO, x = p - y * HO;
+        boff[t] = kq * G::PLANE + y * G::PW + x;
+        // unconditional loads at clamped positions (all in flight together); invalid columns are masked in the tail
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = base[(size_t)(4 * kq + r) * G::HW + p];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    conv_tile_tail<HO>(acc, boff, my_tiles, hwv, P, tower, oc0, cpg, eps, sm, sm + 16 * G::PLANE, base, tid, lane, wave, kq,
+                       xl);
 }
 
 // logits[n][ch][pos] = bias[ch] + sum over the tower's tiles of the partial head sums (fixed tile order), ReLU on the
 // four reg channels.  grid (N, 7, ceil(HW / 256)).
 __global__ void __launch_bounds__(256)
-heads_combine_hw_kernel(const float* __restrict__ part, int tpt, int HW, const float* __restrict__ cls_b,
-                        const float* __restrict__ center_b, const float* __restrict__ reg_b,
-                        float* __restrict__ logits) {
+heads_combine_hw_kernel(const float* __restrict__ part, int tpt, int HW, int planes_per_tile,
+                        const float* __restrict__ cls_b, const float* __restrict__ center_b,
+                        const float* __restrict__ reg_b, float* __restrict__ logits) {
+    // planes_per_tile: 4 (the tile's four partial head planes back to back) or 16 (they sit at the head of the tile's
+    // sixteen convolution planes: tower_gn_heads_kernel)
     const int n = blockIdx.x, ch = blockIdx.y;
     const int pos = blockIdx.z * 256 + threadIdx.x;
     if (pos >= HW) return;
     const int side = ch >= 3;
     const int o = side ? ch - 3 : ch;
-    const float* __restrict__ p = part + (((size_t)n * 2 * tpt + side * tpt) * 4 + o) * HW + pos;
+    const float* __restrict__ p = part + (((size_t)n * 2 * tpt + side * tpt) * planes_per_tile + o) * HW + pos;
     float s = 0.0f;
     for (int t0 = 0; t0 < tpt; t0 += 8) {
         float v[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = (t0 + t < tpt) ? p[(size_t)(t0 + t) * 4 * HW] : 0.0f;    // loads in flight together
+        for (int t = 0; t < 8; ++t) v[t] = (t0 + t < tpt) ? p[(size_t)(t0 + t) * planes_per_tile * HW] : 0.0f;    // loads in flight together
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             if (t0 + t < tpt) s += v[t];
@@ -315,7 +385,31 @@ int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int
     int rc = check_launch("predictor towers (conv, Ho=29)");
     if (rc) return rc;
     hipLaunchKernelGGL(heads_combine_hw_kernel, dim3(N, 7, (G::HW + 255) / 256), dim3(256), 0, st,
-                       (const float*)tower_ws, C / 16, G::HW, cls_b, center_b, reg_b, logits);
+                       (const float*)tower_ws, C / 16, G::HW, 4, cls_b, center_b, reg_b, logits);
+    return check_launch("predictor heads combine (Ho=29)");
+}
+
+// The same result through the blocked Winograd kernel (tower_wino.hip): convolution output of every 16x16 block of the
+// 29x29 map -> tower_ws [N][2C][HW], then GroupNorm + ReLU + partial heads per (track, tower, 16-channel tile) in place,
+// then the combine.  Needs the packed (transformed) filters of smot_emm_tower_pack.
+int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
+                             float* conv, unsigned* zero_words, hipStream_t st);                       // tower_wino.hip
+int launch_tower_conv_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int Ho, int cpg,
+                           float eps, const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws,
+                           float* logits, unsigned* zero_words, hipStream_t st) {
+    if (Ho != 29 || C % 32 != 0 || cpg > 16 || 16 % cpg != 0 || packed == nullptr) return SMOT_ERR_UNSUPPORTED;
+    using G = ConvGeom<29>;
+    int rc = launch_tower_wino_blocks(resp, packed, P, N, C, cpg, tower_ws, zero_words, st);
+    if (rc) return rc;
+    const size_t smem = (size_t)(16 * G::PLANE + 128) * sizeof(float);
+    const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_gn_heads_kernel<29>), smem,
+                                     "predictor GroupNorm + heads (Ho=29)");
+    if (rco) return rco;
+    hipLaunchKernelGGL(tower_gn_heads_kernel<29>, dim3(N * 2 * (C / 16)), dim3(256), smem, st, tower_ws, P, C, cpg, eps);
+    rc = check_launch("predictor GroupNorm + heads (Ho=29)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(heads_combine_hw_kernel, dim3(N, 7, (G::HW + 255) / 256), dim3(256), 0, st,
+                       (const float*)tower_ws, C / 16, G::HW, 16, cls_b, center_b, reg_b, logits);
     return check_launch("predictor heads combine (Ho=29)");
 }
 

@@ -83,14 +83,26 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 // ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
 // loads inside the loop, 3 = no LDS reads / operand transform, 4 = no MFMAs, 5 = MFMAs + barriers only,
 // 6 = MFMAs only.  Instantiated in the measurement library only (knobs.h: SMOT_WINO_ABL).
-template <int ABL, int OCT>
+// BHO > 0: BLOCKED mode for a response map of BHO x BHO (16 < BHO <= 32; the second yaml family's 29 x 29): the map is
+// covered by four overlapping 16 x 16 output blocks with origins {0, BHO - 16}^2 and a workgroup convolves ONE block of
+// one track — N counts tracks, the grid 4 N "block tracks".  The stage buffers then hold 18 x 18 windows of the map with
+// their REAL halo (zero only outside the map: buffer loads past the resource's size return 0), the main loop is the
+// same, and the epilogue stops after the output transform: the block's outputs (those no block before it owns) go to
+// `part` = the convolution output [N][2C][BHO * BHO]; GroupNorm needs the whole map and runs in tower_gn_heads_kernel
+// (tower_conv.hip).  17 % more MFMAs than a 15 x 15-tile Winograd of the whole map would need (overlap + the 32 x 32
+// cover), 54 % of the direct convolution's.
+template <int ABL, int OCT, int BHO = 0>
 __global__ void __launch_bounds__(256 * OCT, OCT == 1 ? 2 : 1)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
                   int cpg, float eps, float* __restrict__ part, unsigned* __restrict__ zero_words,
                   long long* __restrict__ trace) {
     constexpr int NT = 256 * OCT;             // threads
     constexpr int NP = 2 / OCT;               // tile-row halves (pairs of N-tiles) per wave
+    constexpr bool BLOCKED = BHO > 0;
+    constexpr int MAP = BLOCKED ? BHO * BHO : 256;                    // positions of a response plane
     constexpr int RAW4 = 512 / NT;            // float4 per thread and stage of raw response
+    constexpr int RAWB = (W_STAGE_IC * 324 + NT - 1) / NT;            // BLOCKED: dwords per thread and stage (18 x 18 windows)
+    static_assert(!BLOCKED || (BHO > 16 && BHO <= 32), "four 16 x 16 blocks cover maps of 17 .. 32");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
 #define W_TRACE(SLOT) \
@@ -109,14 +121,16 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int wg_per_track = tiles / OCT;
     // consecutive workgroup ids go round-robin over the 8 XCDs: give all workgroups of a track the same XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int n = (slot / wg_per_track) * 8 + xcd;
+    const int bt = (slot / wg_per_track) * 8 + xcd;     // track — BLOCKED: block track = 4 * track + block
+    const int n = BLOCKED ? bt >> 2 : bt;
+    const int oy = BLOCKED ? ((bt >> 1) & 1) * (BHO - 16) : 0, ox = BLOCKED ? (bt & 1) * (BHO - 16) : 0;   // block origin
     const int tile0 = (slot % wg_per_track) * OCT;      // first 16-channel tile (OCT = 2: tile0, tile0 + 1: same tower)
     if (n >= N) return;
-    if (zero_words != nullptr && tile0 == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
+    if (zero_words != nullptr && tile0 == 0 && (!BLOCKED || (bt & 3) == 0) && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
     // (Workgroups b and b + 256 share a CU — HW_ID trace in measure/debug/tower_bench.py.  Delaying the second
     // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
     // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
-    const float* __restrict__ in = resp + (size_t)n * C * 256;
+    const float* __restrict__ in = resp + (size_t)n * C * MAP;
     const int nk = C >> 2;
     const int nstages = C / W_STAGE_IC;
     // epilogue roles: thread (sub, ltid) works on tile tile0 + sub exactly as a 256-thread workgroup would
@@ -137,34 +151,73 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
                                                  0x7fffffff, 0x00020000);
     };
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const auto rs_in = make_rsrc(in);
+    // BLOCKED: the resource ends with the track's response, so that an offset past it (an element outside the map)
+    // loads 0 — the zero padding of the convolution, with no instruction spent on it
+    auto make_rsrc_sized = [](const float* base, unsigned bytes) {
+        const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 (int)bytes, 0x00020000);
+    };
+    const auto rs_in = BLOCKED ? make_rsrc_sized(in, (unsigned)C * MAP * 4u) : make_rsrc(in);
     const auto rs_a = make_rsrc(packed);
-    float4 prs[2][RAW4];                      // two stages in flight in registers
-    unsigned raw_voff[RAW4];
-    int raw_lds[RAW4];
-#pragma unroll
-    for (int j = 0; j < RAW4; ++j) {
-        const int f = tid + NT * j;
-        const int f4 = f & 63;
-        raw_voff[j] = (unsigned)((f >> 6) * 256 + f4 * 4) * 4u;
-        raw_lds[j] = (f >> 6) * W_PLANE + ((f4 >> 2) + 1) * W_ROW + 1 + (f4 & 3) * 4;
-    }
-    auto load_raw = [&](int st, float4* pr) {
-        const int soff = __builtin_amdgcn_readfirstlane(st * (W_STAGE_IC * 256 * 4));
+    constexpr int NRAW = BLOCKED ? (RAWB + 3) / 4 : RAW4;             // float4 registers per thread and stage
+    float4 prs[2][NRAW];                      // two stages in flight in registers
+    unsigned raw_voff[BLOCKED ? RAWB : RAW4];
+    int raw_lds[BLOCKED ? RAWB : RAW4];
+    if constexpr (!BLOCKED) {
 #pragma unroll
         for (int j = 0; j < RAW4; ++j) {
-            const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, raw_voff[j], soff, 0));
-            pr[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            const int f = tid + NT * j;
+            const int f4 = f & 63;
+            raw_voff[j] = (unsigned)((f >> 6) * 256 + f4 * 4) * 4u;
+            raw_lds[j] = (f >> 6) * W_PLANE + ((f4 >> 2) + 1) * W_ROW + 1 + (f4 & 3) * 4;
+        }
+    } else {
+        // element e = tid + NT j of a stage: channel e / 324, window row (e % 324) / 18, column e % 18; the window starts
+        // one cell above / left of the block.  Elements past the stage (the last j of some threads) go to the unused
+        // tail of the stage's last plane (floats 432 .. 447: no read touches them).
+#pragma unroll
+        for (int j = 0; j < RAWB; ++j) {
+            const int e = tid + NT * j;
+            const int ch = e / 324, rem = e - ch * 324;
+            const int r = rem / 18, c = rem - r * 18;
+            const int sy = oy - 1 + r, sx = ox - 1 + c;
+            const bool inside = e < W_STAGE_IC * 324 && sy >= 0 && sy < BHO && sx >= 0 && sx < BHO;
+            raw_voff[j] = inside ? (unsigned)(ch * MAP + sy * BHO + sx) * 4u : 0x7FFF0000u;
+            raw_lds[j] = e < W_STAGE_IC * 324 ? ch * W_PLANE + r * W_ROW + c : (W_STAGE_IC - 1) * W_PLANE + 432 + (tid & 15);
+        }
+    }
+    auto load_raw = [&](int st, float4* pr) {
+        const int soff = __builtin_amdgcn_readfirstlane(st * (W_STAGE_IC * MAP * 4));
+        if constexpr (!BLOCKED) {
+#pragma unroll
+            for (int j = 0; j < RAW4; ++j) {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, raw_voff[j], soff, 0));
+                pr[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        } else {
+            float* f = reinterpret_cast<float*>(pr);
+#pragma unroll
+            for (int j = 0; j < RAWB; ++j)
+                f[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, raw_voff[j], soff, 0));
         }
     };
     auto store_raw = [&](float* buf, const float4* pr) {
+        if constexpr (!BLOCKED) {
 #pragma unroll
-        for (int j = 0; j < RAW4; ++j) {
-            float* d = buf + raw_lds[j];
-            d[0] = pr[j].x;
-            d[1] = pr[j].y;
-            d[2] = pr[j].z;
-            d[3] = pr[j].w;
+            for (int j = 0; j < RAW4; ++j) {
+                float* d = buf + raw_lds[j];
+                d[0] = pr[j].x;
+                d[1] = pr[j].y;
+                d[2] = pr[j].z;
+                d[3] = pr[j].w;
+            }
+        } else {
+            const float* f = reinterpret_cast<const float*>(pr);
+#pragma unroll
+            for (int j = 0; j < RAWB; ++j) buf[raw_lds[j]] = f[j];
         }
     };
     // A operands: packed[tile][k][xi][lane][4]
@@ -394,6 +447,24 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         }
     }
 
+    if constexpr (BLOCKED) {
+        // the block's convolution outputs that no earlier block owns (blocks overlap by 32 - BHO rows / columns) -> part
+        // = conv [N][2C][BHO*BHO]; tile 4*x16 + t -> (ty, tx) as below
+        constexpr int OV = 32 - BHO;
+        float* __restrict__ cdst = part + ((size_t)n * 2 * C + (size_t)tower * C + oc0 + ocl) * MAP;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ty = (x16 & 3) + 4 * (x16 >> 3), tx = 2 * t + ((x16 >> 2) & 1);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int lr = 2 * ty + a, lc = 2 * tx + b;
+                    if ((oy == 0 || lr >= OV) && (ox == 0 || lc >= OV)) cdst[(oy + lr) * BHO + ox + lc] = y[t][a][b];
+                }
+        }
+        return;
+    }
     // ---- GroupNorm (two-pass, fp32) + affine + ReLU --------------------------------------------------
     const float inv_cnt = 1.0f / (float)(cpg * 256);
     float s = 0.0f;
@@ -538,6 +609,33 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 #endif
 #undef W_LAUNCH
     return check_launch("predictor towers (winograd)");
+}
+
+// Convolution output of the two towers for a 29 x 29 response (blocked mode above): conv [N][2C][841].
+int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
+                             float* conv, unsigned* zero_words, hipStream_t st) {
+    const int tiles = 2 * (C / 16);
+    const int np8 = ((4 * N + 7) / 8) * 8;                 // block tracks, padded to the XCD count
+    // same dispatch-round arithmetic as launch_tower_wino, on four block tracks per track
+    const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
+    const float c1 = (w1 <= 256) ? 20.0f
+                                 : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
+    const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
+    int oct = (c2 < c1) ? 2 : 1;
+    if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+    const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
+    const int grid = np8 * (tiles / oct);
+    if (oct == 2) {
+        const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 29>), smem,
+                                         "predictor towers (winograd, 29x29 in blocks)");
+        if (rco) return rco;
+        SMOT_LAUNCH((tower_wino_kernel<0, 2, 29>), dim3(grid), dim3(512), smem, st, resp, packed, P, N, C, cpg, 0.0f, conv,
+                    zero_words, (long long*)nullptr);
+    } else {
+        SMOT_LAUNCH((tower_wino_kernel<0, 1, 29>), dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, 0.0f, conv,
+                    zero_words, (long long*)nullptr);
+    }
+    return check_launch("predictor towers (winograd, 29x29 in blocks)");
 }
 
 }  // namespace smot

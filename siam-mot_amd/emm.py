@@ -246,7 +246,7 @@ class EMM(nn.Module):
         loop's serial chain and saves the head 0.4-1.5 us at 30-100 tracks (measure/loop_hint_ab.py)."""
         tu = self.track_utils
         sz = self._template_pooler()
-        if not (self.rz == 15 and sz[1] == 2):
+        if not (self.rz in (15, 7) and sz[1] == 2):
             return None                                    # no masked kernel for this shape family: caller falls back
         return ops.emm_extract_cache(features, boxes, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
                                      tu.min_search_wh, n_valid=n_valid, hint=hint and self.use_order_hint)

@@ -367,7 +367,7 @@ def emm_predictor(resp, params, gn_groups=32, gn_eps=1e-5, winograd=True):
                                % (PREDICTOR_KEYS[i], tuple(w[i].shape), shp))
     tower_ws = torch.empty((N, 2 * C, Ho, Ho), dtype=torch.float32, device=resp.device)
     logits = torch.empty((N, 7, Ho, Ho), dtype=torch.float32, device=resp.device)
-    packed = tower_packed(params) if (winograd and Ho == 16) else None
+    packed = tower_packed(params) if (winograd and Ho in (16, 29)) else None       # (29: Winograd in 16 x 16 blocks)
     with _Launch(resp, *w) as ln:
         rc = lib.smot_emm_predictor_fwd(_ptr(resp), N, C, Ho, *[_ptr(t) for t in w], int(gn_groups), float(gn_eps),
                                         _ptr(packed), _ptr(tower_ws), _ptr(logits), ln.stream)
@@ -604,7 +604,7 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
         raise RuntimeError("siammot_amd.emm_track: predictor has %d channels, features have %d" % (blk.C, C))
     ho = rx - rz + 1
     a_pp = blk.a_pp
-    if not (winograd and ho == 16) and blk.packed is not None:
+    if not (winograd and ho in (16, 29)) and blk.packed is not None:
         pp = (ctypes.c_void_p * 13)(*([t.data_ptr() for t in blk.tensors] + [None]))    # direct tower kernel
         a_pp = ctypes.addressof(pp)
     stream = _stream(dev)

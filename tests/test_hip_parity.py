@@ -254,7 +254,8 @@ def test_xcorr_rejects_bad_inputs(ops):
                                     (2, 128, 29), (3, 64, 29), (1, 96, 29), (2, 32, 21)])
 def test_predictor_vs_oracle(ops, n, c, ho, winograd):
     """Matrix-core towers (Ho=16, C in {64,128,256}: Winograd F(2x2,3x3) with the packed filters, or the direct
-    kernel; Ho=29, the reference's second yaml family: direct implicit GEMM, tower_conv.hip) and the scalar generic
+    kernel; Ho=29, the reference's second yaml family: Winograd in 16x16 blocks, or the direct implicit GEMM of
+    tower_conv.hip) and the scalar generic
     kernel (C=96 -> 3 channels per group; Ho=21).  Same tolerance for all tower kernels."""
     rs = np.random.RandomState(100 + c + ho)
     boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
@@ -289,6 +290,33 @@ def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
             two_dbg = ops.emm_predictor(resp, params)
         assert torch.equal(two, one), "n=%d C=%d: max diff %g" % (n, c, float((two - one).abs().max()))
         assert torch.equal(two, two_dbg)
+
+
+def test_blocked_winograd_towers_for_the_29x29_response(ops):
+    """The second yaml family's towers as Winograd over four overlapping 16x16 blocks of the 29x29 map (tower_wino.hip
+    BHO = 29 -> tower_gn_heads_kernel): against the direct matrix-core kernel (same bound as the 16x16 pair: they differ
+    in rounding order only), one- vs two-tile workgroups bit-identical, track counts that leave block tracks in the
+    XCD padding (N = 1, 3, 30), every block border exercised by a response with structure across rows 12..16."""
+    rs = np.random.RandomState(291)
+    boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+    for n, c in ((1, 32), (3, 64), (30, 128), (2, 256)):
+        params = {k: _d(v) for k, v in gi.predictor_params(rs, c, boxes).items()}
+        resp_np = (rs.standard_normal((n, c, 29, 29)) * 15.0).astype(np.float32)
+        resp_np[:, :, 12:17, :] += 40.0                      # a ridge across the block seam (rows 13..15 are shared)
+        resp_np[:, :, :, 12:17] -= 25.0
+        resp = _d(resp_np)
+        blocked = ops.emm_predictor(resp, params)
+        direct = ops.emm_predictor(resp, params, winograd=False)
+        scale = direct.abs().amax(dim=(0, 2, 3), keepdim=True)
+        err = float(((blocked - direct).abs() / scale).max())
+        assert err < 5e-5, "n=%d C=%d: blocked Winograd vs direct %.3e" % (n, c, err)
+        with ops.debug_library(SMOT_TOWER_OCT=1):
+            one = ops.emm_predictor(resp, params)
+        with ops.debug_library(SMOT_TOWER_OCT=2):
+            two = ops.emm_predictor(resp, params)
+        assert torch.equal(one, two) and torch.equal(blocked, one), "n=%d C=%d" % (n, c)
+        with ops.debug_library(SMOT_TOWER_DIRECT=1):
+            assert torch.equal(ops.emm_predictor(resp, params), direct)
 
 
 def test_tower_pack_cache_follows_the_weights(ops):
