@@ -135,29 +135,40 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
     __syncthreads();
 
     // ---- fused partial heads: 16 channels x 9 taps -> 4 head outputs per position, 64 positions per group ---------
-    for (int g = wave; g < G::NGROUPS; g += 4) {
-        const int p = 64 * g + lane;
-        const int pc = min(p, G::HW - 1);
+    // A wave's groups (g = wave, wave + 4, ...: up to NGW of them) run SIDE BY SIDE: one accumulator chain per group — a
+    // single chain is 144 dependent matrix instructions (each waits for the previous one's result: 4.7 k cycles per
+    // group), four chains pipeline.
+    constexpr int NGW = (G::NGROUPS + 3) / 4;
+    const float* pl0[NGW];
+    f32x4 hacc[NGW];
+#pragma unroll
+    for (int q = 0; q < NGW; ++q) {
+        const int pc = min(64 * (wave + 4 * q) + lane, G::HW - 1);        // (groups past the map re-read the last cell)
         const int y = pc / HO, x = pc - y * HO;
-        const float* pl0 = hp + y * G::PW + x;
-        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        pl0[q] = hp + y * G::PW + x;
+        hacc[q] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
 #define C_HEAD(ID)                                                                                               \
-    hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16],                                                    \
-                                              pl0[((ID) / 9) * G::PLANE + (((ID) % 9) / 3) * G::PW + ((ID) % 9) % 3], \
-                                              hacc, 4, (ID) % 16, 0);
+    _Pragma("unroll") for (int q = 0; q < NGW; ++q)                                                              \
+        hacc[q] = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16],                                             \
+                                                     pl0[q][((ID) / 9) * G::PLANE + (((ID) % 9) / 3) * G::PW + ((ID) % 9) % 3], \
+                                                     hacc[q], 4, (ID) % 16, 0);
 #define C_HEAD16(R)                                                                                              \
     C_HEAD((R) * 16 + 0) C_HEAD((R) * 16 + 1) C_HEAD((R) * 16 + 2) C_HEAD((R) * 16 + 3) C_HEAD((R) * 16 + 4)        \
     C_HEAD((R) * 16 + 5) C_HEAD((R) * 16 + 6) C_HEAD((R) * 16 + 7) C_HEAD((R) * 16 + 8) C_HEAD((R) * 16 + 9)        \
     C_HEAD((R) * 16 + 10) C_HEAD((R) * 16 + 11) C_HEAD((R) * 16 + 12) C_HEAD((R) * 16 + 13)                       \
     C_HEAD((R) * 16 + 14) C_HEAD((R) * 16 + 15)
-        C_HEAD16(0) C_HEAD16(1) C_HEAD16(2) C_HEAD16(3) C_HEAD16(4) C_HEAD16(5) C_HEAD16(6) C_HEAD16(7) C_HEAD16(8)
+    C_HEAD16(0) C_HEAD16(1) C_HEAD16(2) C_HEAD16(3) C_HEAD16(4) C_HEAD16(5) C_HEAD16(6) C_HEAD16(7) C_HEAD16(8)
 #undef C_HEAD16
 #undef C_HEAD
-        if (p < G::HW) {
-            dst[0 * G::HW + p] = hacc[0];
-            dst[1 * G::HW + p] = hacc[1];
-            dst[2 * G::HW + p] = hacc[2];
-            dst[3 * G::HW + p] = hacc[3];
+#pragma unroll
+    for (int q = 0; q < NGW; ++q) {
+        const int p = 64 * (wave + 4 * q) + lane;
+        if (wave + 4 * q < G::NGROUPS && p < G::HW) {
+            dst[0 * G::HW + p] = hacc[q][0];
+            dst[1 * G::HW + p] = hacc[q][1];
+            dst[2 * G::HW + p] = hacc[q][2];
+            dst[3 * G::HW + p] = hacc[q][3];
         }
     }
 }
@@ -301,15 +312,19 @@ tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int
 // them; this workgroup has them in registers): part[(n*tiles + tile) * 16 * HW + o * HW + p], tile stride 16 * HW.
 template <int HO>
 __global__ void __launch_bounds__(256, 2)
-tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int C, int cpg, float eps) {
+tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int cpg, float eps) {
     using G = ConvGeom<HO>;
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [16][PLANE] + [128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kq = lane >> 4, xl = lane & 15;
     const int tiles_per_tower = C >> 4;
-    const int n = blockIdx.x / (2 * tiles_per_tower);
-    const int rem = blockIdx.x - n * 2 * tiles_per_tower;
+    // consecutive workgroup ids go round-robin over the 8 XCDs: a track's workgroups run on the XCD whose L2 the blocked
+    // Winograd kernel left the track's convolution output in (same arithmetic as there)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int n = (slot / (2 * tiles_per_tower)) * 8 + xcd;
+    if (n >= N) return;
+    const int rem = slot % (2 * tiles_per_tower);
     const int tower = rem / tiles_per_tower;
     const int oc0 = (rem - tower * tiles_per_tower) * 16;
     float hwv[9];
@@ -405,7 +420,8 @@ int launch_tower_conv_wino(const float* resp, const float* packed, const TowerPa
     const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_gn_heads_kernel<29>), smem,
                                      "predictor GroupNorm + heads (Ho=29)");
     if (rco) return rco;
-    hipLaunchKernelGGL(tower_gn_heads_kernel<29>, dim3(N * 2 * (C / 16)), dim3(256), smem, st, tower_ws, P, C, cpg, eps);
+    hipLaunchKernelGGL(tower_gn_heads_kernel<29>, dim3(((N + 7) / 8) * 8 * 2 * (C / 16)), dim3(256), smem, st, tower_ws, P, N, C,
+                       cpg, eps);
     rc = check_launch("predictor GroupNorm + heads (Ho=29)");
     if (rc) return rc;
     hipLaunchKernelGGL(heads_combine_hw_kernel, dim3(N, 7, (G::HW + 255) / 256), dim3(256), 0, st,

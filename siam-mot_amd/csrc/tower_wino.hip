@@ -121,12 +121,16 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     const int wg_per_track = tiles / OCT;
     // consecutive workgroup ids go round-robin over the 8 XCDs: give all workgroups of a track the same XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int bt = (slot / wg_per_track) * 8 + xcd;     // track — BLOCKED: block track = 4 * track + block
-    const int n = BLOCKED ? bt >> 2 : bt;
-    const int oy = BLOCKED ? ((bt >> 1) & 1) * (BHO - 16) : 0, ox = BLOCKED ? (bt & 1) * (BHO - 16) : 0;   // block origin
-    const int tile0 = (slot % wg_per_track) * OCT;      // first 16-channel tile (OCT = 2: tile0, tile0 + 1: same tower)
+    // BLOCKED: the four blocks of a track are four consecutive "tracks" of the slot arithmetic, all on the track's XCD
+    // (the map is fetched into one L2 and the convolution output lands where tower_gn_heads_kernel reads it)
+    const int wg_per_n = BLOCKED ? 4 * wg_per_track : wg_per_track;
+    const int n = (slot / wg_per_n) * 8 + xcd;
+    const int within = slot % wg_per_n;
+    const int blk = BLOCKED ? within / wg_per_track : 0;
+    const int oy = BLOCKED ? (blk >> 1) * (BHO - 16) : 0, ox = BLOCKED ? (blk & 1) * (BHO - 16) : 0;   // block origin
+    const int tile0 = (within % wg_per_track) * OCT;    // first 16-channel tile (OCT = 2: tile0, tile0 + 1: same tower)
     if (n >= N) return;
-    if (zero_words != nullptr && tile0 == 0 && (!BLOCKED || (bt & 3) == 0) && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
+    if (zero_words != nullptr && tile0 == 0 && blk == 0 && tid == 0) zero_words[n] = 0u;     // visible at the kernel boundary
     // (Workgroups b and b + 256 share a CU — HW_ID trace in measure/debug/tower_bench.py.  Delaying the second
     // dispatch round so that one workgroup's epilogue overlaps the other's main loop was measured: every 4 k
     // cycles of stagger cost 1 us — the CU is throughput-bound in every phase, not latency-bound.)
@@ -615,7 +619,7 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
                              float* conv, unsigned* zero_words, hipStream_t st) {
     const int tiles = 2 * (C / 16);
-    const int np8 = ((4 * N + 7) / 8) * 8;                 // block tracks, padded to the XCD count
+    const int np8 = ((N + 7) / 8) * 8 * 4;                 // block tracks: tracks padded to the XCD count, four blocks each
     // same dispatch-round arithmetic as launch_tower_wino, on four block tracks per track
     const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
     const float c1 = (w1 <= 256) ? 20.0f
