@@ -1,0 +1,47 @@
+"""Soak: the tracking loop's three paths (frame entry point in two calls = default, Python-composed one-launch path,
+general path) on the same 300-frame sequence with tracks going dormant, resuming and expiring — outputs, memory and
+pool must be identical frame by frame.  usage: [frames]"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+import golden_inputs as gi
+from fake_tracker import detections
+from siammot_amd.config import get_default_cfg
+from siammot_amd.track_head import build_tracking_loop
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+dev = torch.device("cuda:0")
+cfg = get_default_cfg(channels=32)
+cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
+cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
+cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(3)]
+with torch.no_grad():
+    for name in ("cls", "center", "reg"):
+        getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
+for lp in loops[1:]:
+    lp.track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+loops[1].native_frame = False
+loops[2]._lean_ok = lambda d: False
+shapes = gi.feature_shapes((1280, 704), 32)
+rs_f = np.random.RandomState(9)
+rs = [np.random.RandomState(5) for _ in loops]
+taken = [0, 0]
+n0, n1 = loops[0]._step_native, loops[1]._step_lean
+loops[0]._step_native = lambda f, d: (taken.__setitem__(0, taken[0] + 1), n0(f, d))[1]
+loops[1]._step_lean = lambda f, d: (taken.__setitem__(1, taken[1] + 1), n1(f, d))[1]
+dormant_frames = kills = 0
+for f in range(frames):
+    feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+    outs = [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops, rs)]
+    for k in (1, 2):
+        a, b = outs[0], outs[k]
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), (f, k)
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")), (f, k)
+        ma, mb = loops[0].track_memory, loops[k].track_memory
+        assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox) and torch.equal(ma[2][0].bbox, mb[2][0].bbox), (f, k)
+        assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids")), (f, k)
+        pa, pb = loops[0].solver.track_pool, loops[k].solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids and pa._max_id == pb._max_id, (f, k)
+    dormant_frames += bool(loops[0].solver.track_pool.get_dormant_ids())
+print("frames %d: identical on all three paths; native frames %d, lean frames %d, frames with dormant tracks %d, ids started %d, killed %d"
+      % (frames, taken[0], taken[1], dormant_frames, loops[0].solver.track_pool._max_id + 1, len(loops[0].solver.track_pool._kill_ids)))
