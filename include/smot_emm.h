@@ -365,7 +365,9 @@ int smot_box_refine_post_fwd(const float* head_out, int ld, int num_classes, int
                              smot_stream_t stream);
 
 /*
- * The whole box-head refinement of the propagated tracks behind one call (eight launches, no host synchronisation).
+ * The whole box-head refinement of the propagated tracks behind one call (six launches, no host synchronisation: the
+ * K-slice sums of fc7 and of cls_score | bbox_pred are added by their consumers while they load; eight launches when the
+ * head is wider than 64 columns or fc7's width is not a multiple of 64).
  *
  * Replaces: CombinedROIHeads._refine_tracks (siammot/modelling/roi_heads.py:60-84) = ROIBoxHead.forward on the
  *   propagated boxes as proposals (box_head/box_head.py:46-50: [UPSTREAM] Pooler 7x7 -> fc6 -> ReLU -> fc7 -> ReLU ->

@@ -997,7 +997,7 @@ def box_refine_post(head_out, num_classes, reg_classes, boxes, labels, ids, trac
 def box_refine(features, scales, pooled, sampling_ratio, boxes, labels, ids, track_conf, layers, weights, xform_clip,
                clip_wh, tracktor=False):
     """``smot_box_refine_fwd``: 7x7 pooler -> fc6 -> fc7 -> cls_score | bbox_pred -> post-processing of N <= 64
-    propagated tracks in ONE call (eight launches, no synchronisation).  ``layers`` = (fc6.weight, fc6.bias, fc7.weight,
+    propagated tracks in ONE call (six launches, no synchronisation).  ``layers`` = (fc6.weight, fc6.bias, fc7.weight,
     fc7.bias, cls_score.weight, cls_score.bias, bbox_pred.weight, bbox_pred.bias).  Returns ``(boxes, scores, ids,
     labels)`` in the box head's output order."""
     lib = _lib or load_library()

@@ -7,10 +7,12 @@ the whole tracker — head, solver, pool — can run from this repository with O
 reference writes one boolean per track into a device tensor, track_head.py:103-108).
 
 ``TrackingLoop`` is the detector-agnostic frame step: FPN features + this frame's detections in, tracked boxes out.
-Per frame it enqueues the head (3 launches), [the box-head refinement of the propagated boxes (8 launches),] the
-one-launch solver and the masked template extraction of the rows the solver leaves active (``_step_lean``; opt-in
-``_step_native``: the same sequence behind ONE library call, ``smot_track_frame_fwd``; the general path covers other
-solvers, CPU tensors and any ``refine_tracks`` callable), then synchronises once on the solver's record.  The box-head refinement of the propagated boxes
+Per frame it enqueues the head (3 launches), [the box-head refinement of the propagated boxes (6 launches),] the
+one-launch solver and the masked template extraction of the rows the solver leaves active — through the frame entry
+point ``smot_track_frame_fwd`` in two calls on an argument block that stays packed between frames (``_step_native``, the
+default) or composed from the per-stage bindings (``_step_lean``, ``loop.native_frame = False``); the general path covers
+other solvers, CPU tensors and any ``refine_tracks`` callable — then synchronises once on the solver's record.  The
+box-head refinement of the propagated boxes
 (``_refine_tracks``, roi_heads.py:60-84) belongs to the detector: ``siammot_amd.box_refine.RefineTracks`` wraps any
 box head with the reference's call signature.
 """
