@@ -690,7 +690,8 @@ def main():
         # what this run's handful of tracks cannot show: the arg-max statistics over many seeded frame pairs
         # (tools/argmax_stats.py; not re-measured by this run)
         parity["argmax_statistics"] = {
-            "source": "static: profiles/r02_argmax_stats.md, profiles/r02_argmax_stats_n100.md (tools/argmax_stats.py)",
+            "source": "static: profiles/r03_argmax_stats.md, profiles/r03_argmax_stats_n100.md (tools/argmax_stats.py, re-run at "
+                      "the end of round 3)",
             "tracks_30": "30,000 / 30,000 arg-max cells identical to the fp32 oracle over 1,000 frame pairs, min IoU 0.999997",
             "tracks_100": "24,997 / 25,000 identical over 250 frame pairs; the 3 others are ties below fp32 resolution "
                           "(fp64 margins 3-9e-8, decided by the towers' summation order) and land one cell away: IoU "

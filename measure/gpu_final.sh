@@ -13,4 +13,4 @@ python tools/rocpd_stats.py gpurun_out/prof_${TAG}a/a_results.db --md gpurun_out
 python tools/rocpd_stats.py gpurun_out/prof_${TAG}b/b_results.db --by-grid --md gpurun_out/${TAG}_loop_kernel_stats.md --title "${TAG}: bench.py --steps 100 incl. multi-stream and tracking loops (with refinement), rows per launch grid" > /dev/null 2>&1
 grep -E "linear_rows|box_refine|fused9_kernel<7|track_solve" gpurun_out/${TAG}_loop_kernel_stats.md | cut -c1-200
 rm -rf gpurun_out/prof_${TAG}a gpurun_out/prof_${TAG}b
-timeout 600 python tools/argmax_stats.py --pairs ${PAIRS:-400} --out gpurun_out/${TAG}_argmax_stats > gpurun_out/${TAG}_argmax.log 2>&1; tail -3 gpurun_out/${TAG}_argmax.log | cut -c1-300
+timeout 600 python tools/argmax_stats.py --pairs ${PAIRS:-1000} --out gpurun_out/${TAG}_argmax_stats > gpurun_out/${TAG}_argmax.log 2>&1; tail -3 gpurun_out/${TAG}_argmax.log | cut -c1-300
