@@ -249,6 +249,32 @@ def test_wait_host_record_polls_then_falls_back_to_the_event():
         ops.wait_host_record(never, Ev(never, 0), spins=50)
 
 
+def test_order_hint_is_bound_to_the_tensors_it_was_made_from():
+    """``emm.OrderHint`` (the scheduling hint ``extract_cache`` leaves for the next ``forward``) is handed to the kernel only
+    for the very tensors it describes: identity of both box tensors, their in-place version counters, the row count and the
+    pooler scales are all checked — pure host logic, no kernel involved."""
+    import torch
+    from siammot_amd.emm import OrderHint
+    from siammot_amd.structures import BoxList
+    boxes, sr = torch.rand(5, 4), torch.rand(5, 4)
+    hint = torch.zeros(5, 8)
+    scales = (0.25, 0.125)
+    srb = BoxList(sr, (100, 100))
+    assert OrderHint.lookup(srb, boxes, srb.bbox, scales) is None                   # nothing attached
+    srb.order_hint = OrderHint(hint, boxes, srb.bbox, scales)
+    assert OrderHint.lookup(srb, boxes, srb.bbox, scales) is hint
+    assert OrderHint.lookup(srb, boxes.clone(), srb.bbox, scales) is None           # other template boxes (equal values)
+    assert OrderHint.lookup(srb, boxes, srb.bbox.clone(), scales) is None           # a copy of the search regions
+    assert OrderHint.lookup(srb, boxes, srb.bbox, (0.25, 0.0625)) is None           # another pooler
+    assert OrderHint.lookup(srb, boxes[:4], srb.bbox, scales) is None               # another row count (a view: other object)
+    srb.bbox[0, 0] += 1.0                                                           # in-place edit: the hint's copy is stale
+    assert OrderHint.lookup(srb, boxes, srb.bbox, scales) is None
+    srb.order_hint = OrderHint(hint, boxes, srb.bbox, scales)                       # re-made after the edit: valid again
+    assert OrderHint.lookup(srb, boxes, srb.bbox, scales) is hint
+    boxes.mul_(1.0)                                                                 # any in-place op on the template boxes
+    assert OrderHint.lookup(srb, boxes, srb.bbox, scales) is None
+
+
 def test_frame_args_buffer_matches_the_header_struct():
     """``ops.FrameArgs`` packs ``smot_frame_args`` by hand (one struct.pack_into per frame): its field order, the
     pointers-then-ints-then-floats grouping and the total size must be exactly the C struct of include/smot_emm.h — a
