@@ -357,7 +357,7 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
             "refine_tracks": "TrackBoxHead (7x7 HIP pooler, 1024-1024 MLP, one-launch post-processing)" if refine else None,
-            "one_launch_path_frames": lean[0], "one_call_frames": lean[1], "frames": steps,
+            "one_launch_path_frames": lean[0], "frame_entry_point_frames": lean[1], "frames": steps,
             "note": "head + %sone-launch solver (device-resident pool) + track memory; synthetic detections resident on "
                     "the device; one host synchronisation per frame" % ("box-head refinement of the propagated boxes + "
                                                                         if refine else "")}

@@ -13,4 +13,4 @@ for rep in range(3):
             with torch.no_grad():
                 r = bench.tracking_loop_throughput(N, dev, feats, steps=600, refine=refine, native=native)
             print(json.dumps({"tracks": N, "refine": refine, "native": native, "ms_per_frame": round(r["ms_per_frame"], 4),
-                              "held": r["track_count_held"], "native_frames": r["one_call_frames"]}), flush=True)
+                              "held": r["track_count_held"], "native_frames": r["frame_entry_point_frames"]}), flush=True)
