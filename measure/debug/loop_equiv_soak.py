@@ -14,6 +14,7 @@ cfg = get_default_cfg(channels=32)
 cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
 cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
 cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+torch.manual_seed(int(os.environ.get("SEED", "0")))
 loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(3)]
 with torch.no_grad():
     for name in ("cls", "center", "reg"):
@@ -21,6 +22,9 @@ with torch.no_grad():
 for lp in loops[1:]:
     lp.track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
 loops[1].native_frame = False
+for lp in loops:
+    lp.lazy_memory = os.environ.get("NO_LAZY") is None
+    lp.solver.track_pool.mirror_skip = os.environ.get("NO_SKIP") is None
 loops[2]._lean_ok = lambda d: False
 shapes = gi.feature_shapes((1280, 704), 32)
 rs_f = np.random.RandomState(9)
@@ -38,10 +42,34 @@ for f in range(frames):
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), (f, k)
         assert torch.equal(a.get_field("scores"), b.get_field("scores")), (f, k)
         ma, mb = loops[0].track_memory, loops[k].track_memory
-        assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox) and torch.equal(ma[2][0].bbox, mb[2][0].bbox), (f, k)
+        if not (ma[0].shape == mb[0].shape and torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox) and torch.equal(ma[2][0].bbox, mb[2][0].bbox)):
+            ids_a, ids_b = ma[2][0].get_field("ids").cpu().tolist(), mb[2][0].get_field("ids").cpu().tolist()
+            print("MISMATCH frame", f, "loop", k, "rows", ma[0].shape[0], mb[0].shape[0], "taken", taken, "ids equal", ids_a == ids_b)
+            if ma[0].shape == mb[0].shape:
+                dz = (ma[0] - mb[0]).abs().amax(dim=(1, 2, 3)).cpu()
+                bad = torch.nonzero(dz > 0).flatten().tolist()
+                act = loops[0].solver.track_pool.get_active_ids()
+                print("  template rows differing:", bad[:20], "ids", [ids_a[i] for i in bad[:20]], "active?", [ids_a[i] in act for i in bad[:20]], "max", float(dz.max()))
+                dsr = (ma[1][0].bbox - mb[1][0].bbox).abs().amax(dim=1).cpu()
+                dbx = (ma[2][0].bbox - mb[2][0].bbox).abs().amax(dim=1).cpu()
+                print("  sr rows differing:", torch.nonzero(dsr > 0).flatten().tolist()[:20], "box rows differing:", torch.nonzero(dbx > 0).flatten().tolist()[:20])
+                print("  n_det", len(detections(np.random.RandomState(5), f % 40)), "nan in a/b:", bool(torch.isnan(ma[0]).any()), bool(torch.isnan(mb[0]).any()))
+            sys.exit(1)
         assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids")), (f, k)
         pa, pb = loops[0].solver.track_pool, loops[k].solver.track_pool
         assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids and pa._max_id == pb._max_id, (f, k)
+    if os.environ.get("WATCH") and f >= int(os.environ.get("WATCH_FROM", "138")):
+        wid = int(os.environ["WATCH"])
+        for k, lp in enumerate(loops):
+            m = lp.track_memory
+            ids_m = m[2][0].get_field("ids").cpu().tolist()
+            row = ids_m.index(wid) if wid in ids_m else -1
+            p = lp.solver.track_pool
+            ce = p._cache.get(wid)
+            print("f", f, "loop", k, "rows", len(ids_m), "row", row, "zsum", float(m[0][row].double().sum()) if row >= 0 else None,
+                  "box", m[2][0].bbox[row].cpu().tolist() if row >= 0 else None,
+                  "active", wid in p.get_active_ids(), "dormant", p._dormant_ids.get(wid), "cache", None if ce is None else float(ce[0].double().sum()),
+                  "pending", p._pending is not None, "taken", list(taken))
     dormant_frames += bool(loops[0].solver.track_pool.get_dormant_ids())
 print("frames %d: identical on all three paths; native frames %d, lean frames %d, frames with dormant tracks %d, ids started %d, killed %d"
       % (frames, taken[0], taken[1], dormant_frames, loops[0].solver.track_pool._max_id + 1, len(loops[0].solver.track_pool._kill_ids)))

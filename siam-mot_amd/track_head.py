@@ -112,6 +112,56 @@ class TrackHead(torch.nn.Module):
         return target[torch.tensor(rows, dtype=torch.int64, device=ids.device)]
 
 
+class _LazyMemory(object):
+    """The track memory ``(templates, [search-region BoxList], [template-box BoxList])`` of a frame whose active rows are
+    the whole memory (no dormant track), as the tracking loop leaves it for the next frame: the tuple's six view tensors
+    and two BoxLists are built on first access.  The next frame's head only needs five POINTERS into the solver's output
+    buffers and the extraction's outputs (``pointers``) — building the views costs ~8 us of host time on the frame's
+    serial chain and, frame after frame, nobody looks at them.  Indexing / iterating / ``len`` behave like the tuple."""
+    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls")
+
+    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls):
+        self._val = None
+        self.fbuf, self.ibuf, self.templates, self.sr_rows = fbuf, ibuf, templates, sr_rows
+        self.M, self.A, self.size, self.sr_size, self.host_ids, self.cls = M, A, size, sr_size, host_ids, cls
+
+    def pointers(self):
+        """(template boxes, search regions, templates, ids, labels) of rows 0 .. A-1 as device addresses."""
+        fp, ip, M = self.fbuf.data_ptr(), self.ibuf.data_ptr(), self.M
+        return fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M
+
+    def _materialise(self):
+        v = self._val
+        if v is None:
+            st, M, A = torch.as_strided, self.M, self.A
+            fbuf, ibuf = self.fbuf, self.ibuf
+            fields = {"ids": st(ibuf, (A,), (1,), 2 * M), "scores": st(fbuf, (A,), (1,), 9 * M),
+                      "labels": st(ibuf, (A,), (1,), 3 * M)}
+            act = BoxList._wrap(st(fbuf, (A, 4), (4, 1), 4 * M), self.size, "xyxy", fields)
+            act.host_ids = self.host_ids.tolist()
+            sr = BoxList._wrap(self.sr_rows.narrow(0, 0, A), self.sr_size, "xyxy", dict(fields))
+            v = self._val = (self.templates.narrow(0, 0, A), [sr], [act])
+        return v
+
+    def __getitem__(self, k):
+        return self._materialise()[k]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __len__(self):
+        return 3
+
+
+def _memory_rows(mem):
+    """Number of rows of a track memory (0 for None / an empty memory) without building a lazy one."""
+    if mem is None:
+        return 0
+    if type(mem) is _LazyMemory:
+        return mem.A
+    return len(mem[2][0]) if mem[0].numel() > 0 else 0
+
+
 class _FramePlan(object):
     """What ``TrackingLoop._frame_plan`` keeps between frames (see there)."""
     __slots__ = ("dev", "emm", "solver", "pool", "refine", "g", "scales", "params", "hann", "rz", "rx", "C", "amodal",
@@ -151,7 +201,7 @@ class TrackingLoop(torch.nn.Module):
         if not (has_raw and has_device_path):
             return False
         mem = self.track_memory
-        n_mem = len(mem[2][0]) if mem is not None else 0
+        n_mem = (mem.A if type(mem) is _LazyMemory else len(mem[2][0])) if mem is not None else 0
         if refine is not None and n_mem > 0:
             # (what a box head can do for n rows follows from its layer shapes: asked once per row count)
             r = refine_ok.get(n_mem)
@@ -224,22 +274,35 @@ class TrackingLoop(torch.nn.Module):
         st = torch.as_strided
         # fbuf = out_boxes [4M] | act_boxes [4M] | out_scores [M] | act_scores [M]; ibuf = out_ids | out_labels | act_ids | act_labels
         ob, oi, osc, ol = st(fbuf, (K, 4), (4, 1), 0), st(ibuf, (K,), (1,), 0), st(fbuf, (K,), (1,), 8 * M), st(ibuf, (K,), (1,), M)
-        ab, ai, asc, al = (st(fbuf, (A, 4), (4, 1), 4 * M), st(ibuf, (A,), (1,), 2 * M), st(fbuf, (A,), (1,), 9 * M),
-                           st(ibuf, (A,), (1,), 3 * M))
         own = cls is BoxList
         if own:
             out = BoxList._wrap(ob, size, "xyxy", {"ids": oi, "scores": osc, "labels": ol})
-            act = BoxList._wrap(ab, size, "xyxy", {"ids": ai, "scores": asc, "labels": al})
         else:
             out = cls(ob, size, mode="xyxy")
             out.add_field("ids", oi)
             out.add_field("scores", osc)
             out.add_field("labels", ol)
+        out.host_ids = rec[8 + M:8 + M + K]
+        hint = pre[2] if pre is not None and len(pre) > 2 else None
+        if own and A > 0 and pre is not None and hint is None and not pool._dormant_ids and self.__dict__.get("lazy_memory", True):
+            # the usual frame: the active rows ARE the next memory — left unbuilt (see _LazyMemory); `out.active_rows` (read by
+            # the general path's TrackHead._get_track_targets only) is not needed either
+            pad2 = emm.track_utils.pad_pixels * 2
+            memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A, size, [int(size[0] + pad2), int(size[1] + pad2)],
+                                 rec[8 + 2 * M:8 + 2 * M + A], cls)
+            pool.note_memory(memory, memory.host_ids)
+            self.__dict__["track_memory"] = memory
+            self.__dict__["_own_memory"] = memory
+            return out
+        ab, ai, asc, al = (st(fbuf, (A, 4), (4, 1), 4 * M), st(ibuf, (A,), (1,), 2 * M), st(fbuf, (A,), (1,), 9 * M),
+                           st(ibuf, (A,), (1,), 3 * M))
+        if own:
+            act = BoxList._wrap(ab, size, "xyxy", {"ids": ai, "scores": asc, "labels": al})
+        else:
             act = cls(ab, size, mode="xyxy")
             act.add_field("ids", ai)
             act.add_field("scores", asc)
             act.add_field("labels", al)
-        out.host_ids = rec[8 + M:8 + M + K]
         act.host_ids = rec[8 + 2 * M:8 + 2 * M + A].tolist()
         out.active_rows = act
         if A == 0 or pre is None:
@@ -247,7 +310,7 @@ class TrackingLoop(torch.nn.Module):
             self.track_memory = self.track.get_track_memory(features, [out])
             return out
         # (the extraction ranked exactly the rows of `act` — the first A of act_boxes — for the next frame's head)
-        hint = pre[2].narrow(0, 0, A) if len(pre) > 2 and pre[2] is not None else None
+        hint = hint.narrow(0, 0, A) if hint is not None else None
         zv, srv = pre[0].narrow(0, 0, A), pre[1].narrow(0, 0, A)
         if own and hint is None:
             pad2 = emm.track_utils.pad_pixels * 2                                  # = EMM.wrap_cache
@@ -277,8 +340,9 @@ class TrackingLoop(torch.nn.Module):
         st = self.__dict__.get("_lean_static")
         if st is not None and st[5] is not None:                         # with refinement: the box head's whole chain must
             mem = self.track_memory                                      # fit smot_box_refine_fwd (asked by _lean_ok)
-            if mem is not None and mem[0].numel() > 0:
-                r = st[6].get(len(mem[2][0]))
+            n_mem = _memory_rows(mem)
+            if n_mem > 0:
+                r = st[6].get(n_mem)
                 if r is None or not r[1]:
                     return False
         elif st is None and self.refine_tracks is not None:
@@ -368,7 +432,12 @@ class TrackingLoop(torch.nn.Module):
         n_trk = 0
         tf = ti = None
         stream = ops._stream(dev)
-        if mem is not None and mem[0].numel() > 0:
+        head_ptrs = None
+        if type(mem) is _LazyMemory and mem._val is None:
+            # the memory this loop left behind, untouched since: five addresses, no tensor is built
+            n_trk = mem.A
+            head_ptrs = mem.pointers() + (0,)
+        elif mem is not None and mem[0].numel() > 0:
             z, sr, tb = mem
             tb0, sr0 = tb[0], sr[0]
             tbb, srb = tb0.bbox, sr0.bbox
@@ -382,6 +451,10 @@ class TrackingLoop(torch.nn.Module):
                 ops._same_device(dev, ("template boxes", tbb), ("sr", srb), ("template_features", z), ("ids", ids_t),
                                  ("labels", lab_t))
             hint = OrderHint.lookup(sr0, tb0.bbox, sr0.bbox, P.scales) if "order_hint" in sr0.__dict__ else None
+            head_ptrs = (tbb.data_ptr(), srb.data_ptr(), z.data_ptr(), ids_t.data_ptr(), lab_t.data_ptr(),
+                         hint.data_ptr() if hint is not None else 0)
+        if head_ptrs is not None:
+            p_tbb, p_sr, p_z, p_ids, p_lab, p_hint = head_ptrs
             need = P.ws_need.get(n_trk)
             if need is None:
                 need = P.ws_need[n_trk] = (
@@ -390,9 +463,8 @@ class TrackingLoop(torch.nn.Module):
                     if a.refine else 0)
             tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = tf.data_ptr()
-            addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), tbb.data_ptr(), srb.data_ptr(),
-                                z.data_ptr(), hint.data_ptr() if hint is not None else 0, ids_t.data_ptr(),
-                                lab_t.data_ptr(), p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
+            addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), p_tbb, p_sr, p_z, p_hint, p_ids,
+                                p_lab, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)                         # the head is running from here on
         # ---- while the head runs: detections, output buffers, the remaining stages --------------------------------------
         seg = solver._segment(detections)

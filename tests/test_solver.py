@@ -366,6 +366,53 @@ def test_one_launch_solver_edge_cases():
 
 
 @pytest.mark.gpu
+def test_a_frame_on_the_host_solver_between_one_launch_frames_keeps_the_dormant_templates():
+    """A loop that leaves the one-launch path for single frames (more than 512 boxes, detections with extra fields, ...) runs
+    the host solver there: tracks suspended in such a frame must enter the cache with the row of the LAST memory they were
+    active in — the lazily noted one (TrackPool.note_memory) — not with an older entry.  (Found by
+    measure/debug/loop_equiv_soak.py at a seed whose track count crossed 512: the host-path transitions did not flush the
+    pending memory first and the dormant rows of the next memories carried templates one frame too old.)"""
+    import golden_inputs as gi
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
+    cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
+    cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+    torch.manual_seed(3)
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    with torch.no_grad():
+        for name in ("cls", "center", "reg"):
+            getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
+    loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+    # the reference loop: general path + host solver in every frame
+    loops[1]._lean_ok = lambda d: False
+    loops[1].solver._device_path = lambda *a, **k: False
+    lean_ok, device_path = loops[0]._lean_ok, loops[0].solver._device_path
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(9)
+    rs = [np.random.RandomState(5), np.random.RandomState(5)]
+    host_frames = dormant_after_host = 0
+    for f in range(30):
+        host = f % 3 == 2                                   # every third frame of loop 0 goes through the host solver
+        loops[0]._lean_ok = (lambda d: False) if host else lean_ok
+        loops[0].solver._device_path = (lambda *a, **k: False) if host else device_path
+        feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+        a, b = [lp(feats, detections(r, f).to(dev)) for lp, r in zip(loops, rs)]
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        ma, mb = loops[0].track_memory, loops[1].track_memory
+        assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids")), "memory ids, frame %d" % f
+        assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
+        pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids
+        host_frames += host
+        dormant_after_host += bool(host and pa.get_dormant_ids())
+    assert host_frames == 10 and dormant_after_host > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_lean_step_equals_general_path(native):
     """TrackingLoop's lean per-frame step (raw tensors, masked template extraction before the synchronisation, lazy
