@@ -34,7 +34,17 @@ n0, n1 = loops[0]._step_native, loops[1]._step_lean
 loops[0]._step_native = lambda f, d: (taken.__setitem__(0, taken[0] + 1), n0(f, d))[1]
 loops[1]._step_lean = lambda f, d: (taken.__setitem__(1, taken[1] + 1), n1(f, d))[1]
 dormant_frames = kills = 0
+switch = os.environ.get("SWITCH") is not None      # loop 0 changes its path at random from frame to frame
+rs_sw = np.random.RandomState(77)
+lean_ok0, dev_path0 = loops[0]._lean_ok, loops[0].solver._device_path
+modes = [0, 0, 0, 0]
 for f in range(frames):
+    if switch:
+        mode = int(rs_sw.randint(0, 4))                # 0 frame entry point, 1 Python-composed, 2 general + device solver, 3 general + host solver
+        modes[mode] += 1
+        loops[0].native_frame = mode == 0
+        loops[0]._lean_ok = lean_ok0 if mode < 2 else (lambda d: False)
+        loops[0].solver._device_path = dev_path0 if mode < 3 else (lambda *a, **k: False)
     feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
     outs = [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops, rs)]
     for k in (1, 2):
@@ -71,5 +81,7 @@ for f in range(frames):
                   "active", wid in p.get_active_ids(), "dormant", p._dormant_ids.get(wid), "cache", None if ce is None else float(ce[0].double().sum()),
                   "pending", p._pending is not None, "taken", list(taken))
     dormant_frames += bool(loops[0].solver.track_pool.get_dormant_ids())
+if switch:
+    print("path switching: frames per mode (entry point, composed, general+device solver, general+host solver):", modes)
 print("frames %d: identical on all three paths; native frames %d, lean frames %d, frames with dormant tracks %d, ids started %d, killed %d"
       % (frames, taken[0], taken[1], dormant_frames, loops[0].solver.track_pool._max_id + 1, len(loops[0].solver.track_pool._kill_ids)))

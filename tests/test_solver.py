@@ -366,6 +366,51 @@ def test_one_launch_solver_edge_cases():
 
 
 @pytest.mark.gpu
+def test_unbuilt_track_memory_feeds_the_next_head_by_address():
+    """Frames without dormant tracks leave the next memory UNBUILT (track_head._LazyMemory): the following frame's head takes
+    five device addresses from it, no view tensor and no BoxList is made unless somebody reads ``loop.track_memory``.  A
+    loop whose memory is never looked at must produce what the general path produces, frame by frame, and the memory it
+    finally builds on access must equal the general path's."""
+    import golden_inputs as gi
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.structures import BoxList
+    from siammot_amd.track_head import build_tracking_loop, _LazyMemory
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    torch.manual_seed(11)
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+    loops[1]._lean_ok = lambda d: False
+    boxes = torch.tensor([[100.0 + 180 * i, 90.0 + 70 * (i % 3), 170.0 + 180 * i, 250.0 + 70 * (i % 3)] for i in range(6)])
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(2)
+
+    def dets():
+        d = BoxList(boxes.clone().to(dev), (1280, 704))
+        d.add_field("scores", torch.full((6,), 0.95, device=dev))
+        d.add_field("labels", torch.ones(6, dtype=torch.int64, device=dev))
+        d.add_field("ids", torch.full((6,), -1, dtype=torch.int64, device=dev))
+        return d
+    unbuilt = 0
+    for f in range(8):
+        feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+        a, b = [lp(feats, dets()) for lp in loops]
+        if f == 0:
+            for lp in loops:                     # from here on no track is started or suspended: the memory is the active rows
+                lp.solver.start_thresh, lp.solver.track_thresh = 2.0, 0.0
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")), "frame %d" % f
+        mem = loops[0].__dict__["track_memory"]                   # (looked at without touching its contents)
+        unbuilt += type(mem) is _LazyMemory and mem._val is None
+    assert unbuilt == 8 and not loops[0].solver.track_pool.get_dormant_ids()
+    ma, mb = loops[0].track_memory, loops[1].track_memory          # built now
+    assert len(ma) == 3 and torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox)
+    assert torch.equal(ma[2][0].bbox, mb[2][0].bbox) and torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids"))
+    assert ma[1][0].size == mb[1][0].size and ma[2][0].get_field("labels").tolist() == mb[2][0].get_field("labels").tolist()
+    assert loops[0].solver.track_pool.get_cache().keys() == loops[1].solver.track_pool.get_cache().keys()
+
+
+@pytest.mark.gpu
 def test_a_frame_on_the_host_solver_between_one_launch_frames_keeps_the_dormant_templates():
     """A loop that leaves the one-launch path for single frames (more than 512 boxes, detections with extra fields, ...) runs
     the host solver there: tracks suspended in such a frame must enter the cache with the row of the LAST memory they were
