@@ -366,6 +366,46 @@ def test_one_launch_solver_edge_cases():
 
 
 @pytest.mark.gpu
+def test_reset_between_videos_leaves_nothing_behind():
+    """``TrackingLoop.reset()`` (rcnn.py:37-39) between two videos: the second video tracked after a first one must come out
+    exactly as on a fresh loop — device-resident pool, record ring, frame plan, lazily noted memory and the id-table
+    snapshot of the mirror all start over (ids restart at 0)."""
+    import golden_inputs as gi
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
+    cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
+    cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+    torch.manual_seed(21)
+    used, fresh = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    with torch.no_grad():
+        for name in ("cls", "center", "reg"):
+            getattr(used.track.tracker.predictor, name).weight.mul_(20.0)
+    fresh.track.tracker.load_state_dict(used.track.tracker.state_dict())
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(4)
+    frames = [tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes) for _ in range(7)]
+    rs = np.random.RandomState(8)
+    for f in range(7):                                   # first video, on the used loop only
+        used(frames[f], detections(rs, f).to(dev))
+    assert used.solver.track_pool._max_id > 0
+    used.reset()
+    ra, rb = np.random.RandomState(15), np.random.RandomState(15)
+    for f in range(7):                                   # second video on both
+        a = used(frames[6 - f], detections(ra, f + 3).to(dev))
+        b = fresh(frames[6 - f], detections(rb, f + 3).to(dev))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")), "frame %d" % f
+        pa, pb = used.solver.track_pool, fresh.solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids and pa._max_id == pb._max_id
+    ma, mb = used.track_memory, fresh.track_memory
+    assert torch.equal(ma[0], mb[0]) and torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids"))
+
+
+@pytest.mark.gpu
 def test_unbuilt_track_memory_feeds_the_next_head_by_address():
     """Frames without dormant tracks leave the next memory UNBUILT (track_head._LazyMemory): the following frame's head takes
     five device addresses from it, no view tensor and no BoxList is made unless somebody reads ``loop.track_memory``.  A
