@@ -182,6 +182,14 @@ class TrackingLoop(torch.nn.Module):
         self.track_memory = None
         self.track.reset_track_pool()
 
+    def __getstate__(self):
+        # per-frame caches (ctypes blocks, library handles, the trusted-memory marker) are rebuilt on demand: a copy or a
+        # pickle of the loop carries none of them
+        d = self.__dict__.copy()
+        for k in ("_plan", "_lean_static", "_own_memory"):
+            d.pop(k, None)
+        return d
+
     def __setattr__(self, name, value):
         if name in ("track", "solver", "refine_tracks"):                 # what the per-frame caches below were built from
             self.__dict__.pop("_lean_static", None)
