@@ -15,7 +15,18 @@ cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 3
 cfg.MODEL.TRACK_HEAD.TRACK_THRESH = 0.5
 cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
 torch.manual_seed(int(os.environ.get("SEED", "0")))
-loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(3)]
+refine = os.environ.get("REFINE") is not None      # box-head refinement on: frame entry point vs Python-composed only (the
+                                                   # general path's BoxList refinement agrees to rounding, not to the bit)
+if refine:
+    from siammot_amd.box_refine import build_refine_tracks
+    cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM = 128
+    heads = [build_refine_tracks(cfg, 32) for _ in range(2)]
+    heads[1].box.load_state_dict(heads[0].box.state_dict())
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=h) for h in heads]
+    for h in heads:
+        h.box.to(dev).eval()
+else:
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(3)]
 with torch.no_grad():
     for name in ("cls", "center", "reg"):
         getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
@@ -25,7 +36,8 @@ loops[1].native_frame = False
 for lp in loops:
     lp.lazy_memory = os.environ.get("NO_LAZY") is None
     lp.solver.track_pool.mirror_skip = os.environ.get("NO_SKIP") is None
-loops[2]._lean_ok = lambda d: False
+if not refine:
+    loops[2]._lean_ok = lambda d: False
 shapes = gi.feature_shapes((1280, 704), 32)
 rs_f = np.random.RandomState(9)
 rs = [np.random.RandomState(5) for _ in loops]
@@ -47,7 +59,7 @@ for f in range(frames):
         loops[0].solver._device_path = dev_path0 if mode < 3 else (lambda *a, **k: False)
     feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
     outs = [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops, rs)]
-    for k in (1, 2):
+    for k in range(1, len(loops)):
         a, b = outs[0], outs[k]
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), (f, k)
         assert torch.equal(a.get_field("scores"), b.get_field("scores")), (f, k)
