@@ -1040,6 +1040,30 @@ def test_order_hint_lists_the_rois_in_cost_order_and_changes_nothing(ops, n):
         head(hint[:n - 1])
 
 
+@pytest.mark.parametrize("n", [1, 9, 30, 70])
+def test_template_extraction_of_the_second_yaml_family_in_one_launch(ops, n):
+    """``extract_cache`` at the 7x7 template of DLA_34_FPN_EMM_AOT.yaml (pad 256, search regions x5): one launch of the
+    separable pooling kernel that also writes the search regions — equal to the stand-alone pooler and to
+    ``smot_search_region_fwd`` bit for bit, the masked form (count on the device) to the unmasked rows, no order hint (its
+    consumer is the 30/15 head)."""
+    rs = np.random.RandomState(700 + n)
+    g = torch.Generator().manual_seed(n)
+    C = 24
+    feats = tuple(torch.randn((1, C, 704 // s, 1280 // s), generator=g).to(DEV) for s in (4, 8, 16, 32))
+    wh = np.exp(rs.uniform(np.log(16), np.log(400), (n, 1))) * np.array([[1.0, 1.9]])
+    xy = rs.uniform(0, 1, (n, 2)) * np.maximum(np.array([1280.0, 704.0]) - wh, 1.0)
+    boxes = _d(np.concatenate((xy, xy + wh), 1).astype(np.float32))
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    z, sr, hint = ops.emm_extract_cache(feats, boxes, 7, scales, 2, 256, 4.0, 0, hint=True)
+    assert hint is None
+    assert torch.equal(z, ops.roi_align_levels(feats, boxes, boxes, 7, scales, 2))
+    assert torch.equal(sr, ops.search_region(boxes, 256, 4.0, 0))
+    nv = max(n - 2, 0)
+    mz, msr = ops.emm_extract_cache(feats, boxes, 7, scales, 2, 256, 4.0, 0,
+                                    n_valid=torch.tensor([nv], dtype=torch.int32, device=DEV))
+    assert torch.equal(mz[:nv], z[:nv]) and torch.equal(msr[:nv], sr[:nv])
+
+
 def test_order_hint_is_dropped_when_the_memory_it_describes_changes(ops):
     """``EMM.extract_cache`` leaves the hint on its search-region BoxList; ``EMM.forward`` passes it only for the very
     tensors it was made from: an in-place edit, a copy or a merged memory falls back to ranking in the kernel — checked
