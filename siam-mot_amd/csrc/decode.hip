@@ -767,7 +767,9 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     // thread groups per band: more of them shorten a lane's serial row walk (latency) but repeat the horizontal
     // pass (work) — worth it while the launch does not fill the chip.  (Measurement library: SMOT_DECODE_SPLIT
     // = 1|2|4 overrides; validated where it is set.)
-    const int split = knobs().decode_split ? knobs().decode_split : ((long long)N * (Ho + 1) <= 768 ? 2 : 1);
+    // (grids wider than 256 columns — the second yaml family's 464 — give a lane two columns: two thread groups per band
+    // there as well, 259.3 -> 256.5 us per frame pair at 30 tracks, measure/aot_ab.py; four were slower)
+    const int split = knobs().decode_split ? knobs().decode_split : (((long long)N * (Ho + 1) <= 768 || G > 256) ? 2 : 1);
 #ifdef SMOT_DEBUG
     if (knobs().decode_two_pass) {       // round-1 structure: band kernel + finalize launch (A/B)
         LogitSrc L1 = L;
