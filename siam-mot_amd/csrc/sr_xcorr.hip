@@ -545,8 +545,8 @@ __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __r
     return true;
 }
 
-template <int RX, int RZ, int G, bool XCORR>
-__global__ void __launch_bounds__(512, 6)      // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
+template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH>
+__global__ void __launch_bounds__(64 * NCH, 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                        const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
                        int32_t* __restrict__ levels_out, SrOut S) {
@@ -557,7 +557,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
-    __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
+    __shared__ __attribute__((aligned(16))) float sm[(NCH / 2) * (2 * XP + 2 * ZP)];
     __shared__ __attribute__((aligned(16))) int4 tab[2][64 + 2 * RH * G];   // y / x sample tables (+ zero pad)
     __shared__ int wbound[4];
 
@@ -643,8 +643,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // second workgroup: per-workgroup spans became equal (25-32 k cycles instead of 26 k / 48 k) but 608 working
     // workgroups no longer fit the chip's 512 resident slots (two rounds: 18.7 -> 24 us), and at three workgroups
     // per CU — 74 VGPRs with the one-plane correlation below — the kernel still took 23.0 us.)
-    constexpr int nplanes = FX_CH;
-    const int c0 = cgrp * FX_CH;
+    constexpr int nplanes = NCH;
+    const int c0 = cgrp * NCH;
     // template of this wave's plane: issue the loads now, park them in LDS after the tables
     const bool owns = (wave < nplanes && c0 + wave < C);  // channel tails / four-plane workgroups: no plane here
     const int plane = n * C + c0 + wave;
@@ -1038,6 +1038,17 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
     timer_mark(0, 0, st);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint};
+#ifdef SMOT_DEBUG
+    // A/B (measurement library, SMOT_FUSED_ABL=4): four channels per workgroup, twice the workgroups (960 of four waves at
+    // 30 tracks: finer balance, twice the table builds).  Bit-identical; 17.7 vs 17.7 us at 30 tracks, 39.0 vs 39.7 at 100
+    // (measure/fused_ab.py): not worth a second configuration.
+    if (knobs().fused_abl == 4) {
+        hipLaunchKernelGGL((sr_xcorr_fused9_kernel<30, 15, 2, true, 4>), dim3(N, (C + 3) / 4), dim3(256), 0, st, P, C, sr, boxes,
+                           templates, resp, x_debug, (int32_t*)nullptr, none);
+        timer_mark(0, 1, st);
+        return check_launch("sr_xcorr_fused");
+    }
+#endif
     launch_fused<30, true>(grid, st, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
     timer_mark(0, 1, st);
     return check_launch("sr_xcorr_fused");
