@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import golden_inputs as gi            # noqa: E402  (tests/golden_inputs.py)
-from siammot_amd.structures import BoxList, cat   # noqa: E402
+from oracle.ref_structures import BoxList, cat   # noqa: E402  (the oracle's OWN restatement: nothing of the product)
 
 
 # ----------------------------------------------------------------------------------------

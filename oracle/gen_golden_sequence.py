@@ -12,7 +12,7 @@ Every frame goes through the reference's own, UNMODIFIED
     ROIBoxHead + PostProcessor         siammot/modelling/box_head/*.py        (case "refine")
 
 on CPU, with the ``maskrcnn_benchmark`` symbols stubbed exactly as in gen_golden.py / gen_golden_refine.py (scalar-loop
-ROIAlign, numpy NMS, this repository's BoxList).  The tracked box of frame t becomes the template box and the search
+ROIAlign, numpy NMS, the oracle's own BoxList (oracle/ref_structures.py)).  The tracked box of frame t becomes the template box and the search
 region of frame t+1, so rounding differences can compound and an arg-max flip moves a template: this is the parity
 the single-frame-pair fixtures cannot give.
 
@@ -47,7 +47,7 @@ import golden_inputs as gi                                    # noqa: E402
 import gen_golden as gg                                       # noqa: E402
 import gen_golden_refine as gr                                # noqa: E402
 from oracle import box_head_oracle as BO                      # noqa: E402
-from siammot_amd.structures import BoxList                    # noqa: E402
+from oracle.ref_structures import BoxList                     # noqa: E402
 
 
 class Cfg(types.SimpleNamespace):

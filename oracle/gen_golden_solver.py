@@ -4,7 +4,7 @@
 Runs only in the build container (needs /root/reference).  Imported UNMODIFIED:
     siammot/modelling/track_head/track_solver.py   (TrackSolver)
     siammot/modelling/track_head/track_utils.py    (TrackPool)
-Their ``maskrcnn_benchmark`` imports (BoxList, boxlist_nms, cat_boxlist) are satisfied by this repository's BoxList
+Their ``maskrcnn_benchmark`` imports (BoxList, boxlist_nms, cat_boxlist) are satisfied by the oracle's own BoxList (oracle/ref_structures.py)
 restatement and by a numpy greedy NMS with upstream's semantics (oracle/solver_oracle.py::nms_indices).
 A seeded sequence of random frames (tests/test_solver.py::_scene) is pushed through the solver; per frame the
 kept rows, output ids and scores and the pool state are stored.  tests/test_solver.py replays the same sequence
@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import solver_oracle as SO                       # noqa: E402
-from siammot_amd.structures import BoxList, cat_boxlist      # noqa: E402
+from oracle.ref_structures import BoxList, cat_boxlist       # noqa: E402
 
 
 def boxlist_nms(boxlist, nms_thresh, max_proposals=-1, score_field="scores"):

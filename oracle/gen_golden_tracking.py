@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import gen_golden_solver as G                                  # noqa: E402
-from siammot_amd.structures import cat_boxlist                 # noqa: E402
+from oracle.ref_structures import BoxList, cat_boxlist         # noqa: E402
 
 
 def main():
@@ -44,13 +44,13 @@ def main():
     from fake_tracker import SEQ, FakeTracker, detections
     pool = utils_mod.TrackPool(max_dormant_frames=SEQ["max_dormant_frames"])
     tu = types.SimpleNamespace(pad_pixels=SEQ["pad"])
-    head = head_mod.TrackHead(FakeTracker(SEQ["pad"]), None, tu, pool).eval()
+    head = head_mod.TrackHead(FakeTracker(SEQ["pad"], BoxList), None, tu, pool).eval()
     solver = solver_mod.TrackSolver(pool, *SEQ["thresholds"])
     rs = np.random.RandomState(SEQ["seed"])
     memory, out = None, {}
     feats = (torch.zeros(1),)
     for f in range(SEQ["frames"]):
-        dets = [detections(rs, f)]
+        dets = [detections(rs, f, boxlist_cls=BoxList)]
         _, tracks, _ = head(feats, track_memory=memory)                 # roi_heads.py:38
         if tracks is not None:
             t = tracks[0]

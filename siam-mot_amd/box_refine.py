@@ -208,6 +208,16 @@ class TrackBoxHead(nn.Module):
         return (isinstance(self.feature_extractor.pooler, Pooler) and pp.score_thresh < 1.0
                 and 0 < n <= ops.box_refine_post_max_rows() and self.predictor.cls_score.weight.is_cuda)
 
+    def raw_state_key(self):
+        """The mutable state ``raw_ok`` / ``one_call_ok`` rest on (the post-processor's score threshold, where the
+        predictor's weights live): the tracking loop caches those verdicts per row count and drops them when this moves
+        (``post_processor.score_thresh = 1.0`` or ``.cpu()`` after the first frame must not leave a stale verdict)."""
+        st = self.__dict__.get("_raw_state_refs")
+        if st is None:                   # (submodule lookups go through nn.Module.__getattr__: once)
+            st = self.__dict__["_raw_state_refs"] = (self.post_processor, self.predictor.cls_score)
+        w = st[1].weight
+        return (float(st[0].score_thresh), w.data_ptr(), w.is_cuda)
+
     @torch.no_grad()
     def refine_raw(self, features, boxes, conf, ids, labels, image_wh, tracktor=False):
         """The box head on N propagated tracks (every row a track with a label in [1, K)) followed by the score rule of
@@ -268,6 +278,10 @@ class RefineTracks(object):
         """The device-only form applies (the tracking loop's one-launch path keeps its single synchronisation)."""
         ok = getattr(self.box, "raw_ok", None)
         return ok is not None and ok(n)
+
+    def raw_state_key(self):
+        k = getattr(self.box, "raw_state_key", None)
+        return k() if k is not None else None
 
     def refine_raw(self, features, boxes, conf, ids, labels, image_wh):
         return self.box.refine_raw(features, boxes, conf, ids, labels, image_wh, self.tracktor)

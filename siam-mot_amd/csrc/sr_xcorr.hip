@@ -545,15 +545,17 @@ __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __r
     return true;
 }
 
-template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH>
-__global__ void __launch_bounds__(64 * NCH, 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
+template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH, bool P2 = false>
+__global__ void __launch_bounds__(64 * NCH, P2 ? 4 : 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                        const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
                        int32_t* __restrict__ levels_out, SrOut S) {
     constexpr int HO = XCORR ? RX - RZ + 1 : 16;
     constexpr int NS = RX * G;                   // samples per axis
     // LDS image of the one-plane-per-wave correlation (xcorr_patch1.h): row stride 40, one plane per slot
-    constexpr int XS = XP1_XS, XP = 32 * XP1_XS, ZS = XP1_ZS, ZP = RZ * XP1_ZS;
+    // P2: the correlation runs on plane PAIRS with 4x2 output patches per lane (xcorr_patch2.h: half the LDS read volume
+    // per FMA of the one-plane form) by waves 0..NCH/2-1; the image then has that phase's strides
+    constexpr int XS = P2 ? XP2_XS : XP1_XS, XP = P2 ? XP2_XP : 32 * XP1_XS, ZS = XP1_ZS, ZP = RZ * XP1_ZS;
     constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
@@ -839,7 +841,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                 // gather; LDS operations of one wave execute in order, so neither a wait nor a barrier is needed).
                 // Rows are processed in two groups to keep the register peak (column sums + gathered taps + tables)
                 // where the correlation phase is scheduled for.  Same values, same FMA order: bit-identical.
-                constexpr int GR = (ROWS + 1) / 2;
+                constexpr int GR = (P2 && X2) ? 3 : (ROWS + 1) / 2;
                 if constexpr (!CHUNKED) {
                     constexpr int SW = (X2 || !PAIR) ? 64 : 32;                      // staged floats per row (and plane)
                     static_assert(GR * SW <= (RH - (RH / ROWS) * ROWS == 0 ? ROWS : RH - (RH / ROWS) * ROWS) * XS,
@@ -943,7 +945,12 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
 #endif
         // every wave correlates its own plane (2x2 output patches per lane): all eight waves work, and the phase
         // needs few enough registers for three workgroups per CU
-        if (owns) {
+        if constexpr (P2) {
+            if (wave < nplanes / 2 && c0 + 2 * wave < C) {
+                const float* xs2 = sm + wave * (2 * XP + 2 * ZP);
+                xcorr_patch2_compute<RX, RZ, 0>(xs2, xs2 + 2 * XP, lane, resp, n * C + c0 + 2 * wave, n * C + min(C, c0 + NCH));
+            }
+        } else if (owns) {
             const float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
             const float* zs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;
             xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane);
@@ -1023,6 +1030,10 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     return check_launch("emm_extract_cache");
 }
 
+int launch_roi_plans(const LevelParams& P, const float* sr, const float* boxes, int N, float* plans, hipStream_t st);
+int launch_fused10(const LevelParams& P, int C, const float* plans, const float* z, int N, float* resp, float* x_debug,
+                   hipStream_t st);
+
 // Pooling + correlation with an optional order hint for its rois (smot_emm_track_fwd; the stand-alone operator
 // smot_sr_xcorr_fused_fwd passes none).
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
@@ -1036,12 +1047,37 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
     SMOT_REQUIRE(order_hint == nullptr || (((uintptr_t)order_hint) & 31) == 0,
                  "sr_xcorr_fused: the order hint must be 32-byte aligned");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
+#ifdef SMOT_DEBUG
+    if (knobs().fused_gen == 10) {             // stage 1 (measurement library): generation 4 with a stand-alone plan launch
+        static float* plans = nullptr;
+        if (plans == nullptr && hipMalloc(&plans, (size_t)4096 * SMOT_PLAN_FLOATS * 4) != hipSuccess) return SMOT_ERR_BAD_ARG;
+        SMOT_REQUIRE(N <= 4096, "fused10 debug: at most 4096 rois");
+        int rcp = launch_roi_plans(P, sr, boxes, N, plans, st);
+        if (rcp) return rcp;
+        timer_mark(0, 0, st);
+        rcp = launch_fused10(P, C, plans, templates, N, resp, x_debug, st);
+        timer_mark(0, 1, st);
+        return rcp;
+    }
+#endif
     timer_mark(0, 0, st);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint};
 #ifdef SMOT_DEBUG
     // A/B (measurement library, SMOT_FUSED_ABL=4): four channels per workgroup, twice the workgroups (960 of four waves at
     // 30 tracks: finer balance, twice the table builds).  Bit-identical; 17.7 vs 17.7 us at 30 tracks, 39.0 vs 39.7 at 100
     // (measure/fused_ab.py): not worth a second configuration.
+    if (knobs().fused_abl == 5) {       // A/B: the correlation on plane pairs with 4x2 patches (half the LDS read volume)
+        hipEvent_t e0_, e1_;
+        if (timer_take(&e0_, &e1_)) {
+            hipExtLaunchKernelGGL((sr_xcorr_fused9_kernel<30, 15, 2, true, 8, true>), grid, dim3(512), 0, st, e0_, e1_, 0, P, C, sr, boxes,
+                                  templates, resp, x_debug, (int32_t*)nullptr, none);
+        } else {
+            hipLaunchKernelGGL((sr_xcorr_fused9_kernel<30, 15, 2, true, 8, true>), grid, dim3(512), 0, st, P, C, sr, boxes,
+                               templates, resp, x_debug, (int32_t*)nullptr, none);
+        }
+        timer_mark(0, 1, st);
+        return check_launch("sr_xcorr_fused");
+    }
     if (knobs().fused_abl == 4) {
         hipLaunchKernelGGL((sr_xcorr_fused9_kernel<30, 15, 2, true, 4>), dim3(N, (C + 3) / 4), dim3(256), 0, st, P, C, sr, boxes,
                            templates, resp, x_debug, (int32_t*)nullptr, none);

@@ -217,6 +217,17 @@ class TrackingLoop(torch.nn.Module):
                 ok = getattr(refine, "raw_ok", None)
                 one = getattr(getattr(refine, "box", None), "one_call_ok", None)
                 r = refine_ok[n_mem] = (ok is not None and bool(ok(n_mem)), one is not None and bool(one(n_mem)))
+            # the verdict rests on mutable state (the post-processor's score threshold, where the weights live): re-read
+            # the two cheap predicates every frame and drop the cached verdicts when they moved
+            key = refine_ok.get("key")
+            cur = getattr(refine, "raw_state_key", None)
+            cur = cur() if cur is not None else None
+            if key != cur:
+                refine_ok.clear()
+                refine_ok["key"] = cur
+                ok = getattr(refine, "raw_ok", None)
+                one = getattr(getattr(refine, "box", None), "one_call_ok", None)
+                r = refine_ok[n_mem] = (ok is not None and bool(ok(n_mem)), one is not None and bool(one(n_mem)))
             if not r[0]:
                 return False
         elif refine is not None and getattr(refine, "raw_ok", None) is None:
@@ -347,7 +358,23 @@ class TrackingLoop(torch.nn.Module):
                 return False
         st = self.__dict__.get("_lean_static")
         if st is not None and st[5] is not None:                         # with refinement: the box head's whole chain must
-            mem = self.track_memory                                      # fit smot_box_refine_fwd (asked by _lean_ok)
+            geom = st[6].get("geom")                                     # fit smot_box_refine_fwd (asked by _lean_ok)
+            if geom is None:
+                # smot_frame_args carries ONE level geometry (scales, level count) and ONE clip pair for the head and the
+                # refinement: the frame entry point applies only when the box head's pooler sits on the search pooler's
+                # levels (the reference keeps MODEL.ROI_BOX_HEAD.POOLER_SCALES and MODEL.TRACK_HEAD.POOLER_SCALES apart) and
+                # both stages clip alike (INPUT.AMODAL in the reference's cfg; RefineTracks accepts any box head).  Otherwise
+                # the Python-composed form, which handles the two independently.
+                emm, box = self.track.tracker, st[5].box
+                bx = getattr(getattr(box, "feature_extractor", None), "pooler", None)
+                pp_ = getattr(box, "post_processor", None)
+                geom = st[6]["geom"] = bool(
+                    bx is not None and pp_ is not None
+                    and tuple(float(v) for v in bx.scales) == tuple(float(v) for v in emm.feature_extractor.pooler_x.scales)
+                    and bool(pp_.amodal_inference) == bool(emm.amodal))
+            if not geom:
+                return False
+            mem = self.track_memory
             n_mem = _memory_rows(mem)
             if n_mem > 0:
                 r = st[6].get(n_mem)

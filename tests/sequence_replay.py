@@ -53,7 +53,7 @@ class OracleEMM(torch.nn.Module):
                                                 template_features, b.size, return_intermediates=True,
                                                 reference_ops=self.reference_ops)
         self.last = inter
-        out = BoxList(bb, b.size, mode="xyxy")
+        out = b.__class__(bb, b.size, mode="xyxy")
         out.add_field("ids", b.get_field("ids"))
         out.add_field("labels", b.get_field("labels"))
         out.add_field("scores", conf)
@@ -63,7 +63,7 @@ class OracleEMM(torch.nn.Module):
         z, sr_bbox = self.O.extract_cache(self.ocfg, list(features), detection.bbox)
         w, h = detection.size
         pad = self.track_utils.pad_pixels
-        sr = BoxList(sr_bbox, [int(w + 2 * pad), int(h + 2 * pad)], mode="xyxy")
+        sr = detection.__class__(sr_bbox, [int(w + 2 * pad), int(h + 2 * pad)], mode="xyxy")
         for f in detection.fields():
             sr.add_field(f, detection.get_field(f))
         return z, [sr], [detection]
@@ -83,9 +83,9 @@ def load_golden(name):
     return np.load(os.path.join(GOLDEN, "sequence_%s.npz" % name))
 
 
-def detections_boxlist(inp, t, device):
+def detections_boxlist(inp, t, device, boxlist_cls=BoxList):
     boxes, scores = inp.detections(t)
-    bl = BoxList(torch.from_numpy(boxes).to(device), inp.case["image_wh"], mode="xyxy")
+    bl = boxlist_cls(torch.from_numpy(boxes).to(device), inp.case["image_wh"], mode="xyxy")
     bl.add_field("ids", torch.full((len(boxes),), -1, dtype=torch.int64, device=device))
     bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64, device=device))
     bl.add_field("scores", torch.from_numpy(scores).to(device))
@@ -167,7 +167,7 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
         feats = tuple(torch.from_numpy(f).to(device) for f in feats_np)
         if probe is not None:
             probe["last"] = None
-        out = loop(feats, detections_boxlist(inp, t, device))
+        out = loop(feats, detections_boxlist(inp, t, device, getattr(loop, "boxlist_cls", BoxList)))
         has_trk = (p + "trk_margin") in golden.files
         margin = golden[p + "trk_margin"] if has_trk else np.array([np.inf])
         ctx = "case %s frame %d (min stored arg-max margin of the frame %.2e; flips so far %s)" % (

@@ -621,7 +621,15 @@ def test_emm_random_geometry_against_oracle(ops, seed):
                                              _t(boxes, torch.float64), sr_ref.double(), z_ref.double(),
                                              case["image_wh"], return_intermediates=True)
         bad = np.nonzero(~ok)[0]
-        assert len(bad) <= 2, "IoU vs oracle: %s" % ious
+        # (none is observed; a flip is tolerated only where the fp32 oracle's own best and second-best cells are closer than
+        # the closed-loop replay's FLIP_MARGIN — a tie below fp32 resolution of the towers' summation order)
+        rows = torch.from_numpy(bad)
+        sc, _ = O.score_map(O.bicubic_upsample(inter["cls"][rows]), O.bicubic_upsample(inter["center"][rows]),
+                            O.bicubic_upsample(inter["reg"][rows]), _t(boxes)[rows], cfg.use_centerness, cfg.sigma)
+        top2 = torch.topk(sc, 2, dim=1).values
+        margins = (top2[:, 0] - top2[:, 1]).numpy()
+        assert len(bad) <= 2 and (margins < 3e-6).all(), "IoU vs oracle: %s (fp32 oracle margins of the rows that moved: %s)" % (
+            ious, margins)
         for t in bad:      # the GPU's box must then coincide with the fp64 oracle's choice, or with the fp32 one
             alt = iou(got[t:t + 1], bb64.numpy()[t:t + 1].astype(np.float32))
             assert alt[0] >= 1 - 1e-3, "track %d: IoU %.4f vs fp32 oracle, %.4f vs fp64 oracle" % (t, ious[t], alt[0])

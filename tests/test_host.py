@@ -115,6 +115,39 @@ def test_product_code_never_imports_the_oracle():
                 assert "oracle" not in src, "%s mentions the oracle" % f
 
 
+def test_oracle_never_imports_the_product():
+    """The golden generators satisfy the reference's ``maskrcnn_benchmark`` imports with the oracle's OWN restatement
+    (oracle/ref_structures.py), not with the package under test.  The one script that is ABOUT the
+    product — check_reference_dropin.py, which plugs siammot_amd.emm.EMM into the reference's TrackHead — is exempt."""
+    odir = os.path.join(ROOT, "oracle")
+    for f in sorted(os.listdir(odir)):
+        if not f.endswith(".py") or f == "check_reference_dropin.py":
+            continue
+        for ln in open(os.path.join(odir, f)):
+            code = ln.split("#")[0]
+            assert not (("import" in code) and "siammot_amd" in code), "oracle/%s imports the product: %s" % (f, ln.strip())
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_structures_probe", os.path.join(odir, "ref_structures.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    from siammot_amd import structures as S
+    assert m.BoxList is not S.BoxList
+    # the two restatements of upstream's container agree where the reference touches it
+    import torch
+    b = torch.tensor([[-5.0, 3.0, 2000.0, 40.0], [10.0, 20.0, 5.0, 800.0], [1.0, 2.0, 3.0, 4.0]])
+    for cls in (m.BoxList, S.BoxList):
+        bl = cls(b.clone(), (1280, 704), "xyxy")
+        bl.add_field("ids", torch.arange(3))
+        kept = bl.clip_to_image(remove_empty=True)
+        assert bl.bbox.tolist() == [[0.0, 3.0, 1279.0, 40.0], [10.0, 20.0, 5.0, 703.0], [1.0, 2.0, 3.0, 4.0]]
+        assert kept.get_field("ids").tolist() == [0, 2] and len(bl) == 3          # filtered COPY; the original keeps every row
+        assert bl.area().tolist() == [1280.0 * 38.0, -4.0 * 684.0, 9.0]
+        x = bl.convert("xywh")
+        assert x.bbox[2].tolist() == [1.0, 2.0, 3.0, 3.0] and x.convert("xyxy").bbox[2].tolist() == [1.0, 2.0, 3.0, 4.0]
+    cat2 = m.cat_boxlist([m.BoxList(b[:1].clone(), (1280, 704)), m.BoxList(b[1:].clone(), (1280, 704))])
+    assert len(cat2) == 3 and m.cat([b]) is b
+
+
 def test_emm_module_mirrors_reference_interface():
     import inspect
     from siammot_amd.config import get_default_cfg

@@ -112,5 +112,64 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     print("closed loop %s lean=%s: %s" % (name, lean, stats))
     if lean:
         assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken
-    assert len(stats["flips"]) <= 2, stats
+    # none is observed; a row one cell away is tolerated only where the REFERENCE's own stored margin is below FLIP_MARGIN
+    assert len(stats["flips"]) <= 2 and all(m < SR.FLIP_MARGIN for (_, _, m, _) in stats["flips"]), stats
+    assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < 1e-4, stats
+
+
+# ---- the reference's call sequence, transcribed (tests/reference_call_sequence.py), around the head ---------------------
+def _reference_loop(tracker, case, cfg):
+    import reference_call_sequence as RC
+    return RC.ReferenceLoop(tracker, build_track_utils(cfg), case["thresholds"], case["max_dormant_frames"])
+
+
+def test_reference_call_sequence_transcription_reproduces_the_reference_golden():
+    """Pins tests/reference_call_sequence.py (TrackHead / TrackPool / TrackSolver / CombinedROIHeads.forward restated on
+    the oracle's upstream-style BoxList — nothing of this repository's tracking glue) against the reference-generated
+    closed loop: with the oracle head on CPU it must reproduce sequence_plain.npz exactly like the reference did."""
+    golden = SR.load_golden("plain")
+    inp = gi.SequenceInputs("plain")
+    cfg = SR.sequence_cfg(inp.case)
+    emm = SR.OracleEMM(inp.params, inp.case["channels"], build_track_utils(cfg))
+    loop = _reference_loop(emm, inp.case, cfg)
+    stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm))
+    assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
+    assert stats["tracked_rows"] > 300 and stats["raw_rows"] > 300, stats
+
+
+@pytest.mark.gpu
+def test_hip_head_driven_by_the_reference_call_sequence_equals_the_reference():
+    """VERDICT r3 missing #4: the HIP ``EMM`` called exactly as the reference's TrackHead calls its tracker — general
+    ``forward`` / ``extract_cache``, upstream-style BoxLists that are NOT this package's class, memories concatenated with
+    dormant tracks' cache rows — over the whole reference-generated sequence: ids / labels / pool / memory order identical
+    in every frame, boxes >= 1 - 1e-3 IoU, no arg-max flip."""
+    from siammot_amd.emm import EMM
+    from siammot_amd import structures
+    import reference_call_sequence as RC
+    golden = SR.load_golden("plain")
+    inp = gi.SequenceInputs("plain")
+    cfg = SR.sequence_cfg(inp.case)
+    emm = EMM(cfg, build_track_utils(cfg)).to("cuda:0").eval()
+    emm.predictor.load_state_dict({k: torch.from_numpy(v) for k, v in inp.params.items()})
+    loop = _reference_loop(emm, inp.case, cfg)
+    seen = {"forward": 0, "extract": 0, "merged": 0}
+    fwd, ext = emm.forward, emm.extract_cache
+
+    def forward(features, boxes, sr, targets=None, template_features=None):
+        assert type(boxes[0]) is RC.BoxList and type(sr[0]) is RC.BoxList and not isinstance(boxes[0], structures.BoxList)
+        seen["forward"] += 1
+        seen["merged"] += int(getattr(sr[0], "order_hint", None) is None)      # a concatenated memory carries no hint
+        out = fwd(features, boxes, sr, targets=targets, template_features=template_features)
+        assert type(out[1][0]) is RC.BoxList
+        return out
+
+    def extract_cache(features, detection):
+        assert type(detection) is RC.BoxList
+        seen["extract"] += 1
+        return ext(features, detection)
+    emm.forward, emm.extract_cache = forward, extract_cache
+    stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm))
+    print("reference call sequence around the HIP head: %s %s" % (stats, seen))
+    assert seen["forward"] >= stats["frames"] - 2 and seen["extract"] >= stats["frames"] - 2 and seen["merged"] > 0, seen
+    assert stats["flips"] == [], stats
     assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < 1e-4, stats
