@@ -242,7 +242,7 @@ def hipgraph_loop_throughput(emm, feats, det, state, steps):
             "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
 
 
-def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None):
+def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None):
     """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
     the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
     cycle, ONE host sync) -> EMM.extract_cache + track memory.  Fixed track count: the n boxes sit on a
@@ -309,6 +309,8 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     fresh_scores = list(torch.full((steps + 31, n), 0.9, device=dev).unbind(0))   # one row per frame, made before the loop
     if native is not None:
         loop.native_frame = bool(native)
+    if loop_hint is not None:
+        loop.loop_order_hint = bool(loop_hint)          # A/B (measure/loop_hint_ab2.py): the extraction's order hint in the loop
 
     def dets(k):
         b, ids, labels = pre[k & 1]

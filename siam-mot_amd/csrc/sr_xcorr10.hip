@@ -244,6 +244,11 @@ sr_xcorr_fused10_kernel(LevelParams P, int C, const int* __restrict__ plans, con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long t_start = trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
+    // experiment (abl >= 256): the second half of the workgroup's waves (the SIMDs' second waves) start (abl >> 8) * 512
+    // cycles late, so that their load / pooling phase runs beside the first half's correlation
+    if ((abl >> 8) && wave >= FX10_WAVES / 2) {
+        for (int d = 0; d < (abl >> 8); ++d) __builtin_amdgcn_s_sleep(8);
+    }
     // item L of the cost-sorted list: (rank k, channel group) — expensive rois are dispatched first
     const int ny = (C + FX10_WAVES - 1) / FX10_WAVES;
     const int L = blockIdx.x;

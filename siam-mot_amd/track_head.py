@@ -118,17 +118,21 @@ class _LazyMemory(object):
     and two BoxLists are built on first access.  The next frame's head only needs five POINTERS into the solver's output
     buffers and the extraction's outputs (``pointers``) — building the views costs ~8 us of host time on the frame's
     serial chain and, frame after frame, nobody looks at them.  Indexing / iterating / ``len`` behave like the tuple."""
-    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls")
+    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls", "hint_ptr")
 
-    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls):
+    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls, hint_ptr=0):
         self._val = None
         self.fbuf, self.ibuf, self.templates, self.sr_rows = fbuf, ibuf, templates, sr_rows
         self.M, self.A, self.size, self.sr_size, self.host_ids, self.cls = M, A, size, sr_size, host_ids, cls
+        # device address of the order hint the masked extraction wrote for exactly rows 0 .. A-1 (it lives behind the
+        # frame's float outputs in `fbuf`), or 0.  It needs no host object: the memory IS the extraction's output, untouched
+        # — the condition under which this class is used at all — so the hint is valid by construction.
+        self.hint_ptr = hint_ptr
 
     def pointers(self):
-        """(template boxes, search regions, templates, ids, labels) of rows 0 .. A-1 as device addresses."""
+        """(template boxes, search regions, templates, ids, labels, order hint or 0) of rows 0 .. A-1 as device addresses."""
         fp, ip, M = self.fbuf.data_ptr(), self.ibuf.data_ptr(), self.M
-        return fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M
+        return fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M, self.hint_ptr
 
     def _materialise(self):
         v = self._val
@@ -276,7 +280,7 @@ class TrackingLoop(torch.nn.Module):
         ring.wait(rec_host)                                                        # the frame's one synchronisation
         return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre)
 
-    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None):
+    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None, hint_ptr=0):
         """After the record arrived: mirror the pool, slice the outputs, build the next track memory.  This is host work on
         the frame's serial chain: ten strided views straight off the two output buffers (no intermediate splits), the
         record through the ring's numpy view, BoxLists of this package's own class without re-validation."""
@@ -308,7 +312,7 @@ class TrackingLoop(torch.nn.Module):
             # the general path's TrackHead._get_track_targets only) is not needed either
             pad2 = emm.track_utils.pad_pixels * 2
             memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A, size, [int(size[0] + pad2), int(size[1] + pad2)],
-                                 rec[8 + 2 * M:8 + 2 * M + A], cls)
+                                 rec[8 + 2 * M:8 + 2 * M + A], cls, hint_ptr if A >= 2 else 0)
             pool.note_memory(memory, memory.host_ids)
             self.__dict__["track_memory"] = memory
             self.__dict__["_own_memory"] = memory
@@ -471,7 +475,7 @@ class TrackingLoop(torch.nn.Module):
         if type(mem) is _LazyMemory and mem._val is None:
             # the memory this loop left behind, untouched since: five addresses, no tensor is built
             n_trk = mem.A
-            head_ptrs = mem.pointers() + (0,)
+            head_ptrs = mem.pointers()
         elif mem is not None and mem[0].numel() > 0:
             z, sr, tb = mem
             tb0, sr0 = tb[0], sr[0]
@@ -512,7 +516,11 @@ class TrackingLoop(torch.nn.Module):
             d0, d1, d2, d3 = db.data_ptr(), dsc.data_ptr(), did.data_ptr(), (dlab.data_ptr() if dlab is not None else 0)
         M = n_det + n_trk
         ring = pool.host_record_ring(dev)
-        fbuf = torch.empty((10 * M,), dtype=torch.float32, device=dev)
+        # float outputs [10 M] and, behind them at a 32-byte boundary, the order hint [M, 8] the masked extraction ranks
+        # the NEXT frame's rois into (one wave of one extra workgroup of that launch; 2..256 rows) — handed to the next
+        # head as a bare address when the memory stays the extraction's own output (_LazyMemory)
+        hint_off = ((10 * M + 7) & ~7) if (2 <= M <= 256 and self.__dict__.get("loop_order_hint", True)) else 0
+        fbuf = torch.empty((hint_off + 8 * M,) if hint_off else (10 * M,), dtype=torch.float32, device=dev)
         ibuf = torch.empty((4 * M,), dtype=torch.int64, device=dev)
         templates = torch.empty((M, P.C, P.rz, P.rz), dtype=torch.float32, device=dev)
         sr_next = torch.empty((M, 4), dtype=torch.float32, device=dev)
@@ -530,7 +538,7 @@ class TrackingLoop(torch.nn.Module):
         addr = a.poke_rest((rw, r0, r1, r2, r3, d0, d1, d2, d3,
                             fp, fp + 32 * M, ip, ip + 8 * M,                       # out_boxes, out_scores, out_ids, out_labels
                             fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,    # act_boxes, act_ids, act_labels, act_scores
-                            rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), 0),
+                            rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), (fp + 4 * hint_off) if hint_off else 0),
                            stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh))
         ops.track_frame_addr(P.lib, addr, dev, stream)
         if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
@@ -542,7 +550,8 @@ class TrackingLoop(torch.nn.Module):
                 if hook is not None:
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
         ring.wait(rec_host, event=False)                                           # the frame's one synchronisation
-        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P)
+        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P,
+                                  hint_ptr=(fp + 4 * hint_off) if hint_off else 0)
 
     @torch.no_grad()
     def forward(self, features, detections):
