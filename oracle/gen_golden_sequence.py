@@ -57,15 +57,17 @@ class Cfg(types.SimpleNamespace):
 
 def reference_cfg(case):
     ns = types.SimpleNamespace
-    emm = ns(USE_CENTERNESS=True, COSINE_WINDOW_WEIGHT=0.4, CLS_POS_REGION=0.8, TRACK_LOSS_WEIGHT=1.0,
+    fam = gi.BENCH_FAMILIES[case.get("family", "default")]       # the yaml family's track-head keys
+    emm = ns(USE_CENTERNESS=fam["use_centerness"], COSINE_WINDOW_WEIGHT=fam["sigma"], CLS_POS_REGION=0.8, TRACK_LOSS_WEIGHT=1.0,
              POS_RATIO=0.25, HN_RATIO=0.25)          # the last two: target sampler only (built, never called)
-    th = ns(POOLER_RESOLUTION=15, POOLER_SCALES=(0.25, 0.125, 0.0625, 0.03125), POOLER_SAMPLING_RATIO=2,
-            SEARCH_REGION=2.0, PAD_PIXELS=512, MINIMUM_SREACH_REGION=0, MAX_DORMANT_FRAMES=case["max_dormant_frames"],
+    th = ns(POOLER_RESOLUTION=fam["rz"], POOLER_SCALES=fam["scales"], POOLER_SAMPLING_RATIO=2,
+            SEARCH_REGION=fam["search_region"], PAD_PIXELS=fam["pad_pixels"], MINIMUM_SREACH_REGION=fam["min_search_wh"],
+            MAX_DORMANT_FRAMES=case["max_dormant_frames"],
             EMM=emm, MODEL="EMM", TRACKTOR=False, FG_IOU_THRESHOLD=0.65, BG_IOU_THRESHOLD=0.35, PROPOSAL_PER_IMAGE=256, TRACK_THRESH=case["thresholds"][0],
             START_TRACK_THRESH=case["thresholds"][1], RESUME_TRACK_THRESH=case["thresholds"][2])
     b = case.get("box_head", dict(resolution=7, sampling_ratio=2, mlp_dim=64, num_classes=2, score_thresh=0.05,
                                   nms=0.5, reg_weights=(10.0, 10.0, 5.0, 5.0)))
-    return Cfg(INPUT=ns(AMODAL=False), TEST=ns(BBOX_AUG=ns(ENABLED=False)),
+    return Cfg(INPUT=ns(AMODAL=bool(case.get("amodal", False))), TEST=ns(BBOX_AUG=ns(ENABLED=False)),
                MODEL=ns(TRACK_ON=True, RPN_ONLY=False, CLS_AGNOSTIC_BBOX_REG=False,
                         BACKBONE=ns(CONV_BODY="DLA-34-FPN"), DLA=ns(BACKBONE_OUT_CHANNELS=case["channels"]),
                         ROI_HEADS=ns(USE_FPN=True, BBOX_REG_WEIGHTS=b["reg_weights"], SCORE_THRESH=b["score_thresh"],
@@ -156,10 +158,12 @@ def run_case(name, save=True):
 
     captured = {}
     real_argmax = torch.argmax
+    fam = gi.BENCH_FAMILIES[case.get("family", "default")]
+    grid = 16 * (int(fam["rz"] * fam["search_region"]) - fam["rz"] + 1)       # 256 (default family), 464 (AOT)
 
     def spy(t, *a, **k):
         r = real_argmax(t, *a, **k)
-        if t.dim() == 2 and t.shape[1] == 256 * 256:
+        if t.dim() == 2 and t.shape[1] == grid * grid:                  # decode_response's score map (track_core.py:120)
             top2 = torch.topk(t, 2, dim=1).values
             captured.update(idx=r.clone(), margin=(top2[:, 0] - top2[:, 1]).clone())
         return r
@@ -193,7 +197,11 @@ def run_case(name, save=True):
         prev_active = set(track_pool._active_ids)
         prev_dormant = set(track_pool._dormant_ids)
         prev_max = track_pool._max_id
-        memory, result, _ = heads(feats, dets, track_memory=memory)        # roi_heads.py:22 (rcnn.py:54 passes these)
+        if case.get("given_detections"):
+            # INFERENCE.USE_GIVEN_DETECTIONS: the cached detections arrive as `given_detection` (roi_heads.py:23-32, rcnn.py:54)
+            memory, result, _ = heads(feats, None, track_memory=memory, given_detection=dets)
+        else:
+            memory, result, _ = heads(feats, dets, track_memory=memory)    # roi_heads.py:22 (rcnn.py:54 passes these)
         res = result[0]
         act, dorm = set(track_pool._active_ids), dict(track_pool._dormant_ids)
         events["start"] += track_pool._max_id - prev_max

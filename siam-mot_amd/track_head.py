@@ -236,7 +236,7 @@ class TrackingLoop(torch.nn.Module):
                 return False
         elif refine is not None and getattr(refine, "raw_ok", None) is None:
             return False
-        if not detections.bbox.is_cuda or emm.rz != 15 or detections.mode != "xyxy":
+        if not detections.bbox.is_cuda or emm.rz not in (15, 7) or detections.mode != "xyxy":     # (the masked extraction's shapes)
             return False
         kernel_fields = solver._KERNEL_FIELDS
         for f in detections.fields():
@@ -358,7 +358,7 @@ class TrackingLoop(torch.nn.Module):
         if P is None:
             emm = self.track.tracker
             fz = emm.feature_extractor.pooler_z
-            if not (emm.rz == 15 and fz.sampling_ratio == 2):
+            if not (emm.rz in (15, 7) and fz.sampling_ratio == 2):
                 return False
         st = self.__dict__.get("_lean_static")
         if st is not None and st[5] is not None:                         # with refinement: the box head's whole chain must

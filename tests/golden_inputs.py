@@ -177,6 +177,21 @@ SEQ_CASES = {
                    max_dormant_frames=2, n_objects=10, refine=True, cls_bias=(1.0, -1.0), reg_gain=1.0,
                    box_head=dict(resolution=7, sampling_ratio=2, mlp_dim=64, num_classes=2, score_thresh=0.05,
                                  nms=0.5, reg_weights=(10.0, 10.0, 5.0, 5.0))),
+    # the second yaml family in the loop (configs/dla/DLA_34_FPN_EMM_AOT.yaml:52-63: 7x7 templates, search region x5 ->
+    # 35x35, 29x29 response, no centerness, cosine window 0.1, pad 256, TRACK_THRESH 0.6 / START_TRACK_THRESH 0.95): small
+    # objects (that data set's airborne objects), a detector whose scores reach the start threshold
+    "aot": dict(channels=128, image_wh=(1280, 704), frames=12, seed=330, thresholds=(0.6, 0.95, 0.4),
+                max_dormant_frames=2, n_objects=7, refine=False, cls_bias=(-0.7, 0.7), reg_gain=1.0, family="aot",
+                object_sizes=[(30, 30), (44, 36), (24, 28), (60, 48), (36, 40), (52, 60)], reg_size=(40.0, 40.0),
+                det_scores=(0.85, 0.995)),
+    # INPUT.AMODAL: True and INFERENCE.USE_GIVEN_DETECTIONS (configs/dla/DLA_34_FPN_EMM_MOT17.yaml:19-20,51-52): neither
+    # the head nor the box head clips to the image, the detections enter through CombinedROIHeads.forward's
+    # `given_detection` argument (roi_heads.py:23-32) and may stick out of the frame, objects leave through the border
+    "amodal": dict(channels=128, image_wh=(1280, 704), frames=18, seed=213, thresholds=(0.4, 0.6, 0.4),
+                   max_dormant_frames=3, n_objects=10, refine=True, cls_bias=(1.0, -1.0), reg_gain=1.0, amodal=True,
+                   given_detections=True, edge_fraction=0.3,
+                   box_head=dict(resolution=7, sampling_ratio=2, mlp_dim=64, num_classes=2, score_thresh=0.05,
+                                 nms=0.5, reg_weights=(10.0, 10.0, 5.0, 5.0))),
 }
 # Random-init regression heads predict a box of about the bias size whatever the object: most objects are near that
 # size (straddling the FPN level 1 / 2 boundary at sqrt(area) = 224) so that tracks and detections keep meeting in
@@ -196,7 +211,8 @@ class SequenceInputs(object):
         shapes = feature_shapes(c["image_wh"], c["channels"])
         self._fields = [[rs.standard_normal(s).astype(F32) for s in shapes] for _ in range(3)]
         self._objects(rs)
-        boxes = np.array([[0, 0, SEQ_REG_SIZE[0], SEQ_REG_SIZE[1]]], dtype=F32)
+        reg_size = c.get("reg_size", SEQ_REG_SIZE)
+        boxes = np.array([[0, 0, reg_size[0], reg_size[1]]], dtype=F32)
         self.params = predictor_params(rs, c["channels"], boxes)
         self.params["cls.bias"] = np.array(c["cls_bias"], dtype=F32)
         for k in ("reg.weight",):
@@ -223,9 +239,13 @@ class SequenceInputs(object):
         c = self.case
         W, H = c["image_wh"]
         n, T = c["n_objects"], c["frames"]
-        self.obj_wh = np.array([SEQ_OBJECT_SIZES[i % len(SEQ_OBJECT_SIZES)] for i in range(n)], dtype=np.float64)
+        sizes = c.get("object_sizes", SEQ_OBJECT_SIZES)
+        self.obj_wh = np.array([sizes[i % len(sizes)] for i in range(n)], dtype=np.float64)
         lo = self.obj_wh / 2 + 4
         hi = np.array([W, H]) - self.obj_wh / 2 - 4
+        if c.get("edge_fraction"):               # amodal: centres may start that fraction of a box beyond the border
+            lo = lo - (0.5 + c["edge_fraction"]) * self.obj_wh
+            hi = hi + (0.5 + c["edge_fraction"]) * self.obj_wh
         self.obj_c0 = lo + rs.uniform(0, 1, (n, 2)) * (hi - lo)
         self.obj_vel = rs.uniform(-2.5, 2.5, (n, 2))
         self.obj_first = np.where(np.arange(n) % 4 == 3, rs.randint(2, T // 2, n), 0)       # late arrivals
@@ -256,9 +276,11 @@ class SequenceInputs(object):
         fc = rs.uniform(60, [W - 60.0, H - 60.0], (nfp, 2))
         fwh = rs.uniform(30, 110, (nfp, 2))
         boxes = np.concatenate((boxes, np.concatenate((fc - fwh / 2, fc + fwh / 2), 1)), 0)
-        boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, W - 1)
-        boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, H - 1)
-        scores = rs.uniform(0.45, 0.99, len(boxes))
+        if not c.get("amodal"):
+            boxes[:, 0::2] = np.clip(boxes[:, 0::2], 0, W - 1)
+            boxes[:, 1::2] = np.clip(boxes[:, 1::2], 0, H - 1)
+        lo_s, hi_s = c.get("det_scores", (0.45, 0.99))
+        scores = rs.uniform(lo_s, hi_s, len(boxes))
         return boxes.astype(F32), scores.astype(F32)
 
 

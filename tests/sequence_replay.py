@@ -22,6 +22,11 @@ def sequence_cfg(case):
     th = cfg.MODEL.TRACK_HEAD
     th.TRACK_THRESH, th.START_TRACK_THRESH, th.RESUME_TRACK_THRESH = case["thresholds"]
     th.MAX_DORMANT_FRAMES = case["max_dormant_frames"]
+    fam = gi.BENCH_FAMILIES[case.get("family", "default")]           # the yaml family's track-head keys
+    th.POOLER_RESOLUTION, th.SEARCH_REGION, th.PAD_PIXELS = fam["rz"], fam["search_region"], fam["pad_pixels"]
+    th.MINIMUM_SREACH_REGION, th.POOLER_SCALES = fam["min_search_wh"], fam["scales"]
+    th.EMM.USE_CENTERNESS, th.EMM.COSINE_WINDOW_WEIGHT = fam["use_centerness"], fam["sigma"]
+    cfg.INPUT.AMODAL = bool(case.get("amodal", False))
     if case["refine"]:
         b = case["box_head"]
         cfg.MODEL.ROI_BOX_HEAD.MLP_HEAD_DIM = b["mlp_dim"]
@@ -37,12 +42,16 @@ def sequence_cfg(case):
 class OracleEMM(torch.nn.Module):
     """oracle/emm_oracle.py behind ``EMM.forward`` / ``EMM.extract_cache`` (CPU tensors)."""
 
-    def __init__(self, params, channels, track_utils, reference_ops=True):
+    def __init__(self, params, channels, track_utils, reference_ops=True, case=None):
         super(OracleEMM, self).__init__()
         self.reference_ops = reference_ops
         from oracle import emm_oracle as O
         self.O = O
-        self.ocfg = O.EMMConfig(channels=channels)
+        fam = gi.BENCH_FAMILIES[(case or {}).get("family", "default")]
+        self.ocfg = O.EMMConfig(channels=channels, rz=fam["rz"], search_region=fam["search_region"], scales=fam["scales"],
+                                pad_pixels=fam["pad_pixels"], min_search_wh=fam["min_search_wh"],
+                                use_centerness=fam["use_centerness"], sigma=fam["sigma"],
+                                amodal=bool((case or {}).get("amodal", False)))
         self.params = {k: torch.from_numpy(v) for k, v in params.items()}
         self.track_utils = track_utils
         self.last = None

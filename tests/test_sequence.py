@@ -37,7 +37,7 @@ def _cpu_loop(name):
     cfg = SR.sequence_cfg(case)
     tu = build_track_utils(cfg)
     pool = TrackPool(max_dormant_frames=case["max_dormant_frames"])
-    emm = SR.OracleEMM(inp.params, case["channels"], tu)
+    emm = SR.OracleEMM(inp.params, case["channels"], tu, case=case)
     refine = None
     if case["refine"]:
         b = case["box_head"]
@@ -50,7 +50,7 @@ def _cpu_loop(name):
     return inp, emm, TrackingLoop(TrackHead(emm, tu, pool).eval(), solver, refine).eval()
 
 
-@pytest.mark.parametrize("name", ["plain", "refine"])
+@pytest.mark.parametrize("name", ["plain", "refine", "aot", "amodal"])
 def test_closed_loop_on_cpu_equals_the_reference(name):
     """Oracle head + this repository's TrackHead / solver / pool (+ RefineTracks / TrackBoxHead over the oracle
     pooler) reproduce the reference's closed loop: same ids, same pool, boxes to fp32 rounding — every event type
@@ -59,11 +59,15 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
     for ev in ("start", "suspend", "resume", "expire"):
         assert int(golden["events_" + ev]) > 0, ev
     inp, emm, loop = _cpu_loop(name)
+    # (the amodal + given-detections case replays its first ten frames here: the oracle head and box head on CPU cost
+    # seconds per frame at 30-40 rows; the device test runs every frame)
+    frames = 10 if name == "amodal" else None
     with torch.no_grad():
-        stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm),
+        stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm), frames=frames,
                           box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
     assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
-    assert stats["tracked_rows"] > 300 and stats["raw_rows"] > 300, stats
+    floor = {"plain": 300, "refine": 300, "aot": 60, "amodal": 100}[name]
+    assert stats["tracked_rows"] > floor and stats["raw_rows"] > floor, stats
 
 
 def _gpu_loop(name, lean):
@@ -90,7 +94,8 @@ def _gpu_loop(name, lean):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("plain", "python"), ("refine", False),
-                                       ("refine", True), ("refine", "python")])
+                                       ("refine", True), ("refine", "python"), ("aot", False), ("aot", True),
+                                       ("aot", "python"), ("amodal", False), ("amodal", True), ("amodal", "python")])
 def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     """The real head in the loop, on the device: (i) general path, (ii) one-launch path behind ONE library call
     (smot_track_frame_fwd), ("python") the same sequence composed in Python, (iii) refinement on (all three).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
