@@ -304,7 +304,6 @@ int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* m
  *   track memory pass NULL.  For the masked form the hint covers the first *n_valid rows.
  */
 #define SMOT_HINT_FLOATS 8
-#define SMOT_PLAN_FLOATS 1024  /* one roi plan (sr_xcorr10.hip): header, both sample tables */
 long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio);
 
 long long smot_emm_track_ws_floats(int N, int C, int rx, int rz);

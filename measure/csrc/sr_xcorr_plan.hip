@@ -28,6 +28,8 @@
 #include "knobs.h"
 #include <type_traits>
 
+#define SMOT_PLAN_FLOATS 1024      // one roi plan: header, band list, both sample tables
+
 namespace smot {
 
 // ---- roi plan: 1024 dwords per roi, entry k = the roi of rank k in the cost-sorted order ---------------------------
@@ -549,6 +551,7 @@ sr_xcorr_fused10_kernel(LevelParams P, int C, const int* __restrict__ plans, con
 }
 
 // ---- launches ----------------------------------------------------------------------------------------------------------
+int fused10_plan_floats() { return SMOT_PLAN_FLOATS; }
 int launch_roi_plans(const LevelParams& P, const float* sr, const float* boxes, int N, float* plans, hipStream_t st) {
     hipLaunchKernelGGL((roi_plan_kernel<30, 2>), dim3(N), dim3(64), 0, st, P, sr, boxes, N, reinterpret_cast<int*>(plans));
     return check_launch("roi_plans");

@@ -242,6 +242,8 @@ class TrackBoxHead(nn.Module):
             return out
         x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
         x = x.view(x.shape[0], -1)
+        if x.shape[0] > ops.linear_rows_max_rows():
+            ops.FALLBACKS["refine_library_gemm"] += 1
         if x.shape[0] <= ops.linear_rows_max_rows() and x.shape[1] % 4 == 0 and fe.fc6.out_features % 4 == 0 \
                 and fe.fc7.out_features % 4 == 0:
             # a handful of rows: weight-streaming kernels on all CUs (csrc/linear_rows.hip); the two predictor layers

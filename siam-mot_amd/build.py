@@ -5,7 +5,7 @@
 
 Two libraries come out of the same sources:
   csrc/libsmot_emm.so        the product: no environment variable is read, no kernel A/B switch, no ablation;
-  csrc/libsmot_emm_debug.so  the measurement build (-DSMOT_DEBUG, + measure/csrc/xcorr_variants.hip): older kernel generations,
+  csrc/libsmot_emm_debug.so  the measurement build (-DSMOT_DEBUG, + measure/csrc/*.hip and *.inc): older kernel generations,
                              A/B switches and timing ablations for tools/ and the A/B tests (csrc/knobs.h).
 
 The library is plain HIP behind a C ABI (include/smot_emm.h): no torch headers, so it is
@@ -21,8 +21,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsmot_emm.so")
 LIB_DEBUG = os.path.join(CSRC, "libsmot_emm_debug.so")
 MEASURE_CSRC = os.path.join(os.path.dirname(HERE), "measure", "csrc")      # measurement-only sources (not product)
-DEBUG_ONLY_SOURCES = ["xcorr_variants.hip"]
-SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "sr_xcorr10.hip", "nms.hip", "tower_wino.hip", "tower_conv.hip", "preprocess.hip",
+DEBUG_ONLY_SOURCES = ["xcorr_variants.hip", "sr_xcorr_plan.hip"]
+SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "nms.hip", "tower_wino.hip", "tower_conv.hip", "preprocess.hip",
            "emm_fused.hip", "track_solver.hip", "box_refine.hip", "linear_rows.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of
@@ -46,6 +46,8 @@ def _src(name):
 
 def _deps(sources):
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    if any(s in DEBUG_ONLY_SOURCES for s in sources):      # the measurement build also includes measure/csrc/*.inc
+        hdrs += [os.path.join(MEASURE_CSRC, f) for f in sorted(os.listdir(MEASURE_CSRC)) if f.endswith(".inc")]
     return [_src(s) for s in sources] + hdrs + [
         os.path.join(os.path.dirname(HERE), "include", "smot_emm.h"), os.path.abspath(__file__)]
 

@@ -497,228 +497,8 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
 }
 
 #ifdef SMOT_DEBUG
-// ---- round-1 structure (band kernel + finalize launch), measurement library only: SMOT_DECODE_2PASS=1 -------------
-
-// SPLIT: workgroups of 256*SPLIT threads; the band's output rows are divided among the SPLIT thread groups
-// (SPLIT = 2 halves the serial row walk of a lane at the price of a duplicated horizontal pass).
-template <int SPLIT>
-__global__ void __launch_bounds__(256 * SPLIT)
-decode_band_kernel(LogitSrc L, const float* __restrict__ boxes,
-                   const float* __restrict__ hann, DecodeParams D,
-                   unsigned long long* __restrict__ cand) {
-    extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
-    __shared__ unsigned long long wbest[4 * SPLIT];
-    const int tcol = threadIdx.x & 255, part = threadIdx.x >> 8;
-    __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
-    __shared__ float dv[4][4][64];     // ranking planes {cls0-cls1, center, l+r, t+b} of the band's 4 source rows
-    const int n = blockIdx.x;
-    const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
-    const int Ho = D.Ho, up = D.up, G = D.G;
-    if (L.logits != nullptr) {
-        for (int e = threadIdx.x; e < 7 * Ho * Ho; e += blockDim.x) {
-            const int ch = e / (Ho * Ho);
-            lg[e] = L.get(n, ch, e - ch * Ho * Ho, Ho * Ho);
-        }
-    } else if (blockIdx.y == 0) {
-        // Ho == 16, band-0 workgroup: all 7 x 256 combined logits (it also leaves them in HBM for pass 2);
-        // thread = position; the 7 channels' tile loads are independent (56 in flight at C = 128)
-        if (part == 0) {
-            float c7[7];
-#pragma unroll
-            for (int ch = 0; ch < 7; ++ch) c7[ch] = L.combine(n, ch, tcol);
-#pragma unroll
-            for (int ch = 0; ch < 7; ++ch) {
-                lg[ch * 256 + tcol] = c7[ch];
-                L.logits_out[((size_t)n * 7 + ch) * 256 + tcol] = c7[ch];
-            }
-        }
-    } else {
-        // other bands only touch their four source rows f-1..f+2 (clamped): 7 x 4 x 16 = 448 logits
-        constexpr int NJ = (448 + 256 * SPLIT - 1) / (256 * SPLIT);
-        float c2[2];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int e = threadIdx.x + 256 * SPLIT * j;          // (ch, k, col)
-            const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
-            c2[j] = (e < 448) ? L.combine(n, ch, row * 16 + (e & 15)) : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int e = threadIdx.x + 256 * SPLIT * j;
-            const int ch = e >> 6, row = clampi(f - 1 + ((e >> 4) & 3), 0, Ho - 1);
-            if (e < 448) lg[ch * 256 + row * 16 + (e & 15)] = c2[j];   // clamped duplicates write equal values
-        }
-    }
-    const int y_begin = max(0, up * f + up / 2);
-    const int y_end = min(G, up * f + up / 2 + up);
-    if ((int)threadIdx.x < y_end - y_begin) {      // row coefficients are lane-independent: once per band
-        int by;
-        float ty, w4[4];
-        cubic_src(y_begin + threadIdx.x, D.inv_up, &by, &ty);
-        cubic_coeffs(ty, w4);
-        wy_tab[threadIdx.x][0] = w4[0];
-        wy_tab[threadIdx.x][1] = w4[1];
-        wy_tab[threadIdx.x][2] = w4[2];
-        wy_tab[threadIdx.x][3] = w4[3];
-    }
-    __syncthreads();
-
-    int rows[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
-    for (int e = threadIdx.x; e < 4 * Ho; e += 256 * SPLIT) {      // (k, col)
-        const int k = e / Ho, col = e - k * Ho;
-        const float* q = lg + rows[k] * Ho + col;
-        const int hw = Ho * Ho;
-        dv[0][k][col] = q[0] - q[hw];
-        dv[1][k][col] = q[2 * hw];
-        dv[2][k][col] = q[5 * hw] + q[3 * hw];
-        dv[3][k][col] = q[6 * hw] + q[4 * hw];
-    }
-    __syncthreads();
-    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
-    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
-    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
-
-    unsigned long long best = 0ull;
-    bool have = false;
-#pragma unroll 1
-    for (int j = 0; j < DEC_MAX_COLS; ++j) {
-        const int X = tcol + 256 * j;
-        if (X >= G) break;
-        int bx;
-        float tx, wx[4];
-        cubic_src(X, D.inv_up, &bx, &tx);
-        cubic_coeffs(tx, wx);
-        int cols[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
-        // horizontal pass: h[ch][k] for the band's four source rows
-        float h[4][4];
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float* rowp = dv[ch][k];
-                h[ch][k] = interp4_fma(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
-            }
-        const float hx = hann[X];
-        const int rows_per_part = (y_end - y_begin + SPLIT - 1) / SPLIT;
-        const int y0p = y_begin + part * rows_per_part, y1p = min(y_end, y0p + rows_per_part);
-        for (int Y = y0p; Y < y1p; ++Y) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wy_tab[Y - y_begin]);
-            const float wy[4] = {w4.x, w4.y, w4.z, w4.w};
-            float v[4];
-#pragma unroll
-            for (int ch = 0; ch < 4; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
-            const float win = hann[Y] * hx;
-            const float s = cell_score_fast(v, inv_bw, inv_bh, win, D);
-            const unsigned long long key = make_key(s, (unsigned)(Y * G + X));
-            if (!have || key > best) {
-                best = key;
-                have = true;
-            }
-        }
-    }
-    // lanes without a column carry key 0 (below every real key: real keys have a non-zero low word
-    // unless idx == 0xFFFFFFFF, which cannot occur)
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(best, m);
-        best = (o > best) ? o : best;
-    }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) wbest[wave] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long b = wbest[0];
-        for (int w = 1; w < 4 * SPLIT; ++w) b = (wbest[w] > b) ? wbest[w] : b;
-        cand[(size_t)n * gridDim.y + blockIdx.y] = b;
-    }
-}
-
-__global__ void __launch_bounds__(64)
-decode_finalize_kernel(LogitSrc L, const float* __restrict__ sr,
-                       const float* __restrict__ boxes, const float* __restrict__ hann, DecodeParams D, int rx,
-                       int rz, float pad, const unsigned long long* __restrict__ cand, int nband, float clip_w,
-                       float clip_h,
-                       float* __restrict__ bb, float* __restrict__ conf, long long* __restrict__ idx_out) {
-    const int n = blockIdx.x;
-    const int lane = threadIdx.x;
-    // lane b re-scores band b's candidate with the exact (reference-sequence) arithmetic; bands beyond 64
-    // (up-sampled grids taller than 63*up rows) are folded onto the lanes by their search-pass keys
-    unsigned long long cand_key = 0ull;
-    for (int b = lane; b < nband; b += 64) {
-        const unsigned long long k = cand[(size_t)n * nband + b];
-        cand_key = (k > cand_key) ? k : cand_key;
-    }
-    const bool have = cand_key != 0ull;
-    const unsigned idx = have ? 0xFFFFFFFFu - (unsigned)(cand_key & 0xFFFFFFFFull) : 0u;
-    const int Ho = D.Ho, G = D.G;
-    const int Y = (int)(idx / (unsigned)G), X = (int)(idx - (unsigned)Y * (unsigned)G);
-    int bx, by;
-    float tx, ty, wx[4], wy[4];
-    cubic_src(X, D.inv_up, &bx, &tx);
-    cubic_src(Y, D.inv_up, &by, &ty);
-    cubic_coeffs(tx, wx);
-    cubic_coeffs(ty, wy);
-    int cols[4], rows[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        cols[k] = clampi(bx - 1 + k, 0, Ho - 1);
-        rows[k] = clampi(by - 1 + k, 0, Ho - 1);
-    }
-    float v[7];
-#pragma unroll
-    for (int ch = 0; ch < 7; ++ch) {
-        float h[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int rb = rows[k] * Ho;
-            h[k] = interp4(L.get(n, ch, rb + cols[0], Ho * Ho), L.get(n, ch, rb + cols[1], Ho * Ho),
-                           L.get(n, ch, rb + cols[2], Ho * Ho), L.get(n, ch, rb + cols[3], Ho * Ho), wx);
-        }
-        v[ch] = interp4(h[0], h[1], h[2], h[3], wy);
-    }
-    // get_locations (track_core.py:184-225): x_k = x1 + (st+k)*((x2-x1)/(rx*up-1)), then -= pad
-    const int full = rx * D.up;
-    const int st = (rz / 2) * D.up;
-    const float sx1 = sr[n * 4 + 0], sy1 = sr[n * 4 + 1], sx2 = sr[n * 4 + 2], sy2 = sr[n * 4 + 3];
-    const float stride_w = div_rn(sub_rn(sx2, sx1), (float)(full - 1));
-    const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
-    const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), pad);
-    const float cy = sub_rn(add_rn(sy1, mul_rn((float)(st + Y), stride_h)), pad);
-    // exact score of this lane's candidate -> exact arg-max over the band winners
-    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
-    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
-    const float score = cell_score(v, box_w, box_h, mul_rn(hann[Y], hann[X]), D);
-    const unsigned long long my_key = have ? make_key(score, idx) : 0ull;
-    unsigned long long best = my_key;
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const unsigned long long o = shfl_xor_u64(best, m);
-        best = (o > best) ? o : best;
-    }
-    if (!have || my_key != best) return;      // keys are unique per cell index: exactly one lane continues
-    float bx1 = sub_rn(cx, v[3]), by1 = sub_rn(cy, v[4]);
-    float bx2 = add_rn(cx, v[5]), by2 = add_rn(cy, v[6]);
-    if (clip_w > 0.0f) {
-        // BoxList.clip_to_image (TO_REMOVE = 1): x in [0, w-1], y in [0, h-1]; NaN passes through
-        bx1 = clamp_nan(bx1, 0.0f, clip_w - 1.0f);
-        by1 = clamp_nan(by1, 0.0f, clip_h - 1.0f);
-        bx2 = clamp_nan(bx2, 0.0f, clip_w - 1.0f);
-        by2 = clamp_nan(by2, 0.0f, clip_h - 1.0f);
-    }
-    bb[n * 4 + 0] = bx1;
-    bb[n * 4 + 1] = by1;
-    bb[n * 4 + 2] = bx2;
-    bb[n * 4 + 3] = by2;
-    const float m = fmaxf(v[0], v[1]);
-    const float e0 = expf(sub_rn(v[0], m)), e1 = expf(sub_rn(v[1], m));
-    conf[n] = div_rn(e1, add_rn(e0, e1));
-    if (idx_out != nullptr) idx_out[n] = (long long)idx;
-}
-#endif  // SMOT_DEBUG (two-pass decode)
+#include "../../measure/csrc/decode_two_pass.inc"      // measurement library only (not product source)
+#endif
 
 }  // namespace smot
 

@@ -66,241 +66,8 @@ __device__ __forceinline__ gptr_t uniform_base(const float* p) {
 }
 
 #ifdef SMOT_DEBUG
-// ---- second generation: one plane per wave, eight waves per workgroup ------------------------------------
-// Same workgroup = (track, 8 channels) and the same LDS image, but every wave pools ONE plane: twice the waves
-// (and row loads) in flight per workgroup, and for windows <= 32 columns the two half-waves take the two halves
-// of the pooled rows, so the whole plane is ONE batch of row loads (one memory round trip instead of two to
-// four per wave).  Waves 0..3 then run the correlation on the plane pairs (0,1) (2,3) (4,5) (6,7).
-template <int RX, int RZ, int G, bool XCORR>
-__global__ void __launch_bounds__(512, 4)      // <= 128 VGPRs: two workgroups (16 waves) per CU
-sr_xcorr_fused8_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
-                       const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
-                       int32_t* __restrict__ levels_out, SrOut S) {
-    constexpr int HO = XCORR ? RX - RZ + 1 : 16;
-    constexpr int NS = RX * G;                   // samples per axis
-    constexpr int XS = XP2_XS, XP = XP2_XP, ZS = XP2_ZS, ZP = RZ * XP2_ZS;
-    constexpr int RH = (RX + 1) / 2;             // pooled rows per half-wave (dual-row mode) / per batch
-    static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP, "see sr_xcorr_fused_kernel");
-    __shared__ __attribute__((aligned(16))) float sm[4 * (2 * XP + 2 * ZP)];
-    __shared__ int y_lo[NS + 2 * G], y_hi[NS + 2 * G], x_lo[NS], x_hi[NS];     // y tables padded for the masked tail rows
-    __shared__ float wy_lo[NS + 2 * G], wy_hi[NS + 2 * G], wx_lo[NS], wx_hi[NS];
-    __shared__ int wbound[4];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7 = plane within the workgroup
-    const int n = blockIdx.x;
-    const int c0 = blockIdx.y * FX_CH;
-#define FX_TRACE(SLOT)                                                                      \
-    if (S.trace && tid == 0)                                                                \
-        S.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
-    FX_TRACE(0)
-    float* xs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;             // this wave's pooled plane
-    float* zs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;    // this wave's template
-
-    const float* roi = sr + (size_t)n * 4;
-    int lvl = 0;
-    if (P.num_levels > 1) lvl = map_level(boxes + (size_t)n * 4, P.k_min, P.k_max);
-    lvl = __builtin_amdgcn_readfirstlane(lvl);
-    if (levels_out != nullptr && blockIdx.y == 0 && tid == 0) levels_out[n] = lvl;
-    if (!XCORR && S.sr != nullptr && blockIdx.y == 0 && tid == 0) {
-        const float bx1 = add_rn(roi[0], S.pad), by1 = add_rn(roi[1], S.pad);
-        const float bx2 = add_rn(roi[2], S.pad), by2 = add_rn(roi[3], S.pad);
-        const float bw = add_rn(sub_rn(bx2, bx1), 1.0f), bh = add_rn(sub_rn(by2, by1), 1.0f);
-        const float w_ext = max_nan(div_rn(sub_rn(S.min_wh, bw), S.two_e), mul_rn(bw, S.half_e));
-        const float h_ext = max_nan(div_rn(sub_rn(S.min_wh, bh), S.two_e), mul_rn(bh, S.half_e));
-        S.sr[n * 4 + 0] = sub_rn(bx1, w_ext);
-        S.sr[n * 4 + 1] = sub_rn(by1, h_ext);
-        S.sr[n * 4 + 2] = add_rn(bx2, w_ext);
-        S.sr[n * 4 + 3] = add_rn(by2, h_ext);
-    }
-    const int H = P.H[lvl], W = P.W[lvl], pad = P.pad[lvl];
-    const float scale = P.scale[lvl];
-    const float x1 = mul_rn(roi[0], scale), y1 = mul_rn(roi[1], scale);
-    const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
-    const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
-    const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
-    const bool owns = (c0 + wave < C);                    // channel tails: this wave has no plane
-    const int plane = n * C + c0 + wave;
-    constexpr int NZ = XCORR ? (RZ * RZ + 63) / 64 : 1;
-    float zreg[NZ];
-    if (XCORR && owns) {
-        const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
-#pragma unroll
-        for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
-    }
-    if (wave < 2) {
-        int lo = 0, hi = 0;
-        float wl = 0.0f, wh = 0.0f;
-        if (lane < NS) {
-            if (wave == 0) {
-                axis_sample(y1, bin_h, G, lane, H, pad, &lo, &hi, &wl, &wh);
-            } else {
-                axis_sample(x1, bin_w, G, lane, W, pad, &lo, &hi, &wl, &wh);
-            }
-        }
-        int mn = 0x7fffffff, mx = -1;
-        if (wl != 0.0f) {
-            mn = lo;
-            mx = lo;
-        }
-        if (wh != 0.0f) {
-            mn = min(mn, hi);
-            mx = max(mx, hi);
-        }
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            mn = min(mn, __shfl_xor(mn, m));
-            mx = max(mx, __shfl_xor(mx, m));
-        }
-        if (wave == 0) {
-            if (lane < NS + 2 * G) {          // entries past NS: the masked tail rows of the second half-wave
-                y_lo[lane] = (lane < NS && wl != 0.0f) ? lo : mn;
-                y_hi[lane] = (lane < NS && wh != 0.0f) ? hi : mn;
-                wy_lo[lane] = lane < NS ? wl : 0.0f;
-                wy_hi[lane] = lane < NS ? wh : 0.0f;
-            }
-        } else if (lane < NS) {
-            x_lo[lane] = (wl != 0.0f) ? lo - mn : 0;
-            x_hi[lane] = (wh != 0.0f) ? hi - mn : 0;
-            wx_lo[lane] = wl;
-            wx_hi[lane] = wh;
-        }
-        if (lane == 0) {
-            wbound[2 * wave] = mn;
-            wbound[2 * wave + 1] = mx;
-        }
-    }
-    __syncthreads();
-    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
-    if (ymax < ymin || xmax < xmin) {
-        if (owns) {
-            if (XCORR)
-                for (int e = lane; e < HO * HO; e += 64) resp[(size_t)plane * HO * HO + e] = 0.0f;
-            if (x_debug != nullptr)
-                for (int e = lane; e < RX * RX; e += 64) x_debug[(size_t)plane * RX * RX + e] = 0.0f;
-        }
-        return;
-    }
-    const int ww = xmax - xmin + 1;
-    FX_TRACE(1)
-    if (XCORR && owns) {
-#pragma unroll
-        for (int t = 0; t < NZ; ++t) {
-            const int e = lane + 64 * t;
-            if (e < RZ * RZ) {
-                const int u = e / RZ;
-                zs[u * ZS + (e - u * RZ)] = zreg[t];
-            }
-        }
-    }
-    FX_TRACE(2)
-    const float* __restrict__ fbase = P.feat[lvl];
-    if (owns) {
-        const gptr_t fc = uniform_base(fbase + (size_t)(c0 + wave) * H * W);
-        if (ww <= 64) {
-            auto pool = [&](auto dual_tag) {
-                constexpr bool DUAL = decltype(dual_tag)::value;       // half-waves split the pooled rows
-                const int half = DUAL ? (lane >> 5) : 0;
-                const int col = DUAL ? (lane & 31) : lane;
-                const int gcol = xmin + min(col, ww - 1);
-                const int pw = col < RX ? col : 0;
-                int sxl[G], sxh[G];
-                float hxw[G], lxw[G];
-#pragma unroll
-                for (int ix = 0; ix < G; ++ix) {
-                    sxl[ix] = (x_lo[pw * G + ix] + 32 * half) << 2;
-                    sxh[ix] = (x_hi[pw * G + ix] + 32 * half) << 2;
-                    hxw[ix] = wx_lo[pw * G + ix];
-                    lxw[ix] = wx_hi[pw * G + ix];
-                }
-                constexpr int NB = DUAL ? 1 : 2;          // batches of RH pooled rows
-#pragma unroll 1
-                for (int k = 0; k < NB; ++k) {
-                    const int ph0 = (DUAL ? half : k) * RH;
-                    float v[RH][G][2];
-#pragma unroll
-                    for (int b = 0; b < RH; ++b)
-#pragma unroll
-                        for (int iy = 0; iy < G; ++iy) {
-                            const int s = (ph0 + b) * G + iy;            // < NS + 2G: tables are padded
-                            v[b][iy][0] = ld_off(fc, (unsigned)(y_lo[s] * W + gcol) * 4u);
-                            v[b][iy][1] = ld_off(fc, (unsigned)(y_hi[s] * W + gcol) * 4u);
-                        }
-#pragma unroll
-                    for (int b = 0; b < RH; ++b) {
-                        float col_sum = 0.0f;
-#pragma unroll
-                        for (int iy = 0; iy < G; ++iy) {
-                            const int s = (ph0 + b) * G + iy;
-                            col_sum = fmaf(wy_lo[s], v[b][iy][0], col_sum);
-                            col_sum = fmaf(wy_hi[s], v[b][iy][1], col_sum);
-                        }
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int ix = 0; ix < G; ++ix) {
-                            const float a = __int_as_float(__builtin_amdgcn_ds_bpermute(sxl[ix], __float_as_int(col_sum)));
-                            const float c = __int_as_float(__builtin_amdgcn_ds_bpermute(sxh[ix], __float_as_int(col_sum)));
-                            acc = fmaf(hxw[ix], a, acc);
-                            acc = fmaf(lxw[ix], c, acc);
-                        }
-                        if (col < RX && ph0 + b < RX) xs[(ph0 + b) * XS + col] = acc * (1.0f / (float)(G * G));
-                    }
-                }
-            };
-            if (ww <= 32) {
-                pool(std::true_type{});
-            } else {
-                pool(std::false_type{});
-            }
-        } else {
-            // slow path (windows wider than a wave): per-bin gathers, reference term order
-            const float* __restrict__ fcp = fbase + (size_t)(c0 + wave) * H * W;
-            for (int t = lane; t < RX * RX; t += 64) {
-                const int ph = t / RX, pwb = t - ph * RX;
-                float acc = 0.0f;
-#pragma unroll
-                for (int iy = 0; iy < G; ++iy)
-#pragma unroll
-                    for (int ix = 0; ix < G; ++ix) {
-                        const int sy = ph * G + iy, sx = pwb * G + ix;
-                        const int xl = x_lo[sx] + xmin, xh = x_hi[sx] + xmin;
-                        const float v1 = fcp[y_lo[sy] * W + xl], v2 = fcp[y_lo[sy] * W + xh];
-                        const float v3 = fcp[y_hi[sy] * W + xl], v4 = fcp[y_hi[sy] * W + xh];
-                        const float w1 = wy_lo[sy] * wx_lo[sx], w2 = wy_lo[sy] * wx_hi[sx];
-                        const float w3 = wy_hi[sy] * wx_lo[sx], w4 = wy_hi[sy] * wx_hi[sx];
-                        acc += w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4;
-                    }
-                xs[ph * XS + pwb] = acc / (float)(G * G);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (x_debug != nullptr) {
-            for (int e = lane; e < RX * RX; e += 64) {
-                const int r = e / RX;
-                x_debug[(size_t)plane * RX * RX + e] = xs[r * XS + (e - r * RX)];
-            }
-        }
-    }
-    FX_TRACE(3)
-    if constexpr (XCORR) {
-        __syncthreads();                                  // both planes of every pair pooled
-#ifdef SMOT_DEBUG
-        if (S.abl == 2) return;                           // timing ablation: measurement library only
+#include "../../measure/csrc/sr_xcorr_gen2.inc"      // measurement library only (not product source)
 #endif
-        if (wave < 4) {
-            const int plane0 = n * C + c0 + 2 * wave;
-            const int nvalid = min(2, n * C + min(C, c0 + FX_CH) - plane0);
-            if (nvalid > 0) {
-                const float* xs2 = sm + wave * (2 * XP + 2 * ZP);
-                xcorr_patch2_compute<RX, RZ, 0>(xs2, xs2 + 2 * XP, lane, resp, plane0, plane0 + nvalid);
-            }
-        }
-    }
-    FX_TRACE(4)
-#undef FX_TRACE
-}
-#endif  // SMOT_DEBUG (generation 2)
 
 // ---- third generation (default): sample tables in registers, wave-uniform addressing, gathers in bulk ------------
 // What the phase traces of generation 2 showed (round-1 traces, ticks per workgroup @30 tracks):
@@ -1030,9 +797,13 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     return check_launch("emm_extract_cache");
 }
 
+#ifdef SMOT_DEBUG
+// measure/csrc/sr_xcorr_plan.hip (measurement library only): the round-4 plan-driven, barrier-free generation
 int launch_roi_plans(const LevelParams& P, const float* sr, const float* boxes, int N, float* plans, hipStream_t st);
 int launch_fused10(const LevelParams& P, int C, const float* plans, const float* z, int N, float* resp, float* x_debug,
                    hipStream_t st);
+int fused10_plan_floats();
+#endif
 
 // Pooling + correlation with an optional order hint for its rois (smot_emm_track_fwd; the stand-alone operator
 // smot_sr_xcorr_fused_fwd passes none).
@@ -1050,7 +821,7 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
 #ifdef SMOT_DEBUG
     if (knobs().fused_gen == 10) {             // stage 1 (measurement library): generation 4 with a stand-alone plan launch
         static float* plans = nullptr;
-        if (plans == nullptr && hipMalloc(&plans, (size_t)4096 * SMOT_PLAN_FLOATS * 4) != hipSuccess) return SMOT_ERR_BAD_ARG;
+        if (plans == nullptr && hipMalloc(&plans, (size_t)4096 * fused10_plan_floats() * 4) != hipSuccess) return SMOT_ERR_BAD_ARG;
         SMOT_REQUIRE(N <= 4096, "fused10 debug: at most 4096 rois");
         int rcp = launch_roi_plans(P, sr, boxes, N, plans, st);
         if (rcp) return rcp;

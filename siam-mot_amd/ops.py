@@ -612,6 +612,8 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     bb = torch.empty((N, 4), dtype=_F32, device=dev)
     conf = torch.empty((N,), dtype=_F32, device=dev)
     idx = torch.empty((N,), dtype=torch.int64, device=dev) if return_index else None
+    if order_hint is None and rx == 30 and rz == 15 and 2 <= N <= 256:
+        FALLBACKS["unhinted_head"] += 1
     if order_hint is not None and (tuple(order_hint.shape) != (N, HINT_FLOATS) or order_hint.device != dev
                                    or order_hint.dtype is not _F32 or not order_hint.is_contiguous()):
         raise RuntimeError("siammot_amd.emm_track: order_hint must be the contiguous fp32 [%d, %d] tensor of the "
@@ -700,6 +702,16 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
 
 
 TIMER_XCORR, TIMER_TOWER = 0, 1
+
+
+# Capacity cliffs of the fast paths fall back to slower (correct) ones: every such event is counted here so that a
+# benchmark / a service can REPORT them instead of silently running slower.  Keys:
+#   refine_library_gemm  box-head refinement of more rows than the weight-streaming kernels take (library GEMMs instead)
+#   host_solver          a frame beyond the one-launch solver's capacity (or with fields it does not carry): host path
+#   unhinted_head        a pooling + correlation launch that ranked its rois itself although an order hint could exist
+#   general_frame        a tracking-loop frame that did not take the one-launch path at all
+import collections as _collections
+FALLBACKS = _collections.Counter()
 
 
 def fused_kernel_name():

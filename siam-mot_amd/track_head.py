@@ -502,6 +502,8 @@ class TrackingLoop(torch.nn.Module):
                     if a.refine else 0)
             tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = tf.data_ptr()
+            if p_hint == 0 and 2 <= n_trk <= 256 and P.rz == 15:
+                ops.FALLBACKS["unhinted_head"] += 1
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), p_tbb, p_sr, p_z, p_hint, p_ids,
                                 p_lab, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)                         # the head is running from here on
@@ -559,6 +561,7 @@ class TrackingLoop(torch.nn.Module):
             if self._native_ok(detections):
                 return self._step_native(features, detections)
             return self._step_lean(features, detections)
+        ops.FALLBACKS["general_frame"] += 1
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38
         fast = getattr(self.solver, "_device_path", None)
         if fast is not None and self.refine_tracks is None and fast(detections, tracks[0] if tracks else None):
