@@ -33,7 +33,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 8
+#define SMOT_ABI_VERSION 9
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -291,19 +291,26 @@ int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* m
  *   on the un-padded maps (boxes pick level and roi) + search regions for the next frame.
  *
  * order_hint (optional, may be NULL everywhere): a scheduling side channel between the two halves, no part of the
- *   reference's interface and without influence on any result.  The pooling + correlation kernel of
+ *   reference's interface.  A hint made from exactly the boxes / search regions it is passed with changes no result
+ *   (bit-identical outputs with and without, tests/test_hip_parity.py); a hint made from OTHER boxes gives wrong
+ *   results — see the last sentences.  The pooling + correlation kernel of
  *   smot_emm_track_fwd balances the chip by handing its workgroups the rois in cost order (wide search windows
  *   first); ranking them costs every workgroup ~3 us of start-up latency.  The extraction that CREATES those rois
  *   can rank them once: given a buffer of smot_emm_order_hint_floats(N, rz, sampling_ratio) floats (32-byte
  *   aligned; 0 = this shape / count writes no hint: pass NULL), smot_emm_extract_cache[_masked]_fwd writes
- *   SMOT_HINT_FLOATS floats per roi — {search region x1,y1,x2,y2, FPN level (int32 bits), roi index (int32 bits),
- *   0, 0}, entry k = the roi of rank k — and smot_emm_track_fwd given that buffer TOGETHER WITH exactly the `boxes`
+ *   SMOT_HINT_FLOATS dwords per roi — {search region x1,y1,x2,y2, FPN level (int32 bits), roi index (int32 bits),
+ *   0, 0 | ymin, ymax, xmin, xmax of the touched window, pad cells / H / W of the level the tables stand for, 0 |
+ *   y sample table 64 x {row byte offset lo, hi, weight lo, hi} | x sample table 64 x {window column lo, hi, weight lo,
+ *   hi}}, entry k = the roi of rank k; the tables (ABI 9) are the FINISHED sample tables of the roi's 30x30 search-region
+ *   pooling in the next frame (zero-pad int(pad_pixels * scale) cells, same map sizes), so that a consumer workgroup
+ *   copies them instead of building them (a geometry stamp that does not match the consumer's level makes it rebuild
+ *   them) — and smot_emm_track_fwd given that buffer TOGETHER WITH exactly the `boxes`
  *   and `sr` of the same extraction (same N, same row order, same maps geometry) reads one entry per workgroup
  *   instead of ranking.  A hint from any other boxes gives wrong results (the entries' search regions are used as
  *   they stand; indices are clamped, so nothing is read out of range): callers that re-order, merge or edit the
  *   track memory pass NULL.  For the masked form the hint covers the first *n_valid rows.
  */
-#define SMOT_HINT_FLOATS 8
+#define SMOT_HINT_FLOATS 528
 long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio);
 
 long long smot_emm_track_ws_floats(int N, int C, int rx, int rz);

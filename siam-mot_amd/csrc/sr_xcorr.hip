@@ -48,8 +48,18 @@ struct SrOut {
                           // (fx_write_hint below; [R] entries of SMOT_HINT_FLOATS floats) or nullptr
     const float* hint_in; // pooling + correlation kernel: such a list for ITS rois (written by the extraction that made
                           // them), read instead of ranking the rois again in every workgroup; or nullptr
+    int plan_pad[SMOT_MAX_LEVELS];   // hint writer: zero-pad cells per level of the NEXT frame's search-region pooling
+                          // (the extraction itself pools un-padded maps); the finished sample tables in a hint entry are
+                          // built against them
 };
-constexpr int HINT_FLOATS = SMOT_HINT_FLOATS;     // {search region x1,y1,x2,y2, FPN level, roi index, 0, 0}
+// One hint entry = SMOT_HINT_FLOATS dwords: {search region x1,y1,x2,y2, FPN level, roi index, 0, 0 | ymin, ymax, xmin, xmax of the
+// touched window, pad cells / H / W of the level the tables were built against, 0 | y table [64] x int4 | x table [64] x int4}
+// — since round 4 the FINISHED sample tables of the roi's 30x30 pooling ride along (exactly the entries the consumer's
+// waves 0 / 1 would compute: reference rounding sequence, re-based rows / columns), so that a consumer workgroup loads 2 KB
+// instead of ranking, dividing and building them.
+constexpr int HINT_FLOATS = SMOT_HINT_FLOATS;
+constexpr int HINT_BOUNDS = 8, HINT_GEOM = 12, HINT_YTAB = 16, HINT_XTAB = 16 + 256;
+static_assert(HINT_XTAB + 256 == HINT_FLOATS, "hint entry layout");
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
 // addressing form (one address VGPR per load instead of a 64-bit pair — 120 loads are in flight).
@@ -112,20 +122,23 @@ __device__ __forceinline__ float4 search_region_of(float b0, float b1, float b2,
 // with its search region and FPN level — so that a consumer workgroup needs one scalar load of its own entry.
 // Same classes and the same order as fx_assign order 1 (class descending, roi ascending); the consumer's results do
 // not depend on it (any permutation of the rois is a valid assignment).
+// Workgroup x of the extraction launch's extra row writes the entry of roi x: both of its first two waves rank the rois
+// (lane = roi, three ballots per 64 rois: the rank of roi x is read out of its lane), wave 0 builds the y table and wave 1
+// the x table of the roi's NEXT-frame search region exactly as the consumer's waves 0 / 1 would (same code, same rounding
+// sequence), against the pad cells the next frame's pooling uses.
+template <int RXN, int G>
 __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float* __restrict__ boxes, const SrOut& S,
-                                              int NT, int lane) {
-    if (NT > 256) return;                                      // (the consumer keeps grid order beyond 256 rois)
+                                              int NT, int x, int wave, int lane) {
+    if (NT > 256 || wave >= 2) return;                         // (the consumer keeps grid order beyond 256 rois)
     const int nv = (S.n_valid != nullptr) ? min(*S.n_valid, NT) : NT;
+    if (x >= nv) return;
     unsigned long long mask[4][3];
     int cnt[3] = {0, 0, 0};
-    float4 srb[4];
-    int lv[4], cl[4];
+    int cl[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int t = lane + 64 * p;
         cl[p] = -1;
-        lv[p] = 0;
-        srb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (64 * p < nv && t < nv) {
             const float4 b4 = *reinterpret_cast<const float4*>(boxes + (size_t)t * 4);
             int lvl = 0;
@@ -133,9 +146,8 @@ __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float*
             float scale = P.scale[0];
 #pragma unroll
             for (int l = 1; l < SMOT_MAX_LEVELS; ++l) scale = (lvl == l) ? P.scale[l] : scale;
-            srb[p] = search_region_of(b4.x, b4.y, b4.z, b4.w, S);
-            lv[p] = lvl;
-            const float ww = (srb[p].z - srb[p].x) * scale;                              // window width in cells
+            const float4 srb = search_region_of(b4.x, b4.y, b4.z, b4.w, S);
+            const float ww = (srb.z - srb.x) * scale;                                    // window width in cells
             cl[p] = ww <= 30.0f ? 0 : (ww <= 62.0f ? 1 : 2);
         }
 #pragma unroll
@@ -144,22 +156,70 @@ __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float*
             cnt[c] += __popcll(mask[p][c]);
         }
     }
-    const int base[3] = {cnt[2] + cnt[1], cnt[2], 0};
-    int before[3] = {0, 0, 0};
+    const int px = x >> 6, lx = x & 63;
+    int cx = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        if (p == px) cx = __builtin_amdgcn_readlane(cl[p], lx);
+    int rank = cx == 2 ? 0 : (cx == 1 ? cnt[2] : cnt[2] + cnt[1]);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        if (cl[p] >= 0) {
-            const int c = cl[p];
-            const unsigned long long mk = c == 2 ? mask[p][2] : (c == 1 ? mask[p][1] : mask[p][0]);
-            const int bf = c == 2 ? before[2] : (c == 1 ? before[1] : before[0]);
-            const int bs = c == 2 ? base[2] : (c == 1 ? base[1] : base[0]);
-            const int rank = bs + bf + __popcll(mk & ((1ull << lane) - 1ull));
-            float4* o = reinterpret_cast<float4*>(S.hint_out + (size_t)rank * HINT_FLOATS);
-            o[0] = srb[p];
-            o[1] = make_float4(__int_as_float(lv[p]), __int_as_float(lane + 64 * p), 0.f, 0.f);
+        const unsigned long long mk = cx == 2 ? mask[p][2] : (cx == 1 ? mask[p][1] : mask[p][0]);
+        if (p < px) rank += __popcll(mk);
+        if (p == px) rank += __popcll(mk & ((1ull << lx) - 1ull));
+    }
+    // the roi itself (wave-uniform scalar loads)
+    const float* bx = boxes + (size_t)x * 4;
+    const float4 roi = search_region_of(bx[0], bx[1], bx[2], bx[3], S);
+    int lvl = 0;
+    if (P.num_levels > 1) lvl = map_level(bx, P.k_min, P.k_max);
+    lvl = __builtin_amdgcn_readfirstlane(lvl);
+    const int H = P.H[lvl], W = P.W[lvl], pad = S.plan_pad[lvl];
+    const float scale = P.scale[lvl];
+    const float x1 = mul_rn(roi.x, scale), y1 = mul_rn(roi.y, scale);
+    const float x2 = mul_rn(roi.z, scale), y2 = mul_rn(roi.w, scale);
+    const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RXN);
+    const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RXN);
+    int* ent = reinterpret_cast<int*>(S.hint_out) + (size_t)rank * HINT_FLOATS;
+    int lo = 0, hi = 0;
+    float wl = 0.0f, wh = 0.0f;
+    if (lane < RXN * G) {
+        if (wave == 0) {
+            axis_sample(y1, bin_h, G, lane, H, pad, &lo, &hi, &wl, &wh);
+        } else {
+            axis_sample(x1, bin_w, G, lane, W, pad, &lo, &hi, &wl, &wh);
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) before[c] += __popcll(mask[p][c]);
+    }
+    int mn = 0x7fffffff, mx = -1;
+    const unsigned long long m = __ballot(wl != 0.0f || wh != 0.0f);
+    if (m != 0ull) {
+        mn = __builtin_amdgcn_readlane((wl != 0.0f) ? lo : hi, __ffsll((long long)m) - 1);
+        mx = __builtin_amdgcn_readlane((wh != 0.0f) ? hi : lo, 63 - __clzll((long long)m));
+    }
+    const int rl = (wl != 0.0f) ? lo : mn, rh = (wh != 0.0f) ? hi : mn;
+    int4 e;
+    if (wave == 0) {
+        e.x = (int)((unsigned)(rl * W) * 4u);
+        e.y = (int)((unsigned)(rh * W) * 4u);
+    } else {
+        e.x = (wl != 0.0f) ? lo - mn : 0;
+        e.y = (wh != 0.0f) ? hi - mn : 0;
+    }
+    e.z = __float_as_int(wl);
+    e.w = __float_as_int(wh);
+    *reinterpret_cast<int4*>(ent + (wave == 0 ? HINT_YTAB : HINT_XTAB) + 4 * lane) = e;
+    if (lane == 0) {
+        ent[HINT_BOUNDS + 2 * wave] = mn;
+        ent[HINT_BOUNDS + 2 * wave + 1] = mx;
+        if (wave == 0) {
+            float4* o = reinterpret_cast<float4*>(ent);
+            o[0] = roi;
+            o[1] = make_float4(__int_as_float(lvl), __int_as_float(x), 0.f, 0.f);
+            ent[HINT_GEOM + 0] = pad;
+            ent[HINT_GEOM + 1] = H;
+            ent[HINT_GEOM + 2] = W;
+            ent[HINT_GEOM + 3] = 0;
+        }
     }
 }
 
@@ -180,7 +240,7 @@ __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float*
 __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __restrict__ sr,
                                           const float* __restrict__ boxes, const int* __restrict__ n_valid, int order,
                                           int by, int ny, const float* __restrict__ hint, int lane, int* n_out,
-                                          int* cg_out, float4* roi_out, int* lvl_out) {
+                                          int* cg_out, float4* roi_out, int* lvl_out, int* k_out) {
     // (by, ny): the workgroup's row and the number of rows of the (roi, channel group) grid — blockIdx.y / gridDim.y
     // less the hint row of an extraction launch
     const int NT = gridDim.x;
@@ -193,6 +253,7 @@ __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __r
         // the list was made when the rois were (fx_write_hint): one scalar load of this workgroup's entry
         const int k = L / ny;
         *cg_out = L - k * ny;
+        *k_out = k;
         // through the constant address space: a wave-uniform address there is a scalar load (one s_load_dwordx8 per
         // wave through the scalar cache; as a plain global pointer hipcc issues vector loads — it cannot see that
         // nothing writes the list during this launch)
@@ -361,16 +422,31 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     if constexpr (!XCORR) {
         if (S.hint_out != nullptr) {                 // extraction launch with one extra row in front: the hint writer
             if (grid_row == 0) {
-                if (blockIdx.x == 0 && wave == 0) fx_write_hint(P, boxes, S, gridDim.x, lane);
+                fx_write_hint<30, G>(P, boxes, S, gridDim.x, blockIdx.x, wave, lane);     // (the consumer's shape: 30x30 bins)
                 return;
             }
             grid_row -= 1;
             grid_rows -= 1;
         }
     }
+    // With a hint the entry's finished tables and its geometry stamp are requested NOW, beside fx_assign's own scalar load
+    // of the entry: everything a hinted workgroup needs before its first feature load is ONE memory round trip.
+    int4 tab_early = make_int4(0, 0, 0, 0);
+    typedef int v8h_t __attribute__((ext_vector_type(8)));
+    v8h_t g8 = {0, 0, 0, 0, -1, -1, -1, 0};
+    if constexpr (XCORR && RX == 30) {
+        if (S.hint_in != nullptr && S.order == 1 && S.n_valid == nullptr && gridDim.x >= 2 && gridDim.x <= 256) {
+            const int k0 = (int)(blockIdx.y * gridDim.x + blockIdx.x) / (int)gridDim.y;        // = fx_assign's rank k
+            const int* ent = reinterpret_cast<const int*>(S.hint_in) + (size_t)k0 * HINT_FLOATS;
+            g8 = *reinterpret_cast<const __attribute__((address_space(4))) v8h_t*>(
+                reinterpret_cast<unsigned long long>(ent) + 4ull * HINT_BOUNDS);
+            if (wave < 2) tab_early = *reinterpret_cast<const int4*>(ent + (wave == 0 ? HINT_YTAB : HINT_XTAB) + 4 * lane);
+        }
+    }
+    int k_assigned = -1;
     const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, grid_row, grid_rows,
                                     XCORR ? S.hint_in : nullptr, lane, &n_assigned, &cg_assigned, &roi_assigned,
-                                    &lvl_assigned);
+                                    &lvl_assigned, &k_assigned);
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
     const int cgrp = __builtin_amdgcn_readfirstlane(cg_assigned);
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
@@ -430,7 +506,15 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // cost more issue slots on the CU than the barrier they saved: 5.1 k instead of 4.3 k ticks.)
     // Entries are stored re-based and packed (16 bytes): y = {row byte offset lo, hi, weight lo, hi}, x = {window
     // column lo, hi, weight lo, hi}; consumers fetch an entry with one ds_read_b128.
-    if (wave < 2) {
+    // With a hint entry the tables arrive FINISHED (fx_write_hint built them when the roi was made, one frame earlier):
+    // waves 0 / 1 copy 1 KB each instead of ~150 vector instructions and two IEEE divisions; the entry's geometry stamp
+    // must match this launch's level (another pad / map size: the tables are rebuilt here, the assignment stands).
+    const bool hent = XCORR && RX == 30 && k_assigned >= 0 && g8[4] == pad && g8[5] == H && g8[6] == W;
+    const int hb[4] = {g8[0], g8[1], g8[2], g8[3]};
+    if (wave < 2 && hent) {
+        tab[wave][lane] = tab_early;
+        if (lane < 2 * RH * G) tab[wave][64 + lane] = make_int4(0, 0, 0, 0);      // the pad behind the table
+    } else if (wave < 2) {
         int lo = 0, hi = 0;
         float wl = 0.0f, wh = 0.0f;
         if (lane < NS) {
@@ -470,7 +554,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         }
     }
     __syncthreads();
-    const int ymin = wbound[0], ymax = wbound[1], xmin = wbound[2], xmax = wbound[3];
+    const int ymin = hent ? hb[0] : wbound[0], ymax = hent ? hb[1] : wbound[1];
+    const int xmin = hent ? hb[2] : wbound[2], xmax = hent ? hb[3] : wbound[3];
     if (ymax < ymin || xmax < xmin) {
         // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
         if (owns) {
@@ -788,6 +873,9 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
     // with a hint to write: one extra row of workgroups in front, of which the first ranks the rois (fx_write_hint)
     dim3 grid(N, (C + FX_CH - 1) / FX_CH + (order_hint != nullptr ? 1 : 0));
     SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order(), order_hint, nullptr};
+    // the next frame's search-region pooling runs on maps zero-padded by int(pad_pixels / stride) cells per level
+    // (track_utils.py:94-96); the hint's finished tables are built against exactly that
+    for (int l = 0; l < num_levels && l < SMOT_MAX_LEVELS; ++l) S.plan_pad[l] = (int)(pad_pixels * scales[l]);
     if (rz == 7) {                 // the second yaml family's template (DLA_34_FPN_EMM_AOT.yaml:52-63): same kernel, 7x7 bins
         SMOT_LAUNCH((sr_xcorr_fused9_kernel<7, 15, 2, false>), grid, dim3(512), 0, st, P, C, boxes, boxes, (const float*)nullptr,
                     (float*)nullptr, templates, (int32_t*)nullptr, S);

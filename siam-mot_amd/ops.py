@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -639,7 +639,7 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     return (bb, conf, idx) if return_index else (bb, conf)
 
 
-HINT_FLOATS = 8                      # SMOT_HINT_FLOATS (include/smot_emm.h)
+HINT_FLOATS = 528                    # SMOT_HINT_FLOATS (include/smot_emm.h): entry header + both finished sample tables
 _hint_floats = {}
 
 

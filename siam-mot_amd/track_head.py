@@ -518,11 +518,11 @@ class TrackingLoop(torch.nn.Module):
             d0, d1, d2, d3 = db.data_ptr(), dsc.data_ptr(), did.data_ptr(), (dlab.data_ptr() if dlab is not None else 0)
         M = n_det + n_trk
         ring = pool.host_record_ring(dev)
-        # float outputs [10 M] and, behind them at a 32-byte boundary, the order hint [M, 8] the masked extraction ranks
+        # float outputs [10 M] and, behind them at a 32-byte boundary, the order hint [M, HINT_FLOATS] the masked extraction ranks
         # the NEXT frame's rois into (one wave of one extra workgroup of that launch; 2..256 rows) — handed to the next
         # head as a bare address when the memory stays the extraction's own output (_LazyMemory)
         hint_off = ((10 * M + 7) & ~7) if (2 <= M <= 256 and self.__dict__.get("loop_order_hint", True)) else 0
-        fbuf = torch.empty((hint_off + 8 * M,) if hint_off else (10 * M,), dtype=torch.float32, device=dev)
+        fbuf = torch.empty((hint_off + ops.HINT_FLOATS * M,) if hint_off else (10 * M,), dtype=torch.float32, device=dev)
         ibuf = torch.empty((4 * M,), dtype=torch.int64, device=dev)
         templates = torch.empty((M, P.C, P.rz, P.rz), dtype=torch.float32, device=dev)
         sr_next = torch.empty((M, 4), dtype=torch.float32, device=dev)

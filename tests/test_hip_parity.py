@@ -1015,13 +1015,19 @@ def test_order_hint_lists_the_rois_in_cost_order_and_changes_nothing(ops, n):
         return
     assert tuple(hint.shape) == (n, ops.HINT_FLOATS) and ops.order_hint_floats(n, 15, 2) == n * ops.HINT_FLOATS
     h = hint.cpu()
-    meta = h[:, 4:].contiguous().view(torch.int32)
+    meta = h[:, 4:8].contiguous().view(torch.int32)
     idx, lvl = meta[:, 1].long(), meta[:, 0].long()
     assert sorted(idx.tolist()) == list(range(n))
     assert torch.equal(h[:, :4], sr.cpu()[idx])
     _, want_lvl = ops.roi_align_levels(feats, boxes, boxes, 15, scales, 2, return_levels=True)   # (vs the oracle: elsewhere)
     assert torch.equal(lvl, want_lvl.cpu()[idx].long())
     assert int(meta[:, 2:].abs().max()) == 0
+    # the entry's geometry stamp and window bounds (ABI 9: the finished sample tables ride along; that they ARE the tables the
+    # consumer would build is what "hinted == un-hinted, bit for bit" below shows)
+    geom = h[:, 8:16].contiguous().view(torch.int32)
+    strides = torch.tensor([4, 8, 16, 32])[lvl]
+    assert torch.equal(geom[:, 4].long(), 512 // strides) and torch.equal(geom[:, 5].long(), 704 // strides)
+    assert torch.equal(geom[:, 6].long(), 1280 // strides) and bool((geom[:, 1] >= geom[:, 0]).all())
     sc = torch.tensor(scales)[lvl]
     cls = ((h[:, 2] - h[:, 0]) * sc > 30.0).int() + ((h[:, 2] - h[:, 0]) * sc > 62.0).int()
     key = (-cls.long()) * 1000 + idx                                  # class descending, roi ascending
@@ -1038,7 +1044,7 @@ def test_order_hint_lists_the_rois_in_cost_order_and_changes_nothing(ops, n):
         nv = n - 3
         mz, msr, mh = ops.emm_extract_cache(feats, boxes, 15, scales, 2, 512, 1.0, 0,
                                             n_valid=torch.tensor([nv], dtype=torch.int32, device=DEV), hint=True)
-        mi = mh[:nv].cpu()[:, 4:].contiguous().view(torch.int32)[:, 1].long()
+        mi = mh[:nv].cpu()[:, 4:8].contiguous().view(torch.int32)[:, 1].long()
         assert sorted(mi.tolist()) == list(range(nv)) and torch.equal(mh[:nv, :4].cpu(), sr.cpu()[mi])
         out = ops.emm_track(feats, boxes[:nv], msr[:nv], mz[:nv], params, 30, 15, scales, 2, 512, clip_wh=(1280, 704),
                             return_index=True, order_hint=mh[:nv])
