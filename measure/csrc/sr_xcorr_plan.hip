@@ -246,6 +246,7 @@ sr_xcorr_fused10_kernel(LevelParams P, int C, const int* __restrict__ plans, con
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long long t_start = trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
+    if (abl & 16) return;          // ablation: the bare dispatch (480 workgroups x 512 threads x 78 KB of LDS at 30 tracks)
     // experiment (abl >= 256): the second half of the workgroup's waves (the SIMDs' second waves) start (abl >> 8) * 512
     // cycles late, so that their load / pooling phase runs beside the first half's correlation
     if ((abl >> 8) && wave >= FX10_WAVES / 2) {

@@ -44,7 +44,7 @@ const KnobName kKnobNames[] = {
     {"SMOT_DECODE_2PASS", &Knobs::decode_two_pass}, {"SMOT_FUSED_GEN", &Knobs::fused_gen},
     {"SMOT_TOWER_OCT", &Knobs::tower_oct},
     {"SMOT_FUSED_ORDER", &Knobs::fused_order},   {"SMOT_NO_HINT", &Knobs::no_hint},
-    {"SMOT_FUSED_ABL", &Knobs::fused_abl},
+    {"SMOT_FUSED_ABL", &Knobs::fused_abl},       {"SMOT_ANY_ORDER", &Knobs::any_order},
     {"SMOT_WINO_ABL", &Knobs::wino_abl},
     {"SMOT_TOWER_ABL", &Knobs::tower_abl},
 };
@@ -97,6 +97,9 @@ extern "C" int smot_debug_set_knob(const char* name, const char* value) {
 #endif
 
 namespace smot {
+#ifdef SMOT_DEBUG
+int smot_debug_launch_flags() { return knobs().any_order ? 1 /* hipExtAnyOrderLaunch */ : 0; }
+#endif
 long long* g_trace = nullptr;
 
 int ensure_lds_optin(const void* kernel, size_t bytes, const char* what) {

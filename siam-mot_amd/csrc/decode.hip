@@ -590,11 +590,11 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
         }
     }
     if (split == 4) {
-        hipLaunchKernelGGL(decode_kernel<4>, dim3(N, Ho + 1), dim3(1024), smem, st, L, boxes, hann, D, cand, F);
+        SMOT_LAUNCH(decode_kernel<4>, dim3(N, Ho + 1), dim3(1024), smem, st, L, boxes, hann, D, cand, F);
     } else if (split == 2) {
-        hipLaunchKernelGGL(decode_kernel<2>, dim3(N, Ho + 1), dim3(512), smem, st, L, boxes, hann, D, cand, F);
+        SMOT_LAUNCH(decode_kernel<2>, dim3(N, Ho + 1), dim3(512), smem, st, L, boxes, hann, D, cand, F);
     } else {
-        hipLaunchKernelGGL(decode_kernel<1>, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand, F);
+        SMOT_LAUNCH(decode_kernel<1>, dim3(N, Ho + 1), dim3(256), smem, st, L, boxes, hann, D, cand, F);
     }
     return check_launch("decode");
 }

@@ -31,6 +31,9 @@ struct Knobs {
     int no_hint = 0;         // SMOT_NO_HINT       : 1 = the pooling + correlation kernel ignores the order hint and ranks
                              //                      its rois itself, 2 = the extraction does not write one either
     int tower_oct = 0;       // SMOT_TOWER_OCT     : 16-channel tiles per Winograd workgroup (0 = default, 1 or 2)
+    int any_order = 0;       // SMOT_ANY_ORDER     : launches carry hipExtAnyOrderLaunch (no barrier between the kernels of a
+                             //                      stream: WRONG results — an upper bound on what overlapping the kernels'
+                             //                      dispatch ramps and tails could buy, measure/any_order_ab.py)
     // timing ablations: WRONG results, measurement builds only
     int fused_abl = 0;       // SMOT_FUSED_ABL
     int wino_abl = 0;        // SMOT_WINO_ABL

@@ -30,6 +30,21 @@ inline int check_launch(const char* what) {
     return SMOT_OK;
 }
 
+#ifdef SMOT_DEBUG
+int smot_debug_launch_flags();      // common.hip: hipExtAnyOrderLaunch when SMOT_ANY_ORDER is set (measurement library only)
+#define SMOT_LAUNCH(KERNEL, GRID, BLOCK, SMEM, STREAM, ...)                                                       \
+    do {                                                                                                         \
+        hipEvent_t smot_e0_, smot_e1_;                                                                           \
+        const int smot_fl_ = smot::smot_debug_launch_flags();                                                    \
+        if (smot::timer_take(&smot_e0_, &smot_e1_)) {                                                            \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, smot_e0_, smot_e1_, smot_fl_, __VA_ARGS__); \
+        } else if (smot_fl_) {                                                                                   \
+            hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, nullptr, nullptr, smot_fl_, __VA_ARGS__);   \
+        } else {                                                                                                 \
+            hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, __VA_ARGS__);                                  \
+        }                                                                                                        \
+    } while (0)
+#else
 #define SMOT_LAUNCH(KERNEL, GRID, BLOCK, SMEM, STREAM, ...)                                                       \
     do {                                                                                                         \
         hipEvent_t smot_e0_, smot_e1_;                                                                           \
@@ -39,6 +54,7 @@ inline int check_launch(const char* what) {
             hipLaunchKernelGGL(KERNEL, GRID, BLOCK, SMEM, STREAM, __VA_ARGS__);                                  \
         }                                                                                                        \
     } while (0)
+#endif
 
 #define SMOT_REQUIRE(cond, ...)            \
     do {                                   \

@@ -567,6 +567,9 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         return;
     }
     const int ww = xmax - xmin + 1;
+    // (Measured and dropped, round 4: s_setprio 1..3 for the waves of wide-window workgroups — twice a narrow one's pooling,
+    // they set the kernel's makespan: 15.3-15.6 us at every priority against 15.3-15.4 without, 36.9 vs 36.9 at 100 tracks,
+    // measure/gpu_r04_prio.sh.  Issue arbitration is not what holds them back.)
     FX_TRACE(1)
 
     if (XCORR && owns) {
