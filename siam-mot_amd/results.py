@@ -69,6 +69,26 @@ def boxlists_to_entities(boxlists, firstframe_idx, timestamps, class_table=None)
     return entities
 
 
+def given_detections_to_boxlist(entities, video_width, video_height, class_table=None, boxlist_cls=None):
+    """``convert_given_detections_to_boxlist`` (boxlists_to_entities.py:40-60): cached / public detections of one frame
+    (entities with xywh boxes in the ORIGINAL frame) -> an xyxy BoxList with labels (1-based index of the entity's first
+    label in ``class_table``), scores and ids = -1.  The caller resizes it to the network's input frame and moves it to
+    the device (inferencer.py:50-55)."""
+    if boxlist_cls is None:
+        from .structures import BoxList as boxlist_cls
+    if class_table is None:
+        class_table = ["person"]
+    boxes = torch.as_tensor([e.bbox for e in entities]).reshape(-1, 4)
+    labels = torch.tensor([class_table.index(list(e.labels.keys())[0]) + 1 for e in entities], dtype=torch.int64)
+    scores = torch.tensor([e.confidence for e in entities])
+    ids = torch.tensor([-1 for _ in entities], dtype=torch.int64)
+    boxlist = boxlist_cls(boxes, [video_width, video_height], mode="xywh").convert("xyxy")
+    boxlist.add_field("labels", labels)
+    boxlist.add_field("scores", scores)
+    boxlist.add_field("ids", ids)
+    return boxlist
+
+
 def to_original_xywh(boxlist, orig_wh):
     """inferencer.py:65-66 / demo_inference.py:108: back to the source frame's size, xywh mode."""
     return boxlist.resize([orig_wh[0], orig_wh[1]]).convert("xywh")
@@ -152,14 +172,15 @@ def cached_video_result(output_dir, sample_id, run):
 def postprocess_tracks(tracks, track_len=5, track_conf=0.7):
     """``DatasetInference._postprocess_tracks`` (inferencer.py:134-153): keep tracks that last at least
     ``track_len`` frames with a mean confidence of at least ``track_conf``."""
-    ids = []
+    import numpy as np
+    ids = set()                                   # (a set, iterated as such: the reference's output order, inferencer.py:139-146)
     for e in tracks.entities:
-        if e.id >= 0 and e.id not in ids:
-            ids.append(e.id)
+        if e.id not in ids and e.id >= 0:
+            ids.add(e.id)
     out = tracks.get_copy_without_entities()
     for i in ids:
         ents = tracks.get_entities_with_id(i)
-        conf = sum(e.confidence for e in ents) / len(ents)
+        conf = np.mean([e.confidence for e in ents])
         if len(ents) >= track_len and conf >= track_conf:
             for e in ents:
                 out.add_entity(e)

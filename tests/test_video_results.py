@@ -214,3 +214,47 @@ def test_frame_sequence_runner_over_an_image_folder(tmp_path):
     assert len(again.entities) == len(res.entities)
     ids = [fid for fid, _ in runner.process_frame_sequence(ImageFolderIterator(str(tmp_path), frame_idxs=[0, 2])())]
     assert ids == [0, 2]
+
+
+# ---- the wire format against the reference's own code (tests/golden/results_wire.json, oracle/gen_golden_results.py) -------
+def _wire_cases():
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_wire.json")
+    return json.load(open(path))
+
+
+@pytest.mark.parametrize("name", ["person_720p", "two_classes_1080p"])
+def test_wire_format_equals_what_the_reference_functions_return(name):
+    """VERDICT r3 missing #5 / SURVEY §8(f) rank 4: ``boxlists_to_entities`` after ``resize(original).convert('xywh')``
+    (inferencer.py:65-68), ``convert_given_detections_to_boxlist`` + resize to the network frame (:47-55) and
+    ``_postprocess_tracks`` (:133-153) — the fixture holds what the REFERENCE's unmodified functions returned on these
+    inputs (gluoncv's containers stubbed as attribute bags); every field must be equal, floats bit for bit."""
+    import torch
+    from siammot_amd import results as R
+    from siammot_amd.structures import BoxList
+    c = _wire_cases()[name]
+    sample = R.ResultSample(name)
+    for k, (fr, want) in enumerate(zip(c["frames"], c["entities"])):
+        n = len(fr["scores"])
+        bl = BoxList(torch.tensor(fr["boxes"], dtype=torch.float32).reshape(n, 4), tuple(c["net_wh"]), mode="xyxy")
+        bl.add_field("scores", torch.tensor(fr["scores"], dtype=torch.float32))
+        bl.add_field("labels", torch.tensor(fr["labels"], dtype=torch.int64))
+        bl.add_field("ids", torch.tensor(fr["ids"], dtype=torch.int64))
+        ents = R.boxlists_to_entities([R.to_original_xywh(bl, c["orig_wh"])], c["first_frame"] + k, [c["timestamps"][k]],
+                                      class_table=c["class_table"])
+        assert len(ents) == len(want)
+        for e, w in zip(ents, want):
+            assert e.bbox == w["bbox"] and e.confidence == w["confidence"] and e.labels == w["labels"]
+            assert (e.id, e.frame_num, e.time) == (w["id"], w["frame_num"], w["time"])
+            sample.add_entity(e)
+    g = c["given"]
+    given = [e for e in sample.entities if e.frame_num == c["first_frame"] + g["frame"]]
+    bl = R.given_detections_to_boxlist(given, c["orig_wh"][0], c["orig_wh"][1], class_table=c["class_table"])
+    assert bl.mode == g["mode"] and list(bl.size) == g["size"] and bl.bbox.tolist() == g["bbox"]
+    assert bl.get_field("labels").tolist() == g["labels"] and bl.get_field("scores").tolist() == g["scores"]
+    assert bl.get_field("ids").tolist() == g["ids"]
+    assert bl.resize((c["net_wh"][0], c["net_wh"][1])).bbox.tolist() == g["bbox_net"]
+    pp = c["postprocess"]
+    kept = R.postprocess_tracks(sample, track_len=pp["track_len"], track_conf=pp["track_conf"])
+    assert [[e.id, e.frame_num] for e in kept.entities] == pp["kept"]
