@@ -17,8 +17,8 @@ from siammot_amd.structures import BoxList
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "refine_tracks.npz")
 
 
-def _cfg():
-    c = gi.REFINE_CASE
+def _cfg(c=None):
+    c = gi.REFINE_CASE if c is None else c
     ns = types.SimpleNamespace
     return ns(INPUT=ns(AMODAL=False),
               MODEL=ns(CLS_AGNOSTIC_BBOX_REG=False,
@@ -34,8 +34,8 @@ def _cpu_nms(boxlist, thresh):
     return boxlist[torch.from_numpy(keep)]
 
 
-def _proposals(boxes, ids, dev, labels=None, scores=None):
-    bl = BoxList(torch.from_numpy(boxes.copy()).to(dev), gi.REFINE_CASE["image_wh"], mode="xyxy")
+def _proposals(boxes, ids, dev, labels=None, scores=None, image_wh=None):
+    bl = BoxList(torch.from_numpy(boxes.copy()).to(dev), image_wh or gi.REFINE_CASE["image_wh"], mode="xyxy")
     bl.add_field("ids", torch.from_numpy(ids.copy()).to(dev))
     if labels is not None:
         bl.add_field("labels", torch.from_numpy(labels.copy()).to(dev))
@@ -276,3 +276,58 @@ def test_tracking_loop_with_refine_tracks_runs_the_reference_order():
     assert len(calls) == 3 and all(n == 7 for n, _, _ in calls)     # every later frame refined the 7 propagated boxes
     assert all(lo > 1.0 and hi <= 2.0 for _, lo, hi in calls)
     assert ids_seen[-1] == list(range(7))                           # the refined tracks win the NMS against detections
+
+
+@pytest.mark.gpu
+def test_yaml_sized_box_head_matches_the_reference_golden():
+    """the refinement at the SHIPPED head width (configs/dla/DLA_34_FPN_EMM.yaml:25-33: 7x7 pooler on
+    128-channel maps, 1024-1024 MLP, two classes) against ``tests/golden/refine_tracks_yaml.npz`` = the reference's own
+    ``ROIBoxHead`` / ``PostProcessor`` / ``_refine_tracks`` on these tensors (oracle/gen_golden_refine.py yaml) — through
+    the general path (HIP pooler, library GEMMs, the reference-shaped post-processor), the device-only ``refine_raw``
+    (weight-streaming GEMM kernels behind one C-ABI call) and the box head's plain ``forward`` on mixed proposals."""
+    c = gi.REFINE_CASE_YAML
+    inp = gi.refine_case_inputs(c)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine_tracks_yaml.npz"))
+    dev = "cuda:0"
+    head = TrackBoxHead(_cfg(c), c["channels"])
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in inp["params"].items()}, strict=True)
+    head = head.to(dev).eval()
+    feats = [torch.from_numpy(f).to(dev) for f in inp["features"]]
+    wh = c["image_wh"]
+    tol = 3e-5            # fp32 dot products of 6,272 and 1,024 terms in another order than torch-CPU's
+    with torch.no_grad():
+        refine = RefineTracks(head)
+        tr = _proposals(inp["track_boxes"], inp["track_ids"], dev, inp["track_labels"], inp["track_scores"], wh)
+        r = refine(feats, [tr])[0]
+        assert refine.raw_ok(len(tr)) and head.one_call_ok(len(tr))
+        rb, rs_, ri, rl = refine.refine_raw(feats, tr.bbox, tr.get_field("scores"), tr.get_field("ids"), tr.get_field("labels"), wh)
+        x, res, _ = head(feats, [_proposals(inp["mixed_boxes"], inp["mixed_ids"], dev, image_wh=wh)])
+    for bb, sc, ids, labels in ((r.bbox, r.get_field("scores"), r.get_field("ids"), r.get_field("labels")), (rb, rs_, ri, rl)):
+        assert ids.cpu().numpy().tolist() == g["refine_ids"].tolist() and labels.cpu().numpy().tolist() == g["refine_labels"].tolist()
+        np.testing.assert_allclose(bb.cpu().numpy(), g["refine_bbox"], rtol=0, atol=tol * 100)
+        np.testing.assert_allclose(sc.cpu().numpy(), g["refine_scores"], rtol=0, atol=tol)
+    m = res[0]
+    assert m.get_field("ids").cpu().numpy().tolist() == g["mixed_ids"].tolist()
+    assert m.get_field("labels").cpu().numpy().tolist() == g["mixed_labels"].tolist()
+    np.testing.assert_allclose(m.bbox.cpu().numpy(), g["mixed_bbox"], rtol=0, atol=tol * 100)
+    np.testing.assert_allclose(m.get_field("scores").cpu().numpy(), g["mixed_scores"], rtol=0, atol=tol)
+    np.testing.assert_allclose(x[:, ::9].cpu().numpy(), g["mixed_x_sub"], rtol=0, atol=tol * 10)
+
+
+def test_yaml_sized_box_head_host_logic_matches_reference_golden():
+    """The same fixture on CPU with the oracle's pooler and the numpy NMS (no HIP library): pins the host logic at the
+    shipped width in the ``-m "not gpu"`` suite."""
+    c = gi.REFINE_CASE_YAML
+    inp = gi.refine_case_inputs(c)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "refine_tracks_yaml.npz"))
+    head = TrackBoxHead(_cfg(c), c["channels"], pooler=BO.OraclePooler(c["resolution"], c["scales"], c["sampling_ratio"]),
+                        nms_fn=_cpu_nms)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in inp["params"].items()}, strict=True)
+    head = head.eval()
+    feats = [torch.from_numpy(f) for f in inp["features"]]
+    with torch.no_grad():
+        r = RefineTracks(head)(feats, [_proposals(inp["track_boxes"], inp["track_ids"], "cpu", inp["track_labels"],
+                                                  inp["track_scores"], c["image_wh"])])[0]
+    assert r.get_field("ids").numpy().tolist() == g["refine_ids"].tolist()
+    np.testing.assert_allclose(r.bbox.numpy(), g["refine_bbox"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(r.get_field("scores").numpy(), g["refine_scores"], rtol=0, atol=1e-5)
