@@ -43,6 +43,7 @@ const KnobName kKnobNames[] = {
     {"SMOT_DECODE_SPLIT", &Knobs::decode_split}, {"SMOT_XCORR_VARIANT", &Knobs::xcorr_variant},
     {"SMOT_DECODE_2PASS", &Knobs::decode_two_pass}, {"SMOT_FUSED_GEN", &Knobs::fused_gen},
     {"SMOT_TOWER_OCT", &Knobs::tower_oct},
+    {"SMOT_TOWER_BF3", &Knobs::tower_bf3},
     {"SMOT_FUSED_ORDER", &Knobs::fused_order},   {"SMOT_NO_HINT", &Knobs::no_hint},
     {"SMOT_FUSED_ABL", &Knobs::fused_abl},       {"SMOT_ANY_ORDER", &Knobs::any_order},
     {"SMOT_WINO_ABL", &Knobs::wino_abl},

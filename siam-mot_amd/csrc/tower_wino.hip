@@ -47,8 +47,15 @@ constexpr int W_EPI_FLOATS = W_ST_OFF + 32;         // epilogue image of ONE 16-
 constexpr int w_smem_floats(int oct) {              // the epilogue images (one per tile) overlay the ring
     return (oct * W_EPI_FLOATS > W_RING * W_BUF) ? oct * W_EPI_FLOATS : W_RING * W_BUF;
 }
+constexpr int W_A_FLOATS = 4 * 4 * 2 * 3 * 256;     // BF3: bf16 A parts of one 32-channel block [q][xi][o][part][1 KB]
+static_assert((W_RING * W_BUF + W_A_FLOATS) * 4 <= 160 * 1024, "BF3: ring + A image in one CU's LDS");
 static_assert(w_smem_floats(1) * 4 <= 64 * 1024, "OCT = 1: two workgroups per CU, no opt-in needed");
 static_assert(w_smem_floats(2) * 4 <= 160 * 1024, "OCT = 2: one workgroup per CU");
+
+__device__ __forceinline__ unsigned short bf16_rne(float v) {      // round to nearest even, finite inputs
+    const unsigned u = __float_as_uint(v);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
 
 // packed[tile][k = ic/4][wave][lane][q] = (G g G^T)[i = wave][j = q] of g = W[oc = 16*tile + lane%16][ic = 4k + lane/16]
 // (oc counts cls_tower channels first, then reg_tower).  One thread per (oc, ic).
@@ -77,6 +84,30 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
         u.z = 0.5f * ((gg[i][0] - gg[i][1]) + gg[i][2]);
         u.w = gg[i][2];
         *reinterpret_cast<float4*>(packed + ((((size_t)tile * nk + k) * 4 + i) * 64 + lane) * 4) = u;
+        if ((C & 31) == 0) {
+            // bf16 image (tower_wino_kernel<.., BF3>): every transformed weight as THREE bf16 parts u = u1 + u2 + u3 (each
+            // part the round-to-nearest bf16 of what the parts before it leave: the residuals are exact, |u - sum| <=
+            // 2^-26 |u|), in the A-operand order of v_mfma_f32_16x16x32_bf16 (lane = oc%16 + 16*(ic%4) holds the eight
+            // channels 32 kb + 4 s + ic%4, s = 0..7), with the 32-channel blocks of xi column q ROTATED by q + 1 stages
+            // (a stage = 8 channels = one dword d = s/2 of the lane's operand): block kb' of column q holds the dwords d <=
+            // q of channel block kb' and the dwords d > q of channel block kb' - 1 (zero outside 0..C/32-1; the image is
+            // zero-filled before this kernel), so that the kernel can consume one column per stage:
+            //   bf[tile][kb' = 0..C/32][i][q][part][lane][s]   (16 B per lane)
+            unsigned short* bf = reinterpret_cast<unsigned short*>(packed + (size_t)2 * C * C * 16);
+            const int kb = ic >> 5, sidx = (ic & 31) >> 2, nkb1 = (C >> 5) + 1;
+            const float uq[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kbp = ((sidx >> 1) <= q) ? kb : kb + 1;
+                float r = uq[q];
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    const unsigned short h = bf16_rne(r);
+                    r -= __uint_as_float((unsigned)h << 16);
+                    bf[((((((size_t)tile * nkb1 + kbp) * 4 + i) * 4 + q) * 3 + part) * 64 + lane) * 8 + sidx] = h;
+                }
+            }
+        }
     }
 }
 
@@ -91,7 +122,16 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 // `part` = the convolution output [N][2C][BHO * BHO]; GroupNorm needs the whole map and runs in tower_gn_heads_kernel
 // (tower_conv.hip).  17 % more MFMAs than a 15 x 15-tile Winograd of the whole map would need (overlap + the 32 x 32
 // cover), 54 % of the direct convolution's.
-template <int ABL, int OCT, int BHO = 0>
+// BF3: the 16 transform-domain GEMMs on the bf16 matrix pipe at fp32 accuracy — every fp32 operand is the sum of three
+// bf16 parts (weights: split once by tower_pack_kernel; activations: split in registers with v_cvt_pk_bf16_f32 as they
+// leave the operand transform), and a product keeps the six part products down to 2^-24 of its size
+//     a b ~ a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1),         dropped: a2 b3 + a3 b2 + a3 b3 <= 2^-25 |a b|,
+// accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (K = 32 input channels per instruction, 16.6 cycles, against 8 x 32
+// cycles of v_mfma_f32_16x16x4_f32: 6 x 16.6 against 256 cycles per 32 channels and tile —
+// profiles/r04_ubench_bf16x3_rate.jsonl).  The transformed operands of a K = 32 block (four stages) are collected as
+// packed bf16 pairs in 96 registers, then one burst of 96 instructions consumes them against A parts fetched as needed.
+// OCT = 2 only, not BLOCKED.
+template <int ABL, int OCT, int BHO = 0, bool BF3 = false>
 __global__ void __launch_bounds__(256 * OCT, OCT == 1 ? 2 : 1)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
                   int cpg, float eps, float* __restrict__ part, unsigned* __restrict__ zero_words,
@@ -239,6 +279,40 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             }
     };
 
+    // BF3: direct-to-LDS fetch of the bf16 A parts (see the BF3 form of the loop below)
+    const int nkb = C >> 5;
+    const int ab_block = 4 * 12288;             // bytes per (tile, kb'): [xi][q][part][lane][8 bf16]
+    const int ab_base = __builtin_amdgcn_readfirstlane(2 * C * C * 64 + ((tile0 + nh) * (nkb + 1) * 4 + xi) * 12288);
+    typedef __attribute__((address_space(3))) float lds_float;
+    lds_float* const a_lds = (lds_float*)(sm + W_RING * W_BUF);
+    const int al_wave = __builtin_amdgcn_readfirstlane((xi * 2 + nh) * 768);            // floats: this wave's DMA slots
+    const int al_row = __builtin_amdgcn_readfirstlane(xi * 2 * 768);                    // floats: the row's slots
+    // (inline asm: through the builtin, hipcc drains vmcnt before the next LDS read of ANY address; here a stage's loads
+    // are waited for at the end of the NEXT stage — s_waitcnt vmcnt(4): the raw fetch and the three loads of that stage may
+    // still be in flight — and consumed after the barrier that follows)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long pa = reinterpret_cast<unsigned long long>(packed);
+    const i32x4 rs_a_words = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
+                              __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0x7fffffff, 0x00020000};
+    const unsigned a_lds_byte = (unsigned)(size_t)a_lds;
+    auto dma_slot = [&](int q, int kbp) __attribute__((always_inline)) {       // column q of rotated block kbp, tile tile0 + nh
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            const int soff = __builtin_amdgcn_readfirstlane(ab_base + kbp * ab_block + (q * 3 + part) * 1024);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(a_lds_byte + (unsigned)(q * (4 * 2 * 768) + al_wave + part * 256) * 4u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rs_a_words), "s"(soff) : "memory");
+        }
+    };
+    auto load_al = [&](int q, u32x4 (*dst)[3]) __attribute__((always_inline)) {
+        const float* src = sm + W_RING * W_BUF + q * (4 * 2 * 768) + al_row + lane * 4;
+#pragma unroll
+        for (int o = 0; o < OCT; ++o)
+#pragma unroll
+            for (int part = 0; part < 3; ++part)
+                dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 3 + part) * 256);
+    };
     f32x4 acc[OCT][4][2 * NP];
 #pragma unroll
     for (int o = 0; o < OCT; ++o)
@@ -249,7 +323,11 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 
     load_raw(0, prs[0]);
     load_raw(1, prs[1]);
-    load_a(0, aset[0]);
+    if constexpr (BF3) {                       // columns 0 and 1 of the first block: consumed in the stages 0 and 1
+        dma_slot(0, 0);
+        dma_slot(1, 0);
+    }
+    if constexpr (!BF3) load_a(0, aset[0]);
     if (ABL == 2 || ABL >= 5) {
 #pragma unroll
         for (int o = 0; o < OCT; ++o) {
@@ -268,7 +346,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // block), so block b of register r holds the four head weights (lane % 4 = output) of tap r*16 + b, and the
     // epilogue's 144 instructions name their tap through ABID.  No LDS image of the taps, no LDS read per tap.
     float hwv[9];
-    {
+    auto load_hwv = [&]() __attribute__((always_inline)) {
         const int o = lane & 3, blk = lane >> 2;
         const float* wsrc = (tower == 1) ? P.reg_w + (size_t)o * C * 9
                                          : (o < 2 ? P.cls_w + (size_t)o * C * 9 : P.center_w);
@@ -276,13 +354,15 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         wsrc += (size_t)oc0 * 9 + blk;
 #pragma unroll
         for (int r = 0; r < 9; ++r) hwv[r] = live ? wsrc[r * 16] : 0.0f;
-    }
+    };
+    if constexpr (!BF3) load_hwv();          // BF3: after the main loop (nine registers the loop needs)
 
     __syncthreads();                       // zero fill complete before interior writes
     store_raw(sm, prs[0]);
     store_raw(sm + W_BUF, prs[1]);
     load_raw(min(2, nstages - 1), prs[0]);
     load_raw(min(3, nstages - 1), prs[1]);
+    if constexpr (BF3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first A parts are in LDS
     __syncthreads();
 
     // rows of the 4x4 patch this wave's xi-row combines:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
@@ -321,24 +401,25 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         }
     }
 #define W_READ(BUFI, Q, RD)                                                                      \
-    if (ABL != 3 && ABL < 5) {                                                                   \
+    if (ABL != 3 && (ABL < 5 || ABL >= 7)) {                                                     \
         const float* oa = sm + ia + ((BUFI) * W_BUF + (Q) * 4 * W_PLANE);                        \
         const float* ob = sm + ib + ((BUFI) * W_BUF + (Q) * 4 * W_PLANE);                        \
         _Pragma("unroll") for (int p = 0; p < NP; ++p) {         /* tile rows ty and ty + 4 */    \
-            const float4 a4 = *reinterpret_cast<const float4*>(oa + p * 8 * W_ROW);              \
-            const float2 a2 = *reinterpret_cast<const float2*>(oa + p * 8 * W_ROW + 4);          \
-            const float4 b4 = *reinterpret_cast<const float4*>(ob + p * 8 * W_ROW);              \
-            const float2 b2 = *reinterpret_cast<const float2*>(ob + p * 8 * W_ROW + 4);          \
-            RD[p][0][0] = a4.x; RD[p][0][1] = b4.x;                                              \
-            RD[p][1][0] = a4.y; RD[p][1][1] = b4.y;                                              \
-            RD[p][2][0] = a4.z; RD[p][2][1] = b4.z;                                              \
-            RD[p][3][0] = a4.w; RD[p][3][1] = b4.w;                                              \
-            RD[p][4][0] = a2.x; RD[p][4][1] = b2.x;                                              \
-            RD[p][5][0] = a2.y; RD[p][5][1] = b2.y;                                              \
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(oa + p * 8 * W_ROW);                      \
+            f32x2 a2 = *reinterpret_cast<const f32x2*>(oa + p * 8 * W_ROW + 4);                  \
+            f32x4 b4 = *reinterpret_cast<const f32x4*>(ob + p * 8 * W_ROW);                      \
+            f32x2 b2 = *reinterpret_cast<const f32x2*>(ob + p * 8 * W_ROW + 4);                  \
+            if (BF3) asm volatile("" : "+v"(a4), "+v"(a2), "+v"(b4), "+v"(b2));                  \
+            RD[p][0][0] = a4[0]; RD[p][0][1] = b4[0];                                            \
+            RD[p][1][0] = a4[1]; RD[p][1][1] = b4[1];                                            \
+            RD[p][2][0] = a4[2]; RD[p][2][1] = b4[2];                                            \
+            RD[p][3][0] = a4[3]; RD[p][3][1] = b4[3];                                            \
+            RD[p][4][0] = a2[0]; RD[p][4][1] = b2[0];                                            \
+            RD[p][5][0] = a2[1]; RD[p][5][1] = b2[1];                                            \
         }                                                                                        \
     }
 #define W_XFORM(RD, BOP)                                                                         \
-    if (ABL != 3 && ABL < 5) _Pragma("unroll") for (int p = 0; p < NP; ++p) {                    \
+    if (ABL != 3 && (ABL < 5 || ABL >= 7)) _Pragma("unroll") for (int p = 0; p < NP; ++p) {      \
         /* six columns of the row combination d_a +- d_b, shared by the tile pair */             \
         float w[6];                                                                              \
         _Pragma("unroll") for (int c = 0; c < 6; ++c)                                            \
@@ -389,8 +470,123 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         W_STAGE(2)                                                                               \
         W_STAGE(3)                                                                               \
     }
+    // ---- BF3 form of the loop -----------------------------------------------------------------------
+    // K index of the bf16 instruction: lane group kq = lane/16 holds K = 8 kq + s, s = 0..7 <-> input channel 32 kb + 4 s +
+    // kq: s is the k-step inside a 32-channel block, so the lane's operand of k-step s is element s of its 8-vector and a
+    // stage (two k-steps) fills dword (stage % 4).  Bp[part][q][t] = the three bf16x8 B operands of xi column q, N-tile t.
+    // One xi column per stage: the K blocks of column q end with the stages = q (mod 4) (the weights are stored rotated to
+    // match, tower_pack_kernel), so every stage ends with the 24 instructions of ONE column ("mini-burst") instead of every
+    // fourth stage with 96: the operand registers are single-buffered all the same, matrix and vector work come in
+    // stage-sized pieces that the two waves of a SIMD run in opposite order (nh = 0: stage work, then the column of this
+    // stage; nh = 1: the column of the previous stage, then stage work) so that one wave's matrix instructions cover the
+    // other's vector work, and the A parts of a column are needed once per four stages.
+    // A parts: the two waves of an xi row need the same 6 KB per column and block; every wave brings HALF of them (those
+    // of tile tile0 + nh) into LDS with direct-to-LDS loads (no registers, 1 KB per instruction), two stages before the
+    // column is consumed, and both read them from there.  (Fetched per wave into registers they saturate the L2 -> CU
+    // path and their latency is exposed: measure/debug/tower_bf3_check.py.)
+    //   LDS: A image behind the ring: slot q = [xi][o][part][lane][8 bf16] = 24 KB, four slots.
+    u32x4 Bp[BF3 ? 3 : 1][4][2];
+    float rdb[NP][6][2];                        // second read set: both k-steps of the next stage are in flight
+    if constexpr (BF3) {
+#pragma unroll
+        for (int e = 0; e < 24; ++e) (&Bp[0][0][0])[e] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    // (v_cvt_pk_bf16_f32 through the vector conversion, NOT inline asm: the results are matrix-instruction operands a few
+    // instructions later, and hipcc's hazard recognizer does not see what an asm statement writes — with asm the column's
+    // instructions read half-written operands now and then)
+#define WB_CVT(D, A, B) D = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){A, B}, bf16x2));
+#define WB_SPLIT(J, BA, BB)                                                                      \
+    if (ABL == 8) { _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
+        Bp[0][q][t][J] = __float_as_uint(BA[q][t]); Bp[BF3 ? 1 : 0][q][t][J] = __float_as_uint(BB[q][t]); } }      \
+    else _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
+        unsigned ph, pm, pl;                                                                     \
+        WB_CVT(ph, BA[q][t], BB[q][t])                                                           \
+        const float r0 = BA[q][t] - __uint_as_float(ph << 16);                  /* exact */      \
+        const float r1 = BB[q][t] - __uint_as_float(ph & 0xffff0000u);                           \
+        WB_CVT(pm, r0, r1)                                                                       \
+        const float s0_ = r0 - __uint_as_float(pm << 16);                                        \
+        const float s1_ = r1 - __uint_as_float(pm & 0xffff0000u);                                \
+        WB_CVT(pl, s0_, s1_)                                                                     \
+        Bp[0][q][t][J] = ph;                                                                     \
+        Bp[BF3 ? 1 : 0][q][t][J] = pm;                                                           \
+        Bp[BF3 ? 2 : 0][q][t][J] = pl;                                                           \
+    }
+#define WB_MM(O, Q, T, PA, PB)                                                                   \
+    if (ABL != 7) acc[O][Q][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AB[O][PA]), \
+                                                           __builtin_bit_cast(bf16x8, Bp[BF3 ? (PB) : 0][Q][T]), acc[O][Q][T], 0, 0, 0);
+#define WB_TERM(Q, PA, PB) WB_MM(0, Q, 0, PA, PB) WB_MM(1, Q, 0, PA, PB) WB_MM(0, Q, 1, PA, PB) WB_MM(1, Q, 1, PA, PB)
+    // one column: smallest terms first; four independent accumulators per term
+#define WB_Q(Q)                                                                                  \
+    {                                                                                            \
+        u32x4 AB[OCT][3];                                                                        \
+        load_al(Q, AB);                                                                          \
+        if (ABL == 7) { _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
+            acc[0][Q][t][e] += __uint_as_float(Bp[0][Q][t][e] ^ Bp[BF3 ? 1 : 0][Q][t][e] ^ Bp[BF3 ? 2 : 0][Q][t][e] ^ AB[0][0][e] ^ AB[1][2][e]); } \
+        WB_TERM(Q, 2, 0) WB_TERM(Q, 1, 1) WB_TERM(Q, 0, 2) WB_TERM(Q, 1, 0) WB_TERM(Q, 0, 1) WB_TERM(Q, 0, 0) \
+    }
+#define WB_STAGE(J)                                                                              \
+    {                                                                                            \
+        __syncthreads();                                                                         \
+        store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
+        load_raw(min(s0 + (J) + 4, nstages - 1), prs[(J) & 1]);                                  \
+        W_FENCE                                                                                  \
+        /* slot (J + 2) % 4 was consumed two stages (nh = 1: one stage) ago; its next use is two stages ahead */ \
+        if (ABL != 9) dma_slot(((J) + 2) & 3, (s0 >> 2) + ((J) >= 2 ? 1 : 0));                   \
+        W_FENCE                                                                                  \
+        if (NH == 1 && ((J) > 0 || s0 > 0)) WB_Q(((J) + 3) & 3)                                  \
+        float ba[4][2 * NP], bb[4][2 * NP];                                                      \
+        W_XFORM(rd, ba)                                /* k-step 2s */                           \
+        W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
+        W_XFORM(rdb, bb)                               /* k-step 2s+1 */                         \
+        W_READ(((J) + 1) & 3, 1, rdb)                                                            \
+        WB_SPLIT(J, ba, bb)                                                                      \
+        if (NH == 0) WB_Q(J)                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the A parts fetched in the stage before this one are in LDS */ \
+        W_FENCE                                                                                  \
+    }
+#define WB_LOOP                                                                                  \
+    W_READ(0, 0, rd)                                                                             \
+    W_READ(0, 1, rdb)                                                                            \
+    for (int s0 = 0; s0 < nstages; s0 += 4) {                                                    \
+        WB_STAGE(0)                                                                              \
+        WB_STAGE(1)                                                                              \
+        WB_STAGE(2)                                                                              \
+        WB_STAGE(3)                                                                              \
+    }                                                                                            \
+    /* the last, partial blocks of the columns 0..2 (zero weights where their stages do not exist) */ \
+    __syncthreads();                                                                             \
+    if (ABL != 9) dma_slot(2, nkb);                                                              \
+    if (NH == 1) WB_Q(3)                                                                         \
+    WB_Q(0)                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    __syncthreads();                                                                             \
+    WB_Q(1)                                                                                      \
+    WB_Q(2)
     W_TRACE(1)
-    if (xi == 1) {               // the xi-row 1 combination adds its two patch rows, the others subtract
+    if constexpr (BF3) {
+        static_assert(!BF3 || (OCT == 2 && BHO == 0 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
+        // which waves run the column before the stage work: the second wave of each SIMD (ABL 10..12: other guesses of
+        // the wave -> SIMD map, for measurement)
+        const int lag = ABL == 10 ? (wave & 1) : ABL == 11 ? ((wave >> 1) & 1) : ABL == 12 ? 0 : nh;
+        if (xi == 1 && lag == 0) {
+            constexpr bool PLUS = true;
+            constexpr int NH = 0;
+            WB_LOOP
+        } else if (xi == 1) {
+            constexpr bool PLUS = true;
+            constexpr int NH = 1;
+            WB_LOOP
+        } else if (lag == 0) {
+            constexpr bool PLUS = false;
+            constexpr int NH = 0;
+            WB_LOOP
+        } else {
+            constexpr bool PLUS = false;
+            constexpr int NH = 1;
+            WB_LOOP
+        }
+        load_hwv();
+    } else if (xi == 1) {        // the xi-row 1 combination adds its two patch rows, the others subtract
         constexpr bool PLUS = true;
         W_LOOP
     } else {
@@ -398,6 +594,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         W_LOOP
     }
     __syncthreads();
+#undef WB_LOOP
+#undef WB_STAGE
+#undef WB_Q
+#undef WB_TERM
+#undef WB_MM
+#undef WB_SPLIT
+#undef WB_CVT
 #undef W_LOOP
 #undef W_FENCE
 #undef W_STAGE
@@ -575,12 +778,42 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
     const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
     int oct = (c2 < c1) ? 2 : 1;
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
-    const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
+    const bool bf3 = oct == 2 && knobs().tower_bf3 != 0;
+    const size_t smem = (size_t)(bf3 ? W_RING * W_BUF + W_A_FLOATS : w_smem_floats(oct)) * sizeof(float);
     const int grid = ((N + 7) / 8) * 8 * (tiles / oct);
     if (oct == 2) {                            // 115 KB of dynamic LDS
-        const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>), smem,
-                                         "predictor towers (winograd)");
+        const void* fn = bf3 ? reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 0, true>)
+                             : reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>);
+#ifdef SMOT_DEBUG
+        if (bf3 && knobs().wino_abl == 7) fn = reinterpret_cast<const void*>(&tower_wino_kernel<7, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 8) fn = reinterpret_cast<const void*>(&tower_wino_kernel<8, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 11) fn = reinterpret_cast<const void*>(&tower_wino_kernel<11, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 12) fn = reinterpret_cast<const void*>(&tower_wino_kernel<12, 2, 0, true>);
+#endif
+        const int rco = ensure_lds_optin(fn, smem, "predictor towers (winograd)");
         if (rco) return rco;
+    }
+    if (bf3) {
+#define WB_LAUNCH(A)                                                                                              \
+    SMOT_LAUNCH((tower_wino_kernel<A, 2, 0, true>), dim3(grid), dim3(512), smem, st, resp, packed, P, N, C, cpg, eps, part, \
+                zero_words, g_trace)
+#ifdef SMOT_DEBUG
+        switch (knobs().wino_abl) {      // 7 = no matrix instructions, 8 = no operand split, 9 = A parts fetched once per block
+            case 7: WB_LAUNCH(7); break;
+            case 8: WB_LAUNCH(8); break;
+            case 9: WB_LAUNCH(9); break;
+            case 10: WB_LAUNCH(10); break;
+            case 11: WB_LAUNCH(11); break;
+            case 12: WB_LAUNCH(12); break;
+            default: WB_LAUNCH(0); break;
+        }
+#else
+        WB_LAUNCH(0);
+#endif
+#undef WB_LAUNCH
+        return check_launch("predictor towers (winograd, bf16 x 3)");
     }
 #define W_LAUNCH(A, O)                                                                                            \
     SMOT_LAUNCH((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, part, \
@@ -646,7 +879,9 @@ int launch_tower_wino_blocks(const float* resp, const float* packed, const Tower
 
 extern "C" long long smot_emm_tower_pack_floats(int C) {
     if (C <= 0 || C % 16 != 0) return 0;          // the packed path needs 16-channel tiles
-    return (long long)2 * C * C * 16;
+    // fp32 image 2 C^2 x 16, then (C % 32 == 0) the three-part bf16 image: C/32 + 1 rotated blocks of 12288 floats per
+    // 16-channel tile
+    return (long long)2 * C * C * 16 + ((C % 32 == 0) ? (long long)(2 * C / 16) * (C / 32 + 1) * 12288 : 0);
 }
 
 extern "C" int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
@@ -655,6 +890,11 @@ extern "C" int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_to
     SMOT_REQUIRE(C > 0 && C % 16 == 0, "tower_pack: C=%d must be a multiple of 16", C);
     SMOT_REQUIRE(cls_tower_w && reg_tower_w && packed, "tower_pack: null pointer");
     SMOT_REQUIRE(((uintptr_t)packed & 15) == 0, "tower_pack: output must be 16-byte aligned");
+    if (C % 32 == 0) {
+        const hipError_t e = hipMemsetAsync(packed + (size_t)2 * C * C * 16, 0, (size_t)(2 * C / 16) * (C / 32 + 1) * 12288 * 4,
+                                            (hipStream_t)stream);
+        SMOT_REQUIRE(e == hipSuccess, "tower_pack: memset failed: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(tower_pack_kernel, dim3((2 * C * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls_tower_w,
                        reg_tower_w, C, packed);
     return check_launch("tower_pack");
