@@ -168,12 +168,18 @@ int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const
  *
  *   tower_packed: optional (may be NULL) output of smot_emm_tower_pack for the SAME tower weights: the
  *   Winograd F(2x2,3x3)-transformed tower filters in the order the matrix-core kernel consumes them.
- *   With it (and Ho == 16) the towers run as a Winograd convolution on the fp32 matrix cores — all-fp32
- *   arithmetic, 2.25x fewer multiplies, results equal to the direct convolution up to fp32 rounding
- *   order; without it the direct fp32 kernel runs.  It is a pure function of the two tower weight
- *   tensors: recompute it whenever they change (the Python layer keys it on the tensors' versions).
+ *   With it (and Ho == 16) the towers run as a Winograd convolution on the matrix cores — 2.25x fewer
+ *   multiplies, results equal to the direct convolution up to fp32 rounding order; without it the direct
+ *   fp32 kernel runs.  Two forms, chosen by the number of tracks: fp32 matrix instructions on the fp32
+ *   image, or (C % 32 == 0, more than 16 tracks) bf16 matrix instructions on operands split into three
+ *   bf16 parts each (weights: split once into the second image; activations: split in registers), which
+ *   keeps every product to 2^-24 of its size with fp32 accumulation: fp32 accuracy at twice the rate.
+ *   It is a pure function of the two tower weight tensors: recompute it whenever they change (the Python
+ *   layer keys it on the tensors' versions).
  */
-long long smot_emm_tower_pack_floats(int C);      /* 2*C*C*16 for C % 16 == 0, else 0 (no packed path) */
+/* floats of the packed image: 2*C*C*16 (fp32 image; C % 16 == 0, else 0 = no packed path), plus for C % 32 == 0 the
+ * three-part bf16 image, (2*C/16) * (C/32 + 1) * 12288 */
+long long smot_emm_tower_pack_floats(int C);
 int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
                         smot_stream_t stream);
 

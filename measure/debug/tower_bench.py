@@ -13,7 +13,7 @@ OCTS = [int(o) for o in os.environ.get("OCTS", "1,2").split(",")]       # 16-cha
 for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     for abl, oct_ in [(a, o) for a in ABLS for o in (OCTS if a != "direct" else [0])]:
-      with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl), SMOT_TOWER_OCT=oct_):
+      with ops.debug_library(SMOT_WINO_ABL=(0 if abl == "direct" else abl), SMOT_TOWER_OCT=oct_, SMOT_TOWER_BF3=os.environ.get("BF3", "1")):
         f = lambda: ops.emm_predictor(resp, P, winograd=(abl != "direct"))
         for _ in range(200): f()
         torch.cuda.synchronize()
@@ -23,7 +23,8 @@ for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
             for _ in range(300): f()
             ms, cnt = ops.kernel_timer_end(ops.TIMER_TOWER)
             ts.append(ms / cnt * 1e3)
-        print(json.dumps({"tracks": n, "variant": abl, "tiles_per_wg": oct_, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
+        print(json.dumps({"tracks": n, "variant": abl, "tiles_per_wg": oct_, "bf3": int(os.environ.get("BF3", "1")) if oct_ == 2 else 0, "tower_event_us_min": round(min(ts), 2), "median": round(sorted(ts)[2], 2)}), flush=True)
+if os.environ.get("SWEEP"): sys.exit(0)
 # phase trace (s_memtime ticks, 100 MHz constant clock on gfx9: report raw ticks and fractions)
 for n, oct_ in [(n, o) for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")] for o in OCTS]:
   with ops.debug_library(SMOT_TOWER_OCT=oct_) as lib:

@@ -30,6 +30,8 @@ ARCH = "gfx950"
 # -ffp-contract=off: the reference's torch kernels round every mul/add separately; coordinate and
 # score arithmetic must do the same (a contracted `start + p*bin` moves a bilinear sample point by
 # 1 ulp ~ 1e-5 in the output).  FMAs are written explicitly (fmaf) where they are wanted.
+# (tower_wino.hip without -fno-slp-vectorize was measured: the packed adds hipcc then forms in the operand transform make
+# both forms of the kernel slower — fp32 main loop 40.6 k -> 42.4 k cycles, bf16 x 3 32.7 k -> 37.9 k)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=off", "--offload-arch=" + ARCH]
 
 

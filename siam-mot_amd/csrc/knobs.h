@@ -31,7 +31,7 @@ struct Knobs {
     int no_hint = 0;         // SMOT_NO_HINT       : 1 = the pooling + correlation kernel ignores the order hint and ranks
                              //                      its rois itself, 2 = the extraction does not write one either
     int tower_oct = 0;       // SMOT_TOWER_OCT     : 16-channel tiles per Winograd workgroup (0 = default, 1 or 2)
-    int tower_bf3 = 0;       // SMOT_TOWER_BF3     : 1 = two-tile Winograd workgroups run the bf16 x 3 form of the GEMMs
+    int tower_bf3 = 1;       // SMOT_TOWER_BF3     : 0 = two-tile Winograd workgroups run the fp32 form of the GEMMs (1 = bf16 x 3)
     int any_order = 0;       // SMOT_ANY_ORDER     : launches carry hipExtAnyOrderLaunch (no barrier between the kernels of a
                              //                      stream: WRONG results — an upper bound on what overlapping the kernels'
                              //                      dispatch ramps and tails could buy, measure/any_order_ab.py)

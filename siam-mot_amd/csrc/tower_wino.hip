@@ -287,9 +287,9 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     lds_float* const a_lds = (lds_float*)(sm + W_RING * W_BUF);
     const int al_wave = __builtin_amdgcn_readfirstlane((xi * 2 + nh) * 768);            // floats: this wave's DMA slots
     const int al_row = __builtin_amdgcn_readfirstlane(xi * 2 * 768);                    // floats: the row's slots
-    // (inline asm: through the builtin, hipcc drains vmcnt before the next LDS read of ANY address; here a stage's loads
-    // are waited for at the end of the NEXT stage — s_waitcnt vmcnt(4): the raw fetch and the three loads of that stage may
-    // still be in flight — and consumed after the barrier that follows)
+    // (inline asm: through the builtin, hipcc drains vmcnt before the next LDS read of ANY address — right after the issue;
+    // here a stage's loads are waited for at the END of the stage, ~2 k cycles after their issue, with a plain vmcnt(0)
+    // (no assumption on the order in which direct-to-LDS and register loads retire), and consumed two barriers later)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const unsigned long long pa = reinterpret_cast<unsigned long long>(packed);
     const i32x4 rs_a_words = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
@@ -477,9 +477,12 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // One xi column per stage: the K blocks of column q end with the stages = q (mod 4) (the weights are stored rotated to
     // match, tower_pack_kernel), so every stage ends with the 24 instructions of ONE column ("mini-burst") instead of every
     // fourth stage with 96: the operand registers are single-buffered all the same, matrix and vector work come in
-    // stage-sized pieces that the two waves of a SIMD run in opposite order (nh = 0: stage work, then the column of this
-    // stage; nh = 1: the column of the previous stage, then stage work) so that one wave's matrix instructions cover the
-    // other's vector work, and the A parts of a column are needed once per four stages.
+    // stage-sized pieces that overlap (the bf16 matrix instructions run beside vector instructions: loop 32.7 k cycles
+    // with, 27.6 k without them; all 96 after every fourth stage: 35 k), and the A parts of a column are needed once per
+    // four stages.  (Running the column of the PREVIOUS stage first in the second wave of each SIMD, so that the two waves
+    // alternate between matrix and vector work, was measured: 35.9 k against 34.2 k cycles — dropped.)
+    // The loop is bound by its vector instructions (118 per wave and stage at ~4.3 cycles each on the SIMD's two waves:
+    // 28 of the operand transform, 88 of the split = 11 per operand pair, 2 addresses).
     // A parts: the two waves of an xi row need the same 6 KB per column and block; every wave brings HALF of them (those
     // of tile tile0 + nh) into LDS with direct-to-LDS loads (no registers, 1 KB per instruction), two stages before the
     // column is consumed, and both read them from there.  (Fetched per wave into registers they saturate the L2 -> CU
@@ -495,17 +498,20 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // instructions later, and hipcc's hazard recognizer does not see what an asm statement writes — with asm the column's
     // instructions read half-written operands now and then)
 #define WB_CVT(D, A, B) D = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){A, B}, bf16x2));
+    // residual v - (half H of the pair P), exact.  (As one v_dot2c_f32_bf16 — P . (-1, 0) + v — it was measured slower,
+    // main loop 32.7 k -> 40.3 k cycles, and not exact.)
+#define WB_RES(V, P, H) ((V) - __uint_as_float((H) ? ((P) & 0xffff0000u) : ((P) << 16)))
 #define WB_SPLIT(J, BA, BB)                                                                      \
     if (ABL == 8) { _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
         Bp[0][q][t][J] = __float_as_uint(BA[q][t]); Bp[BF3 ? 1 : 0][q][t][J] = __float_as_uint(BB[q][t]); } }      \
     else _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
         unsigned ph, pm, pl;                                                                     \
         WB_CVT(ph, BA[q][t], BB[q][t])                                                           \
-        const float r0 = BA[q][t] - __uint_as_float(ph << 16);                  /* exact */      \
-        const float r1 = BB[q][t] - __uint_as_float(ph & 0xffff0000u);                           \
+        const float r0 = WB_RES(BA[q][t], ph, 0);                               /* exact */      \
+        const float r1 = WB_RES(BB[q][t], ph, 1);                                                \
         WB_CVT(pm, r0, r1)                                                                       \
-        const float s0_ = r0 - __uint_as_float(pm << 16);                                        \
-        const float s1_ = r1 - __uint_as_float(pm & 0xffff0000u);                                \
+        const float s0_ = WB_RES(r0, pm, 0);                                                     \
+        const float s1_ = WB_RES(r1, pm, 1);                                                     \
         WB_CVT(pl, s0_, s1_)                                                                     \
         Bp[0][q][t][J] = ph;                                                                     \
         Bp[BF3 ? 1 : 0][q][t][J] = pm;                                                           \
@@ -524,39 +530,53 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             acc[0][Q][t][e] += __uint_as_float(Bp[0][Q][t][e] ^ Bp[BF3 ? 1 : 0][Q][t][e] ^ Bp[BF3 ? 2 : 0][Q][t][e] ^ AB[0][0][e] ^ AB[1][2][e]); } \
         WB_TERM(Q, 2, 0) WB_TERM(Q, 1, 1) WB_TERM(Q, 0, 2) WB_TERM(Q, 1, 0) WB_TERM(Q, 0, 1) WB_TERM(Q, 0, 0) \
     }
-#define WB_STAGE(J)                                                                              \
+    // the row combination d_a +- d_b as one fused multiply-add with the wave's sign in a scalar register (exact: the
+    // factor is +-1): ONE copy of the loop for all four xi rows, which leaves the instruction cache room for unrolling it
+    const float sgn = __uint_as_float(__builtin_amdgcn_readfirstlane(xi == 1 ? 0x3f800000u : 0xbf800000u));
+#define WB_XFORM(RD, BOP)                                                                        \
+    _Pragma("unroll") for (int p = 0; p < NP; ++p) {                                             \
+        float w[6];                                                                              \
+        _Pragma("unroll") for (int c = 0; c < 6; ++c) w[c] = __builtin_fmaf(sgn, RD[p][c][1], RD[p][c][0]); \
+        BOP[0][2 * p] = w[0] - w[2];                                                             \
+        BOP[1][2 * p] = w[1] + w[2];                                                             \
+        BOP[2][2 * p] = w[2] - w[1];                                                             \
+        BOP[3][2 * p] = w[1] - w[3];                                                             \
+        BOP[0][2 * p + 1] = w[2] - w[4];                                                         \
+        BOP[1][2 * p + 1] = w[3] + w[4];                                                         \
+        BOP[2][2 * p + 1] = w[4] - w[3];                                                         \
+        BOP[3][2 * p + 1] = w[3] - w[5];                                                         \
+    }
+#define WB_STAGE(J, KB)                                                                          \
     {                                                                                            \
         __syncthreads();                                                                         \
         store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
-        load_raw(min(s0 + (J) + 4, nstages - 1), prs[(J) & 1]);                                  \
+        load_raw(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);                            \
         W_FENCE                                                                                  \
-        /* slot (J + 2) % 4 was consumed two stages (nh = 1: one stage) ago; its next use is two stages ahead */ \
-        if (ABL != 9) dma_slot(((J) + 2) & 3, (s0 >> 2) + ((J) >= 2 ? 1 : 0));                   \
+        /* slot (J + 2) % 4 was consumed two stages ago; its next use is two stages ahead */     \
+        if (ABL != 9) dma_slot(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0));                        \
         W_FENCE                                                                                  \
-        if (NH == 1 && ((J) > 0 || s0 > 0)) WB_Q(((J) + 3) & 3)                                  \
         float ba[4][2 * NP], bb[4][2 * NP];                                                      \
-        W_XFORM(rd, ba)                                /* k-step 2s */                           \
+        WB_XFORM(rd, ba)                               /* k-step 2s */                           \
         W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
-        W_XFORM(rdb, bb)                               /* k-step 2s+1 */                         \
+        WB_XFORM(rdb, bb)                              /* k-step 2s+1 */                         \
         W_READ(((J) + 1) & 3, 1, rdb)                                                            \
         WB_SPLIT(J, ba, bb)                                                                      \
-        if (NH == 0) WB_Q(J)                                                                     \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the A parts fetched in the stage before this one are in LDS */ \
+        WB_Q(J)                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the A parts fetched in this stage are in LDS */        \
         W_FENCE                                                                                  \
     }
+#define WB_BLOCK(KB) WB_STAGE(0, KB) WB_STAGE(1, KB) WB_STAGE(2, KB) WB_STAGE(3, KB)
 #define WB_LOOP                                                                                  \
     W_READ(0, 0, rd)                                                                             \
     W_READ(0, 1, rdb)                                                                            \
-    for (int s0 = 0; s0 < nstages; s0 += 4) {                                                    \
-        WB_STAGE(0)                                                                              \
-        WB_STAGE(1)                                                                              \
-        WB_STAGE(2)                                                                              \
-        WB_STAGE(3)                                                                              \
+    if (nkb == 4) {        /* C = 128 unrolled: no loop-carried register shuffle (160 moves per trip otherwise) */ \
+        WB_BLOCK(0) WB_BLOCK(1) WB_BLOCK(2) WB_BLOCK(3)                                          \
+    } else {                                                                                     \
+        for (int kb = 0; kb < nkb; ++kb) { WB_BLOCK(kb) }                                        \
     }                                                                                            \
     /* the last, partial blocks of the columns 0..2 (zero weights where their stages do not exist) */ \
     __syncthreads();                                                                             \
     if (ABL != 9) dma_slot(2, nkb);                                                              \
-    if (NH == 1) WB_Q(3)                                                                         \
     WB_Q(0)                                                                                      \
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
     __syncthreads();                                                                             \
@@ -565,24 +585,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     W_TRACE(1)
     if constexpr (BF3) {
         static_assert(!BF3 || (OCT == 2 && BHO == 0 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
-        // which waves run the column before the stage work: the second wave of each SIMD (ABL 10..12: other guesses of
-        // the wave -> SIMD map, for measurement)
-        const int lag = ABL == 10 ? (wave & 1) : ABL == 11 ? ((wave >> 1) & 1) : ABL == 12 ? 0 : nh;
-        if (xi == 1 && lag == 0) {
-            constexpr bool PLUS = true;
-            constexpr int NH = 0;
-            WB_LOOP
-        } else if (xi == 1) {
-            constexpr bool PLUS = true;
-            constexpr int NH = 1;
-            WB_LOOP
-        } else if (lag == 0) {
-            constexpr bool PLUS = false;
-            constexpr int NH = 0;
-            WB_LOOP
-        } else {
-            constexpr bool PLUS = false;
-            constexpr int NH = 1;
+        {
             WB_LOOP
         }
         load_hwv();
@@ -596,10 +599,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     __syncthreads();
 #undef WB_LOOP
 #undef WB_STAGE
+#undef WB_BLOCK
+#undef WB_XFORM
 #undef WB_Q
 #undef WB_TERM
 #undef WB_MM
 #undef WB_SPLIT
+#undef WB_RES
 #undef WB_CVT
 #undef W_LOOP
 #undef W_FENCE
@@ -763,19 +769,20 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
                       float* part, unsigned* zero_words, hipStream_t st) {
     const int tiles = 2 * (C / 16);
     // One or two 16-channel tiles per workgroup, whichever the dispatch-round arithmetic favours (kernel durations by
-    // start/stop events at C = 128, profiles/r02_tower_forms_by_tracks.jsonl):
-    //   one tile  : 16 workgroups per track, 2 per CU -> rounds of 512; 27 us per full round, ~15 us for a last round
-    //               that leaves every workgroup a CU of its own (<= 256), and 20 us when the WHOLE launch does;
-    //   two tiles : 8 workgroups per track, 115 KB of LDS -> 1 per CU, rounds of 256; 24.5 us per full round, 22.5 us
-    //               for a partial one.
-    // e.g. <= 16 tracks: one tile (20 vs 25.5 us); 17..32: two (25.8 vs 28.6); 33..48: one (43 vs 48); 64: two (49 vs
-    // 54); 100: equal.  The constants scale with C alike, so the comparison holds for other channel counts.
-    // SMOT_TOWER_OCT = 1 / 2 forces a form in the measurement library.
+    // start/stop events at C = 128, profiles/r04_tower_sweep.jsonl; round 2: r02_tower_forms_by_tracks.jsonl):
+    //   one tile (fp32)      : 16 workgroups per track, 2 per CU -> rounds of 512; 27 us per full round, ~15 us for a last
+    //                          round that leaves every workgroup a CU of its own (<= 256), 20 us when the WHOLE launch does;
+    //   two tiles (bf16 x 3) : 8 workgroups per track, 152 KB of LDS -> 1 per CU, rounds of 256; 3.8 + 19.8 us per round
+    //                          (fp32 form: 24.5 per full round, 22.5 for a partial one).
+    // e.g. <= 16 tracks: one tile (19.8 vs 23.3 us); 17..32: two (23.6 vs 29.3); 33..48: two (43.4 vs 44); 64: two (43.5
+    // vs 55); 100: two (82.9 vs 92.6).  The constants scale with C alike, so the comparison holds for other channel counts.
+    // SMOT_TOWER_OCT = 1 / 2 forces a form, SMOT_TOWER_BF3 = 0 the fp32 form of two tiles, in the measurement library.
     const int np8 = ((N + 7) / 8) * 8;
     const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
     const float c1 = (w1 <= 256) ? 20.0f
                                  : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
-    const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
+    const float c2 = knobs().tower_bf3 != 0 ? 3.8f + 19.8f * (float)((w2 + 255) / 256)
+                                            : 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
     int oct = (c2 < c1) ? 2 : 1;
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
     const bool bf3 = oct == 2 && knobs().tower_bf3 != 0;
@@ -788,9 +795,6 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
         if (bf3 && knobs().wino_abl == 7) fn = reinterpret_cast<const void*>(&tower_wino_kernel<7, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 8) fn = reinterpret_cast<const void*>(&tower_wino_kernel<8, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 11) fn = reinterpret_cast<const void*>(&tower_wino_kernel<11, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 12) fn = reinterpret_cast<const void*>(&tower_wino_kernel<12, 2, 0, true>);
 #endif
         const int rco = ensure_lds_optin(fn, smem, "predictor towers (winograd)");
         if (rco) return rco;
@@ -804,9 +808,6 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
             case 7: WB_LAUNCH(7); break;
             case 8: WB_LAUNCH(8); break;
             case 9: WB_LAUNCH(9); break;
-            case 10: WB_LAUNCH(10); break;
-            case 11: WB_LAUNCH(11); break;
-            case 12: WB_LAUNCH(12); break;
             default: WB_LAUNCH(0); break;
         }
 #else

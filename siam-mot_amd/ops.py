@@ -119,7 +119,7 @@ def _open(path, signatures):
 
 _KNOB_DEFAULTS = {"SMOT_NO_FUSE": "0", "SMOT_ROI_GENERIC": "0", "SMOT_TOWER_DIRECT": "0", "SMOT_TOWER_WIDE": "0",
                   "SMOT_DECODE_SPLIT": "0", "SMOT_XCORR_VARIANT": "default", "SMOT_DECODE_2PASS": "0",
-                  "SMOT_FUSED_GEN": "0", "SMOT_TOWER_OCT": "0", "SMOT_TOWER_BF3": "0", "SMOT_FUSED_ORDER": "0", "SMOT_NO_HINT": "0", "SMOT_FUSED_ABL": "0",
+                  "SMOT_FUSED_GEN": "0", "SMOT_TOWER_OCT": "0", "SMOT_TOWER_BF3": "1", "SMOT_FUSED_ORDER": "0", "SMOT_NO_HINT": "0", "SMOT_FUSED_ABL": "0",
                   "SMOT_ANY_ORDER": "0",
                   "SMOT_WINO_ABL": "0",
                   "SMOT_TOWER_ABL": "0"}

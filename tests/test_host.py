@@ -91,7 +91,9 @@ def test_argument_errors_are_reported_without_a_device():
     assert rc == -1
     rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null, null)
     assert rc == -1 and b"divisible" in lib.smot_last_error()
-    assert lib.smot_emm_tower_pack_floats(128) == 2 * 128 * 128 * 16 and lib.smot_emm_tower_pack_floats(100) == 0
+    # fp32 image + (C % 32 == 0) the three-part bf16 image: C/32 + 1 rotated blocks of 12288 floats per 16-channel tile
+    assert lib.smot_emm_tower_pack_floats(128) == 2 * 128 * 128 * 16 + 16 * 5 * 12288
+    assert lib.smot_emm_tower_pack_floats(48) == 2 * 48 * 48 * 16 and lib.smot_emm_tower_pack_floats(100) == 0
     assert lib.smot_emm_tower_pack(null, null, 100, null, null) == -1
     assert lib.smot_emm_decode_ws_floats(16, 16) == 2 * 5 * 17 + 2        # 17 band records of 5 words + a ticket
 
