@@ -402,21 +402,34 @@ TIMER_NOTE = ("kernel start/stop events on the launch stream (hipExtLaunchKernel
               "timestamps, the quantity rocprofv3 reports), every %d-th step of the timed region" % TIMER_STRIDE)
 
 
-def tower_roofline(n, total_ms, launches):
-    """The towers against the fp32 matrix pipe.  ``frac`` divides the multiply-adds the kernel EXECUTES (Winograd
-    F(2x2,3x3): 16/36 of the direct convolution's) by the dense fp32 MFMA peak — a fraction of a pipe, <= 1;
-    ``effective_tflops`` is the direct-convolution figure the reference computes, for comparison with other
-    implementations (it can exceed the peak: the algorithm does less work)."""
-    algo = 2.0 * n * 2 * CHANNELS * 256 * 9 * CHANNELS
+def tower_roofline(n, total_ms, launches, ho=16):
+    """The towers against the matrix pipes.  ``frac`` divides the multiply-adds of the Winograd algorithm (F(2x2,3x3): 16/36
+    of the direct convolution's) by the dense fp32 MFMA peak — what an fp32 implementation of the same algorithm could
+    reach at best, <= 1 for the fp32 forms; the three-part bf16 form (``form`` 3) executes six bf16 instructions of K = 32
+    where the fp32 forms execute eight of K = 4 and is bound by the vector instructions that split its operands
+    (DESIGN.md §3), so its own pipe fraction is reported beside it (``bf16_mfma``).  ``effective_tflops`` is the
+    direct-convolution figure the reference computes, for comparison with other implementations."""
+    import siammot_amd.ops as ops
+    algo = 2.0 * n * 2 * CHANNELS * ho * ho * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
     sec = total_ms * 1e-3 / launches
-    return {
-        "bound": "mfma", "kernel": "tower_wino_kernel<0,2> (Winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32)",
+    form = ops.tower_form(n, CHANNELS, ho)
+    out = {
+        "bound": "mfma", "kernel": "tower_wino_kernel (%s)" % ops.TOWER_FORMS.get(form, "?"), "form": form,
         "executed_flops_per_launch": executed, "avg_launch_us": sec * 1e6,
         "achieved": executed / sec / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": executed / sec / 1e12 / 157.3,
         "direct_conv_flops_per_launch": algo, "effective_tflops": algo / sec / 1e12,
         "launches_timed": launches,
     }
+    if form == 3:
+        # per workgroup (two tiles x all 64 output tiles of a track): 8 waves x (C/8 + 3) columns x 24 instructions of
+        # 16 x 16 x 32 multiply-adds (the three partial K blocks of the rotation included)
+        insts = ((n + 7) // 8 * 8) * (2 * CHANNELS // 32) * 8 * (CHANNELS // 8 + 3) * 24
+        flops = insts * 2.0 * 16 * 16 * 32
+        out["bf16_mfma"] = {"executed_flops_per_launch": flops, "achieved": flops / sec / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                            "frac": flops / sec / 1e12 / 2500.0,
+                            "note": "vector-bound: 118 vector instructions per wave and stage beside 24 matrix instructions"}
+    return out
 
 
 PREDICTOR_PARAM_BYTES = 1213980          # SURVEY.md §8(d)-B: (2*128*128*9 + 7*128*9) conv + 2*2*128 GN + 7 biases, x4 B
@@ -831,10 +844,11 @@ def main():
             "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },
-        # the kernel with the largest share of GPU time: the two conv3x3 towers, Winograd F(2x2,3x3) on the fp32
-        # matrix cores.  frac = EXECUTED multiply-adds / dense fp32 MFMA peak (<= 1); effective_tflops = the direct
-        # convolution's FLOPs / time (the figure to compare implementations by).
-        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches),
+        # the kernel with the largest share of GPU time: the two conv3x3 towers, Winograd F(2x2,3x3) on the matrix cores
+        # (tower_roofline: which form ran, its multiply-adds against the fp32 pipe, effective_tflops = the direct
+        # convolution's FLOPs / time, the figure to compare implementations by).  At the 29 x 29 response of the second yaml
+        # family the timer brackets the blocked convolution kernel only (GroupNorm + heads run in a second kernel).
+        "roofline_tower": None if tower_launches == 0 else tower_roofline(n, tower_total_ms, tower_launches, rx - rz + 1),
         # the whole frame pair against HBM: compulsory bytes / ms_per_step.  The path is issue-,
         # matrix-pipe- and latency-bound, so this fraction is small by construction.
         "roofline_path": (lambda pb: {"bound": "hbm", "algorithmic_bytes_per_step": pb,

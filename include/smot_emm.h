@@ -180,6 +180,10 @@ int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const
 /* floats of the packed image: 2*C*C*16 (fp32 image; C % 16 == 0, else 0 = no packed path), plus for C % 32 == 0 the
  * three-part bf16 image, (2*C/16) * (C/32 + 1) * 12288 */
 long long smot_emm_tower_pack_floats(int C);
+/* which form of the packed towers N tracks get (reporting: bench.py, tools/): 0 = none (the direct kernel: C not a power
+ * of two, C % 32 != 0, C > 512 or a response map other than 16 x 16 / 29 x 29), 1 = one 16-channel tile per workgroup
+ * (fp32), 2 = two tiles (fp32), 3 = two tiles, three-part bf16 operands */
+int smot_emm_tower_form(int N, int C, int Ho);
 int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
                         smot_stream_t stream);
 

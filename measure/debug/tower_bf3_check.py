@@ -59,6 +59,8 @@ for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
             lib.smot_debug_trace(ops._ptr(None))
             t = tr.view(grid, 8).cpu().numpy(); t = t[t[:, 5] != 0]
             phases = [round(float(x), 1) for x in np.diff(t[:, :6], axis=1).mean(0)]
+            if str(env.get("SMOT_WINO_ABL")) == "11":
+                phases += [{"in_stage_barriers": round(float(t[:, 6].mean()), 1), "in_vmcnt_waits": round(float(t[:, 7].mean()), 1)}]
         e = (o.double() - r64).abs()
         scale = r64.abs().amax(dim=(0, 2, 3)).clamp_min(1e-30)
         print(json.dumps({"tracks": n, "form": name, "tower_us_min": round(min(ts), 2), "tower_us_median": round(sorted(ts)[2], 2),

@@ -526,6 +526,10 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     {                                                                                            \
         u32x4 AB[OCT][3];                                                                        \
         load_al(Q, AB);                                                                          \
+        WB_QM(Q)                                                                                 \
+    }
+#define WB_QM(Q)                                                                                 \
+    {                                                                                            \
         if (ABL == 7) { _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
             acc[0][Q][t][e] += __uint_as_float(Bp[0][Q][t][e] ^ Bp[BF3 ? 1 : 0][Q][t][e] ^ Bp[BF3 ? 2 : 0][Q][t][e] ^ AB[0][0][e] ^ AB[1][2][e]); } \
         WB_TERM(Q, 2, 0) WB_TERM(Q, 1, 1) WB_TERM(Q, 0, 2) WB_TERM(Q, 1, 0) WB_TERM(Q, 0, 1) WB_TERM(Q, 0, 0) \
@@ -546,9 +550,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         BOP[2][2 * p + 1] = w[4] - w[3];                                                         \
         BOP[3][2 * p + 1] = w[3] - w[5];                                                         \
     }
+    // ABL 11: where a wave's time goes (s_memtime sums of wave 0: slot 6 = in the stage barriers, slot 7 = in the vmcnt waits)
+    long long t_bar = 0, t_vm = 0;
 #define WB_STAGE(J, KB)                                                                          \
     {                                                                                            \
+        const long long tb0 = ABL == 11 ? (long long)__builtin_amdgcn_s_memtime() : 0;           \
         __syncthreads();                                                                         \
+        if (ABL == 11) t_bar += (long long)__builtin_amdgcn_s_memtime() - tb0;                   \
         store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
         load_raw(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);                            \
         W_FENCE                                                                                  \
@@ -556,13 +564,17 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         if (ABL != 9) dma_slot(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0));                        \
         W_FENCE                                                                                  \
         float ba[4][2 * NP], bb[4][2 * NP];                                                      \
+        u32x4 AB[OCT][3];                                                                        \
+        if (ABL == 10) load_al(J, AB);                 /* A parts of the stage's column: early */ \
         WB_XFORM(rd, ba)                               /* k-step 2s */                           \
         W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
         WB_XFORM(rdb, bb)                              /* k-step 2s+1 */                         \
         W_READ(((J) + 1) & 3, 1, rdb)                                                            \
         WB_SPLIT(J, ba, bb)                                                                      \
-        WB_Q(J)                                                                                  \
+        if (ABL == 10) WB_QM(J) else WB_Q(J)                                                     \
+        const long long tv0 = ABL == 11 ? (long long)__builtin_amdgcn_s_memtime() : 0;           \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the A parts fetched in this stage are in LDS */        \
+        if (ABL == 11) t_vm += (long long)__builtin_amdgcn_s_memtime() - tv0;                    \
         W_FENCE                                                                                  \
     }
 #define WB_BLOCK(KB) WB_STAGE(0, KB) WB_STAGE(1, KB) WB_STAGE(2, KB) WB_STAGE(3, KB)
@@ -589,6 +601,10 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             WB_LOOP
         }
         load_hwv();
+        if (ABL == 11 && trace && tid == 0) {
+            trace[(size_t)blockIdx.x * 8 + 6] = t_bar;
+            trace[(size_t)blockIdx.x * 8 + 7] = t_vm;
+        }
     } else if (xi == 1) {        // the xi-row 1 combination adds its two patch rows, the others subtract
         constexpr bool PLUS = true;
         W_LOOP
@@ -602,6 +618,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #undef WB_BLOCK
 #undef WB_XFORM
 #undef WB_Q
+#undef WB_QM
 #undef WB_TERM
 #undef WB_MM
 #undef WB_SPLIT
@@ -765,8 +782,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #undef W_TRACE
 }
 
-int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
-                      float* part, unsigned* zero_words, hipStream_t st) {
+// 16-channel tiles per workgroup of the 16 x 16 towers for N tracks (1 or 2)
+static int tower_tiles_per_workgroup(int N, int C) {
     const int tiles = 2 * (C / 16);
     // One or two 16-channel tiles per workgroup, whichever the dispatch-round arithmetic favours (kernel durations by
     // start/stop events at C = 128, profiles/r04_tower_sweep.jsonl; round 2: r02_tower_forms_by_tracks.jsonl):
@@ -785,6 +802,13 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
                                             : 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
     int oct = (c2 < c1) ? 2 : 1;
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+    return oct;
+}
+
+int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
+                      float* part, unsigned* zero_words, hipStream_t st) {
+    const int tiles = 2 * (C / 16);
+    const int oct = tower_tiles_per_workgroup(N, C);
     const bool bf3 = oct == 2 && knobs().tower_bf3 != 0;
     const size_t smem = (size_t)(bf3 ? W_RING * W_BUF + W_A_FLOATS : w_smem_floats(oct)) * sizeof(float);
     const int grid = ((N + 7) / 8) * 8 * (tiles / oct);
@@ -795,6 +819,8 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
         if (bf3 && knobs().wino_abl == 7) fn = reinterpret_cast<const void*>(&tower_wino_kernel<7, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 8) fn = reinterpret_cast<const void*>(&tower_wino_kernel<8, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 11) fn = reinterpret_cast<const void*>(&tower_wino_kernel<11, 2, 0, true>);
 #endif
         const int rco = ensure_lds_optin(fn, smem, "predictor towers (winograd)");
         if (rco) return rco;
@@ -808,6 +834,8 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
             case 7: WB_LAUNCH(7); break;
             case 8: WB_LAUNCH(8); break;
             case 9: WB_LAUNCH(9); break;
+            case 10: WB_LAUNCH(10); break;
+            case 11: WB_LAUNCH(11); break;
             default: WB_LAUNCH(0); break;
         }
 #else
@@ -877,6 +905,23 @@ int launch_tower_wino_blocks(const float* resp, const float* packed, const Tower
 }
 
 }  // namespace smot
+
+extern "C" int smot_emm_tower_form(int N, int C, int Ho) {
+    using namespace smot;
+    const bool pow2 = C > 0 && (C & (C - 1)) == 0;
+    if (N <= 0 || !pow2 || C % 32 != 0 || C > 512 || (Ho != 16 && Ho != 29)) return 0;     // (predictor.hip: mfma_ok)
+    if (Ho == 29) {        // launch_tower_wino_blocks: four block tracks per track, fp32 form
+        const int tiles = 2 * (C / 16), np8 = ((N + 7) / 8) * 8 * 4;
+        const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
+        const float c1 = (w1 <= 256) ? 20.0f : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
+        const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
+        int oct = (c2 < c1) ? 2 : 1;
+        if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+        return oct;
+    }
+    const int oct = tower_tiles_per_workgroup(N, C);
+    return oct == 1 ? 1 : (knobs().tower_bf3 != 0 ? 3 : 2);
+}
 
 extern "C" long long smot_emm_tower_pack_floats(int C) {
     if (C <= 0 || C % 16 != 0) return 0;          // the packed path needs 16-channel tiles

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "smot_emm_predictor_fwd": (ctypes.c_int, [_vp, _i, _i, _i] + [_vp] * 12 + [_i, _f, _vp, _vp, _vp, _vp]),
     "smot_debug_trace": (None, [_vp]),
     "smot_emm_tower_pack_floats": (ctypes.c_longlong, [_i]),
+    "smot_emm_tower_form": (ctypes.c_int, [_i, _i, _i]),
     "smot_emm_tower_pack": (ctypes.c_int, [_vp, _vp, _i, _vp, _vp]),
     "smot_emm_decode_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _f, _f,
                                            _vp, _vp, _vp, _vp, _vp]),
@@ -714,6 +715,17 @@ TIMER_XCORR, TIMER_TOWER = 0, 1
 #   general_frame        a tracking-loop frame that did not take the one-launch path at all
 import collections as _collections
 FALLBACKS = _collections.Counter()
+
+
+TOWER_FORMS = {0: "direct fp32 (no packed path)", 1: "Winograd, one 16-channel tile per workgroup, fp32 matrix instructions",
+               2: "Winograd, two tiles per workgroup, fp32 matrix instructions",
+               3: "Winograd, two tiles per workgroup, three-part bf16 operands on v_mfma_f32_16x16x32_bf16"}
+
+
+def tower_form(n, channels, ho=16):
+    """Which form of the tower kernel ``n`` tracks get from the current library (``smot_emm_tower_form``): 0..3, see
+    ``TOWER_FORMS``."""
+    return int(load_library().smot_emm_tower_form(int(n), int(channels), int(ho)))
 
 
 def fused_kernel_name():
