@@ -358,11 +358,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     if constexpr (!BF3) load_hwv();          // BF3: after the main loop (nine registers the loop needs)
 
     __syncthreads();                       // zero fill complete before interior writes
+    // BF3: the first A parts are in LDS (the first raw planes are needed here anyway; waiting BEFORE the next fetches are
+    // issued keeps their latency out of this wait)
+    if constexpr (BF3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     store_raw(sm, prs[0]);
     store_raw(sm + W_BUF, prs[1]);
     load_raw(min(2, nstages - 1), prs[0]);
     load_raw(min(3, nstages - 1), prs[1]);
-    if constexpr (BF3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first A parts are in LDS
     __syncthreads();
 
     // rows of the 4x4 patch this wave's xi-row combines:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
