@@ -130,7 +130,7 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
 // cycles of v_mfma_f32_16x16x4_f32: 6 x 16.6 against 256 cycles per 32 channels and tile —
 // profiles/r04_ubench_bf16x3_rate.jsonl).  The transformed operands of a K = 32 block (four stages) are collected as
 // packed bf16 pairs in 96 registers, then one burst of 96 instructions consumes them against A parts fetched as needed.
-// OCT = 2 only, not BLOCKED.
+// OCT = 2 only (also in BLOCKED mode: the same loop over 18 x 18 windows).
 template <int ABL, int OCT, int BHO = 0, bool BF3 = false>
 __global__ void __launch_bounds__(256 * OCT, OCT == 1 ? 2 : 1)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
@@ -598,7 +598,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     WB_Q(2)
     W_TRACE(1)
     if constexpr (BF3) {
-        static_assert(!BF3 || (OCT == 2 && BHO == 0 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
+        static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
         {
             WB_LOOP
         }
@@ -879,21 +879,37 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
     return check_launch("predictor towers (winograd)");
 }
 
+// 16-channel tiles per workgroup of the blocked 29 x 29 convolution for N tracks (1 or 2)
+static int tower_blocks_tiles_per_workgroup(int N, int C) {
+    const int tiles = 2 * (C / 16);
+    const int np8 = ((N + 7) / 8) * 8 * 4;                 // block tracks: tracks padded to the XCD count, four blocks each
+    // same dispatch-round arithmetic as tower_tiles_per_workgroup, on four block tracks per track (the two-tile form on
+    // three-part bf16 operands: 108.7 -> 97.0 us at 30 tracks, measure/debug/tower_blocked_bf3.py: 0.9 of the fp32 rounds)
+    const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
+    const float c1 = (w1 <= 256) ? 20.0f
+                                 : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
+    const float c2 = (knobs().tower_bf3 != 0 ? 0.9f : 1.0f) * (24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f));
+    int oct = (c2 < c1) ? 2 : 1;
+    if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+    return oct;
+}
+
 // Convolution output of the two towers for a 29 x 29 response (blocked mode above): conv [N][2C][841].
 int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
                              float* conv, unsigned* zero_words, hipStream_t st) {
     const int tiles = 2 * (C / 16);
-    const int np8 = ((N + 7) / 8) * 8 * 4;                 // block tracks: tracks padded to the XCD count, four blocks each
-    // same dispatch-round arithmetic as launch_tower_wino, on four block tracks per track
-    const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
-    const float c1 = (w1 <= 256) ? 20.0f
-                                 : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
-    const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
-    int oct = (c2 < c1) ? 2 : 1;
-    if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
+    const int np8 = ((N + 7) / 8) * 8 * 4;
+    const int oct = tower_blocks_tiles_per_workgroup(N, C);
     const size_t smem = (size_t)w_smem_floats(oct) * sizeof(float);
     const int grid = np8 * (tiles / oct);
-    if (oct == 2) {
+    if (oct == 2 && knobs().tower_bf3 != 0) {      // the three-part bf16 form of the main loop (BF3 above)
+        const size_t smem3 = (size_t)(W_RING * W_BUF + W_A_FLOATS) * sizeof(float);
+        const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 29, true>), smem3,
+                                         "predictor towers (winograd, 29x29 in blocks, bf16 x 3)");
+        if (rco) return rco;
+        SMOT_LAUNCH((tower_wino_kernel<0, 2, 29, true>), dim3(grid), dim3(512), smem3, st, resp, packed, P, N, C, cpg, 0.0f, conv,
+                    zero_words, (long long*)nullptr);
+    } else if (oct == 2) {
         const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 29>), smem,
                                          "predictor towers (winograd, 29x29 in blocks)");
         if (rco) return rco;
@@ -912,16 +928,7 @@ extern "C" int smot_emm_tower_form(int N, int C, int Ho) {
     using namespace smot;
     const bool pow2 = C > 0 && (C & (C - 1)) == 0;
     if (N <= 0 || !pow2 || C % 32 != 0 || C > 512 || (Ho != 16 && Ho != 29)) return 0;     // (predictor.hip: mfma_ok)
-    if (Ho == 29) {        // launch_tower_wino_blocks: four block tracks per track, fp32 form
-        const int tiles = 2 * (C / 16), np8 = ((N + 7) / 8) * 8 * 4;
-        const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
-        const float c1 = (w1 <= 256) ? 20.0f : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
-        const float c2 = 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
-        int oct = (c2 < c1) ? 2 : 1;
-        if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
-        return oct;
-    }
-    const int oct = tower_tiles_per_workgroup(N, C);
+    const int oct = Ho == 29 ? tower_blocks_tiles_per_workgroup(N, C) : tower_tiles_per_workgroup(N, C);
     return oct == 1 ? 1 : (knobs().tower_bf3 != 0 ? 3 : 2);
 }
 

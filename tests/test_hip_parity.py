@@ -350,9 +350,19 @@ def test_blocked_winograd_towers_for_the_29x29_response(ops):
         assert err < 5e-5, "n=%d C=%d: blocked Winograd vs direct %.3e" % (n, c, err)
         with ops.debug_library(SMOT_TOWER_OCT=1):
             one = ops.emm_predictor(resp, params)
-        with ops.debug_library(SMOT_TOWER_OCT=2):
+        with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=0):
             two = ops.emm_predictor(resp, params)
-        assert torch.equal(one, two) and torch.equal(blocked, one), "n=%d C=%d" % (n, c)
+        assert torch.equal(one, two), "n=%d C=%d" % (n, c)                # the fp32 forms: bit for bit
+        # the three-part bf16 form of two tiles (round 4): the same accuracy against fp64, the same result on every launch,
+        # and what the product computes when it picks two tiles
+        with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1):
+            runs = [ops.emm_predictor(resp, params) for _ in range(3)]
+        assert all(torch.equal(runs[0], r) for r in runs[1:]), "n=%d C=%d: bf16 x 3 form differs between launches" % (n, c)
+        ref = _predictor_fp64(resp, params)
+        s64 = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+        e32, e3 = (float(((t.double() - ref).abs() / s64).max()) for t in (one, runs[0]))
+        assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: bf16 x 3 error %.3e vs fp32 form %.3e" % (n, c, e3, e32)
+        assert torch.equal(blocked, runs[0]) or torch.equal(blocked, one), "n=%d C=%d" % (n, c)
         with ops.debug_library(SMOT_TOWER_DIRECT=1):
             assert torch.equal(ops.emm_predictor(resp, params), direct)
 

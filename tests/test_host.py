@@ -98,7 +98,7 @@ def test_argument_errors_are_reported_without_a_device():
     # that two tiles on three-part bf16 operands; no packed path for channel counts that are not powers of two
     assert [lib.smot_emm_tower_form(n, 128, 16) for n in (1, 16, 17, 30, 100)] == [1, 1, 3, 3, 3]
     assert lib.smot_emm_tower_form(30, 96, 16) == 0 and lib.smot_emm_tower_form(30, 128, 15) == 0
-    assert lib.smot_emm_tower_form(30, 128, 29) == 2
+    assert lib.smot_emm_tower_form(30, 128, 29) == 3
     assert lib.smot_emm_tower_pack(null, null, 100, null, null) == -1
     assert lib.smot_emm_decode_ws_floats(16, 16) == 2 * 5 * 17 + 2        # 17 band records of 5 words + a ticket
 
