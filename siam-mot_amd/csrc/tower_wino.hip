@@ -774,6 +774,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         W_HEAD16(0) W_HEAD16(1) W_HEAD16(2) W_HEAD16(3) W_HEAD16(4) W_HEAD16(5) W_HEAD16(6) W_HEAD16(7) W_HEAD16(8)
 #undef W_HEAD16
 #undef W_HEAD
+        // (two accumulation chains instead of one were measured: 4.70 k against 4.76 k cycles — not latency-bound)
         float* __restrict__ dst = part + ((size_t)n * tiles + etile) * 4 * 256 + ltid;
         dst[0 * 256] = hacc[0];
         dst[1 * 256] = hacc[1];
