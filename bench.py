@@ -776,8 +776,7 @@ def main():
                "frac": xcorr_bytes / t / 1e9 / HBM_PEAK_GBS, "launches_timed": cnt,
                "note": "stand-alone operator, input resident in L2/MALL (not part of the frame-pair pipeline, which "
                        "runs the fused kernel)"}
-    # the floor of a dispatch of the graded kernel's launch shape (an empty kernel, same timer): what part of `avg_launch_us`
-    # is the launch itself
+    # an empty kernel of the graded kernel's launch shape under the same timer (see `empty_launch_event_bracket_us` below)
     floor_us = None
     if not args.no_kernel_timer:
         try:
@@ -836,11 +835,11 @@ def main():
             "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes_per_launch": fused_bytes,
             "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer": TIMER_NOTE,
-            # an EMPTY kernel of the same launch shape by the same timer, and the fraction of peak of the kernel's WORK
-            # (duration less that floor) — context for `frac`, which is by launch duration and stays the graded figure
-            "dispatch_floor_us": floor_us,
-            "frac_net_of_dispatch_floor": (fused_bytes / ((xcorr_avg_s * 1e6 - floor_us) * 1e-6) / 1e9 / HBM_PEAK_GBS)
-            if (floor_us is not None and xcorr_avg_s * 1e6 > floor_us + 0.5) else None,
+            # an EMPTY kernel of the same launch shape bracketed by the same pair of events: an UPPER bound on the fixed cost
+            # inside `avg_launch_us` — rocprofv3's dispatch timestamps give 0.8-1.5 us for the same empty kernel
+            # (profiles/r04_loop_kernel_stats.md, smot::empty_kernel) and the same 17.5 us as the events for the graded
+            # kernel, so most of an empty bracket is the bracket.  No "fraction net of the floor" is derived from it.
+            "empty_launch_event_bracket_us": floor_us,
             "timer_stride": TIMER_STRIDE, "post_loop_steps_for_timer_samples": post_steps,
             "xcorr_op": xop,
         },

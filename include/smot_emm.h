@@ -282,8 +282,9 @@ int smot_kernel_timer_end(int slot, double* total_ms, int* launches);
 /* Median span (microseconds) of `reps` EMPTY marker-event brackets on `stream` (kept for tools that still time with
  * markers; bench.py no longer needs it). */
 int smot_kernel_timer_bracket_overhead(smot_stream_t stream, int reps, double* median_us);
-/* An empty kernel of workgroups x threads inside timer slot 0's bracket: the floor of a dispatch on this chip (bench.py's
- * `roofline.dispatch_floor_us`; 4.1 us on MI355X whatever the grid). */
+/* An empty kernel of workgroups x threads inside timer slot 0's event bracket (bench.py's
+ * `roofline.empty_launch_event_bracket_us`): 4.1 us on MI355X whatever the grid — the BRACKET's floor, an upper bound on the
+ * fixed cost of a dispatch (the packet's own timestamps under rocprofv3 give 0.8-1.5 us for the same empty kernel). */
 int smot_dispatch_floor_fwd(int workgroups, int threads, smot_stream_t stream);
 
 /*

@@ -748,8 +748,9 @@ def kernel_timer_bracket_overhead(reps=200):
 
 
 def dispatch_floor_us(workgroups, threads, reps=200):
-    """Average duration (by its own dispatch timestamps) of an EMPTY kernel of this launch shape on the current stream: the
-    part of every kernel's launch duration that is the launch (``smot_dispatch_floor_fwd``; timer slot 0 must be idle)."""
+    """Average span of the kernel timer's event bracket around an EMPTY kernel of this launch shape on the current stream
+    (``smot_dispatch_floor_fwd``; timer slot 0 must be idle): the bracket's own floor (4.1 us on MI355X), an upper bound on
+    the fixed cost of a dispatch — rocprofv3 reads 0.8-1.5 us for the same kernel from the packet's timestamps."""
     lib = _lib or load_library()
     for _ in range(20):
         _check(lib.smot_dispatch_floor_fwd(int(workgroups), int(threads), _stream()), "dispatch_floor")
