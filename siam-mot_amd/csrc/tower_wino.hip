@@ -585,6 +585,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     W_READ(0, 1, rdb)                                                                            \
     if (nkb == 4) {        /* C = 128 unrolled: no loop-carried register shuffle (160 moves per trip otherwise) */ \
         WB_BLOCK(0) WB_BLOCK(1) WB_BLOCK(2) WB_BLOCK(3)                                          \
+    } else if ((nkb & 1) == 0) {                     /* C = 64, 256, 512: two blocks per trip (half the shuffle) */ \
+        for (int kb = 0; kb < nkb; kb += 2) { WB_BLOCK(kb) WB_BLOCK(kb + 1) }                    \
     } else {                                                                                     \
         for (int kb = 0; kb < nkb; ++kb) { WB_BLOCK(kb) }                                        \
     }                                                                                            \
