@@ -482,7 +482,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // stage-sized pieces that overlap (the bf16 matrix instructions run beside vector instructions: loop 32.7 k cycles
     // with, 27.6 k without them; all 96 after every fourth stage: 35 k), and the A parts of a column are needed once per
     // four stages.  (Running the column of the PREVIOUS stage first in the second wave of each SIMD, so that the two waves
-    // alternate between matrix and vector work, was measured: 35.9 k against 34.2 k cycles — dropped.)
+    // alternate between matrix and vector work, was measured twice — four loop copies: 35.9 k against 34.2 k cycles; one
+    // copy with a wave-uniform branch: 38.8 k against 33.9 k — and dropped.)
     // The loop is bound by its vector instructions (118 per wave and stage at ~4.3 cycles each on the SIMD's two waves:
     // 28 of the operand transform, 88 of the split = 11 per operand pair, 2 addresses).
     // A parts: the two waves of an xi row need the same 6 KB per column and block; every wave brings HALF of them (those
