@@ -321,6 +321,16 @@ def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
         e3 = float(((runs[0].double() - ref).abs() / scale).max())
         assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: bf16 x 3 error %.3e vs fp32 form %.3e (relative to channel scale)" % (n, c, e3, e32)
         assert e32 < 2e-6
+    # a track with non-finite responses poisons its own outputs only (the bf16 x 3 form multiplies stale operand parts by
+    # zero weights in its last partial K blocks: that must stay inside the workgroup's own track)
+    params = {k: _d(v) for k, v in gi.predictor_params(rs, 128, boxes).items()}
+    resp_np = (rs.standard_normal((30, 128, 16, 16)) * 15.0).astype(np.float32)
+    clean = ops.emm_predictor(_d(resp_np), params)
+    resp_np[3, 17, 4, 5] = np.nan
+    resp_np[11, 90, 0, 0] = np.inf
+    dirty = ops.emm_predictor(_d(resp_np), params)
+    keep = [i for i in range(30) if i not in (3, 11)]
+    assert torch.equal(dirty[keep], clean[keep]) and not bool(torch.isfinite(dirty[3]).all()) and not bool(torch.isfinite(dirty[11]).all())
     # placement independence: ONE track's response replicated — every copy runs on another CU, in another dispatch round,
     # over whatever the workgroup before it left in LDS; all copies must come out bit-identical
     params = {k: _d(v) for k, v in gi.predictor_params(rs, 128, boxes).items()}
