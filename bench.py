@@ -275,13 +275,15 @@ def hipgraph_loop_throughput(emm, feats, det, state, steps):
             "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
 
 
-def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None):
+def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None, ahead=False):
     """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
     the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
     cycle, ONE host sync) -> EMM.extract_cache + track memory.  Fixed track count: the n boxes sit on a
     grid on which neither the detections nor the propagated boxes overlap above the NMS threshold, TRACK_THRESH = 0 and
     START_TRACK_THRESH = 2 after the first frame, so the unchanged solver never suspends or starts a track;
-    ``tracked_in_last_frame`` must equal n (``track_count_held``).  Informational (not part of the metric)."""
+    ``tracked_in_last_frame`` must equal n (``track_count_held``).  Informational (not part of the metric).
+    ``ahead``: every call is also shown the NEXT frame's feature maps (a streaming caller has them): the loop launches the
+    next frame's head speculatively behind this frame's extraction (``TrackingLoop.forward(..., next_features=)``)."""
     from siammot_amd.box_refine import build_refine_tracks
     from siammot_amd.config import get_default_cfg
     from siammot_amd.structures import BoxList
@@ -368,8 +370,13 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
         lean[1] += 1
         return step_native(*a, **k)
     loop._step_lean, loop._step_native = counted, counted_native
+    import siammot_amd.ops as _ops
+    if ahead:
+        step = lambda k: loop(feats[k & 1], dets(k), next_features=feats[(k + 1) & 1])
+    else:
+        step = lambda k: loop(feats[k & 1], dets(k))
     for k in range(1, 30):
-        out = loop(feats[k & 1], dets(k))
+        out = step(k)
     torch.cuda.synchronize()
     # setup, not part of the timed frames: building the loop (random box-head weights on the CPU) left the GPU idle for
     # up to a second and its clocks at rest — single runs came out at 0.15 or 0.25-0.3 ms per frame depending on that
@@ -379,13 +386,14 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     k = 30
     while time.perf_counter() - t_pre < 0.3:
         fresh_scores.append(spare[k & 63].fill_(0.9))
-        out = loop(feats[k & 1], dets(k))
+        out = step(k)
         k += 1
     torch.cuda.synchronize()
     lean[0] = lean[1] = 0
+    _ops.SPECULATION.clear()
     t0 = time.perf_counter()
-    for k in range(steps):
-        out = loop(feats[k & 1], dets(k))
+    for k in range(k & 1, steps + (k & 1)):          # (frame parity continues: the speculative head saw feats[k & 1])
+        out = step(k)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tracked = int((out.get_field("ids") >= 0).sum().item())
@@ -393,6 +401,7 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
             "refine_tracks": "TrackBoxHead (7x7 HIP pooler, 1024-1024 MLP, one-launch post-processing)" if refine else None,
             "one_launch_path_frames": lean[0], "frame_entry_point_frames": lean[1], "frames": steps,
+            "speculative_heads": dict(_ops.SPECULATION) if ahead else None,
             "note": "head + %sone-launch solver (device-resident pool) + track memory; synthetic detections resident on "
                     "the device; one host synchronisation per frame" % ("box-head refinement of the propagated boxes + "
                                                                         if refine else "")}
@@ -712,6 +721,14 @@ def main():
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
         loop_stats = tracking_loop_throughput(n, dev, feats)
         loop_stats["with_refinement"] = tracking_loop_throughput(n, dev, feats, refine=True)
+        # the same loops with every call shown the next frame's features (a streaming caller): the next head is launched a
+        # call early on the guess that the track count holds, the host's record -> launch path runs beside it
+        loop_stats["next_frame_shown"] = {k: v for k, v in tracking_loop_throughput(n, dev, feats, ahead=True).items()
+                                          if k in ("value", "unit", "ms_per_frame", "tracked_in_last_frame", "track_count_held",
+                                                   "frame_entry_point_frames", "frames", "speculative_heads")}
+        loop_stats["next_frame_shown"]["with_refinement"] = {
+            k: v for k, v in tracking_loop_throughput(n, dev, feats, refine=True, ahead=True).items()
+            if k in ("value", "unit", "ms_per_frame", "tracked_in_last_frame", "track_count_held", "speculative_heads")}
     # host cost of a step: the time to ENQUEUE frame pairs (no synchronisation), measured outside the timed region on
     # a burst short enough for the stream's queue; next to the GPU time per step it says how much host headroom a
     # rank has (eight ranks share one host)

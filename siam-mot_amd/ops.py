@@ -715,6 +715,9 @@ TIMER_XCORR, TIMER_TOWER = 0, 1
 #   general_frame        a tracking-loop frame that did not take the one-launch path at all
 import collections as _collections
 FALLBACKS = _collections.Counter()
+# speculative next-frame heads of the tracking loop (TrackingLoop.forward(..., next_features=...)): launched / used as they
+# were / discarded because the row count, the memory, the features or the parameters were not what the launch assumed
+SPECULATION = _collections.Counter()
 
 
 TOWER_FORMS = {0: "direct fp32 (no packed path)", 1: "Winograd, one 16-channel tile per workgroup, fp32 matrix instructions",

@@ -190,7 +190,7 @@ class TrackingLoop(torch.nn.Module):
         # per-frame caches (ctypes blocks, library handles, the trusted-memory marker) are rebuilt on demand: a copy or a
         # pickle of the loop carries none of them
         d = self.__dict__.copy()
-        for k in ("_plan", "_lean_static", "_own_memory"):
+        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head"):
             d.pop(k, None)
         return d
 
@@ -432,14 +432,22 @@ class TrackingLoop(torch.nn.Module):
         self.__dict__["_plan"] = P
         return P
 
-    def _step_native(self, features, detections):
+    def _step_native(self, features, detections, next_features=None):
         """``_step_lean`` through ``smot_track_frame_fwd``: same kernels, same arguments, same single synchronisation, two
         binding calls per frame on an argument block that is packed once per video (``_frame_plan``) and of which only two
         short ranges are rewritten per call.  A frame is a serial chain — host work before the first launch, the GPU chain,
         the record, host bookkeeping — so the FIRST call (stage HEAD) goes out as soon as the head's nine pointers stand,
         and the detections' segment, the output buffers and the remaining stages' call are prepared while the head runs.
         (The first version of this path prepared all 80 fields before ONE call: the first kernel started 20 us later than
-        in the Python-composed form and the frame was slower, 0.165 vs 0.14 ms.)"""
+        in the Python-composed form and the frame was slower, 0.165 vs 0.14 ms.)
+
+        ``next_features`` (optional: the NEXT frame's feature maps, complete on this stream — a streaming caller has them
+        while this frame's solver runs): the next frame's head is enqueued behind this frame's extraction BEFORE the host
+        waits for the record, on the guess that the number of tracks stays what it was; the host's record -> first-launch
+        path (~30 us of Python) then runs while the GPU works on that head instead of leaving it idle.  The next call
+        takes the head's output as it is when the guess held (same memory, same row count, same feature tensors, same
+        parameters) and launches the head again when it did not — the speculative launch only ever wrote its own buffers,
+        so results are the synchronous path's bit for bit either way."""
         dev = detections.bbox.device
         P = self._frame_plan(dev, features)
         a, emm, solver, pool = P.args, P.emm, P.solver, P.pool
@@ -492,7 +500,16 @@ class TrackingLoop(torch.nn.Module):
             hint = OrderHint.lookup(sr0, tb0.bbox, sr0.bbox, P.scales) if "order_hint" in sr0.__dict__ else None
             head_ptrs = (tbb.data_ptr(), srb.data_ptr(), z.data_ptr(), ids_t.data_ptr(), lab_t.data_ptr(),
                          hint.data_ptr() if hint is not None else 0)
-        if head_ptrs is not None:
+        spec = self.__dict__.pop("_spec_head", None)
+        if spec is not None and not (head_ptrs is not None and not repack and spec[0] is mem and spec[1] == n_trk
+                                     and spec[2] is features and spec[3] == blk.a_pp):
+            spec = None                                   # the guess did not hold: the head runs again, below
+            ops.SPECULATION["discarded"] += 1
+        if spec is not None:
+            tf = spec[4]                                  # the head of this frame has been running since the last call
+            need = P.ws_need[n_trk]
+            ops.SPECULATION["used"] += 1
+        elif head_ptrs is not None:
             p_tbb, p_sr, p_z, p_ids, p_lab, p_hint = head_ptrs
             need = P.ws_need.get(n_trk)
             if need is None:
@@ -551,15 +568,35 @@ class TrackingLoop(torch.nn.Module):
                 hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
                 if hook is not None:
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
+        hint_ptr = (fp + 4 * hint_off) if hint_off else 0
+        spec_tf = None
+        if (next_features is not None and n_trk >= 1 and type(mem) is _LazyMemory and detections.__class__ is BoxList
+                and self.__dict__.get("lazy_memory", True) and ops._geometry_refresh(P.g, next_features, dev)):
+            # the next frame's head on this frame's outputs, guessing that n_trk rows stay active (the steady state: the
+            # memory of this frame was the previous frame's active rows, untouched): rows 0 .. n_trk-1 of act_boxes / ids /
+            # labels, of the extraction's search regions and templates, and its order hint
+            need = P.ws_need[n_trk]
+            spec_tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
+            p = spec_tf.data_ptr()
+            addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
+                                templates.data_ptr(), hint_ptr if n_trk >= 2 else 0, ip + 16 * M, ip + 24 * M, p, p + 16 * n_trk),
+                               n_trk, ops.STAGE_HEAD)
+            ops.track_frame_addr(P.lib, addr, dev, stream)
+            ops.SPECULATION["launched"] += 1
         ring.wait(rec_host, event=False)                                           # the frame's one synchronisation
-        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P,
-                                  hint_ptr=(fp + 4 * hint_off) if hint_off else 0)
+        out = self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P, hint_ptr=hint_ptr)
+        if spec_tf is not None:
+            # valid for exactly the memory _finish_frame just built, if it is the lazy one over these buffers with n_trk rows
+            m2 = self.__dict__.get("track_memory")
+            if type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk:
+                self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf)
+        return out
 
     @torch.no_grad()
-    def forward(self, features, detections):
+    def forward(self, features, detections, next_features=None):
         if self._lean_ok(detections):
             if self._native_ok(detections):
-                return self._step_native(features, detections)
+                return self._step_native(features, detections, next_features)
             return self._step_lean(features, detections)
         ops.FALLBACKS["general_frame"] += 1
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38

@@ -151,7 +151,7 @@ SCORE_TOL = 1e-3       # scores in the closed loop.  Single frame pairs agree to
                        # frames (oracle with the reference's library calls vs the explicit restatements)
 
 
-def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, box_probe=None):
+def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, box_probe=None, prefetch=False):
     """Run the loop over the sequence and compare every frame with the golden: ids, labels, pool state and memory
     ids must be IDENTICAL in every frame; boxes >= 1 - 1e-3 IoU, scores within 1e-4.  With ``probe``
     (``probe_tracker``) the raw head output is compared too, and a tracked row that lands one arg-max cell away from
@@ -160,6 +160,8 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
     accumulate in a closed loop; with a random-init box head in it — large regressions off noise features — two CPU
     fp32 implementations of the same head flip a 6e-6 margin after nine frames); that track id is then held to
     IoU >= 0.97 from there on (its template moved by a cell) and reported in ``flips``.
+    ``prefetch``: every call also gets the NEXT frame's feature maps (``TrackingLoop.forward(..., next_features=)``: the
+    next head is launched speculatively behind this frame's extraction) — results must not change.
     Returns a dict of statistics; raises AssertionError (frame, row, stored margins) at the first divergence."""
     n_frames = int(golden["n_frames"]) if frames is None else frames
     pool = loop.solver.track_pool
@@ -167,16 +169,25 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
                  raw_rows=0, raw_max_box_err=0.0, raw_max_score_err=0.0, flips=[])
     tainted = set()
     loop.reset()
+    ahead = None                  # (frame index, device tensors) of the frame prepared one call early (prefetch)
     for t in range(n_frames):
         p = "f%02d_" % t
         feats_np = inp.features(t)
         chk = np.array([float(f.astype(np.float64).sum()) for f in feats_np] +
                        [float(np.abs(f.astype(np.float64)).sum()) for f in feats_np])
         np.testing.assert_allclose(chk, golden[p + "feat_checksum"], rtol=1e-9, err_msg="inputs drifted, frame %d" % t)
-        feats = tuple(torch.from_numpy(f).to(device) for f in feats_np)
+        if ahead is not None and ahead[0] == t:
+            feats = ahead[1]                                                      # the SAME tensors the last call was shown
+        else:
+            feats = tuple(torch.from_numpy(f).to(device) for f in feats_np)
         if probe is not None:
             probe["last"] = None
-        out = loop(feats, detections_boxlist(inp, t, device, getattr(loop, "boxlist_cls", BoxList)))
+        dets_t = detections_boxlist(inp, t, device, getattr(loop, "boxlist_cls", BoxList))
+        if prefetch and t + 1 < n_frames:
+            ahead = (t + 1, tuple(torch.from_numpy(f).to(device) for f in inp.features(t + 1)))
+            out = loop(feats, dets_t, next_features=ahead[1])
+        else:
+            out = loop(feats, dets_t)
         has_trk = (p + "trk_margin") in golden.files
         margin = golden[p + "trk_margin"] if has_trk else np.array([np.inf])
         ctx = "case %s frame %d (min stored arg-max margin of the frame %.2e; flips so far %s)" % (

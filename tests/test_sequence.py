@@ -95,14 +95,23 @@ def _gpu_loop(name, lean):
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("plain", "python"), ("refine", False),
                                        ("refine", True), ("refine", "python"), ("aot", False), ("aot", True),
-                                       ("aot", "python"), ("amodal", False), ("amodal", True), ("amodal", "python")])
+                                       ("aot", "python"), ("amodal", False), ("amodal", True), ("amodal", "python"),
+                                       ("plain", "ahead"), ("refine", "ahead"), ("aot", "ahead"), ("amodal", "ahead")])
 def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     """The real head in the loop, on the device: (i) general path, (ii) one-launch path behind ONE library call
     (smot_track_frame_fwd), ("python") the same sequence composed in Python, (iii) refinement on (all three).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
     may sit one arg-max cell away only where the reference's own margin is below SR.FLIP_MARGIN (reported)."""
     golden = SR.load_golden(name)
+    # "ahead": the frame entry point with the NEXT frame's features shown to every call — the next head is launched
+    # speculatively behind this frame's extraction on the guess that the track count holds; in these sequences tracks
+    # start, suspend and resume all the time, so most guesses are discarded and the head re-runs: nothing may change
+    ahead = lean == "ahead"
+    lean = True if ahead else lean
     inp, emm, loop = _gpu_loop(name, lean)
     taken = {"lean": 0}
+    if ahead:
+        import siammot_amd.ops as ops_a
+        ops_a.SPECULATION.clear()
     if lean:
         which = "_step_lean" if lean == "python" else "_step_native"
         loop.native_frame = lean != "python"            # (the one-call frame is opt-in)
@@ -124,11 +133,16 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
         ops_.FrameArgs.poke_head = counting_poke
     try:
         stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm),
-                          box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
+                          box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None,
+                          prefetch=ahead)
     finally:
         if lean is True:
             ops_.FrameArgs.poke_head = poke
     print("closed loop %s lean=%s: %s hinted frames %d" % (name, lean, stats, hinted["frames"]))
+    if ahead:
+        sp = dict(ops_a.SPECULATION)
+        print("speculative heads:", sp)
+        assert sp.get("used", 0) + sp.get("discarded", 0) <= sp.get("launched", 0)
     if lean:
         assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken
     # (frames whose memory was merged with dormant tracks' rows carry no hint — most frames of these sequences; the steady
@@ -228,7 +242,7 @@ def test_frame_entry_point_hands_the_order_hint_to_the_next_head():
         pr.reg.bias.copy_(torch.tensor([0.5 * mw + dx, 0.5 * mh + dy, 0.5 * mw - dx, 0.5 * mh - dy]))
     loop.solver.track_thresh = 0.0
 
-    def run(hint):
+    def run(hint, ahead=False):
         loop.reset()
         loop.loop_order_hint = hint
         poke, seen, outs = ops_.FrameArgs.poke_head, [], []
@@ -243,13 +257,22 @@ def test_frame_entry_point_hands_the_order_hint_to_the_next_head():
                 d.add_field("ids", torch.full((n,), -1, dtype=torch.int64, device=dev))
                 d.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
                 d.add_field("scores", torch.full((n,), 0.97, device=dev))
-                out = loop(feats[t & 1], d)
+                out = loop(feats[t & 1], d, next_features=feats[(t + 1) & 1]) if ahead else loop(feats[t & 1], d)
                 outs.append((out.bbox.clone(), out.get_field("scores").clone(), out.get_field("ids").clone()))
         finally:
             ops_.FrameArgs.poke_head = poke
         return seen, outs
     seen_h, out_h = run(True)
     seen_0, out_0 = run(False)
+    # the same frames with every call shown the next frame's features (TrackingLoop.forward(..., next_features=)): the
+    # steady state is where the speculative head's guess holds — from the third frame on every head is the one launched
+    # a call early, and nothing changes
+    ops_.SPECULATION.clear()
+    seen_s, out_s = run(True, ahead=True)
+    sp = dict(ops_.SPECULATION)
+    assert sp.get("used", 0) >= 5 and sp.get("discarded", 0) <= 1, sp
+    for (b1, s1, i1), (b2, s2, i2) in zip(out_h, out_s):
+        assert torch.equal(i1, i2) and torch.equal(b1, b2) and torch.equal(s1, s2)
     assert sum(seen_0) == 0
     assert len(seen_h) >= 6 and all(seen_h[2:]), "head launches that carried a hint: %s" % seen_h
     for (b1, s1, i1), (b0, s0, i0) in zip(out_h, out_0):
