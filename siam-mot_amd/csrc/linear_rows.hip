@@ -177,10 +177,10 @@ linear_rows_partial_xpart_kernel(const float* __restrict__ xp, int SX, int nblk_
             v.w = add_rn(v.w, b4.w);
         }
         if (relu_x) {
-            v.x = fmaxf(v.x, 0.0f);
-            v.y = fmaxf(v.y, 0.0f);
-            v.z = fmaxf(v.z, 0.0f);
-            v.w = fmaxf(v.w, 0.0f);
+            v.x = relu_nan(v.x);
+            v.y = relu_nan(v.y);
+            v.z = relu_nan(v.z);
+            v.w = relu_nan(v.w);
         }
         if (!(xr + 16 * q < M)) v = zero4;
         *reinterpret_cast<float4*>(&xs[xr + 16 * q][xk]) = v;
@@ -237,7 +237,7 @@ linear_rows_reduce_kernel(const float* __restrict__ part, int S, int nblk, int r
     }
     const float* __restrict__ bsel = (bias2 != nullptr && n >= N1) ? bias2 + (n - N1) : (bias != nullptr ? bias + n : nullptr);
     if (bsel != nullptr) v = add_rn(v, *bsel);
-    if (relu) v = fmaxf(v, 0.0f);
+    if (relu) v = relu_nan(v);
     y[(size_t)m * ldy + n] = v;
 }
 

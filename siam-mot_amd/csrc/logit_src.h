@@ -39,7 +39,7 @@ struct LogitSrc {
                 if (t0 + t < tpt) s += v[t];
         }
         s += (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
-        return side ? fmaxf(s, 0.0f) : s;
+        return side ? relu_nan(s) : s;
     }
 };
 

@@ -255,7 +255,7 @@ tower_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int cpg,
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 float v = (acc[m][t][r] - mean[m][r]) * rstd * ga + be;
-                v = fmaxf(v, 0.0f);
+                v = relu_nan(v);
                 pl[(4 * wave + t + 1) * 18 + xl + 1] = v;
             }
         }
@@ -312,7 +312,7 @@ heads_combine_kernel(const float* __restrict__ part, const float* __restrict__ c
 #pragma unroll
     for (int t = 0; t < TPT; ++t) s += v[t];
     s += (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
-    if (side) s = fmaxf(s, 0.0f);
+    if (side) s = relu_nan(s);
     logits[((size_t)n * 7 + ch) * 256 + pos] = s;
 }
 
@@ -380,7 +380,7 @@ tower_generic_kernel(const float* __restrict__ resp, TowerParams P, int C, int H
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
         const int ocl = e / HW;
         const float v = (sm[e] - mean) * rstd * gamma[oc0 + ocl] + beta[oc0 + ocl];
-        dst[e] = fmaxf(v, 0.0f);
+        dst[e] = relu_nan(v);
     }
 }
 
@@ -478,7 +478,7 @@ heads_kernel(const float* __restrict__ tower_ws, HeadsParams H, int C, int Ho, f
             for (int o = 0; o < 4; ++o) {
                 if (o < n_out) {
                     float v = acc[p][o] + bias[o];
-                    if (reg_side) v = fmaxf(v, 0.0f);
+                    if (reg_side) v = relu_nan(v);
                     logits[((size_t)n * 7 + out_ch0 + o) * HW + pos] = v;
                 }
             }

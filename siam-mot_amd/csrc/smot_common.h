@@ -73,6 +73,9 @@ __device__ __forceinline__ float sub_rn(float a, float b) { return __fsub_rn(a, 
 __device__ __forceinline__ float div_rn(float a, float b) { return __fdiv_rn(a, b); }
 
 // torch.max / torch.maximum semantics: NaN propagates.
+// ReLU as torch computes it: NaN goes through (fmaxf / v_max_f32 return the OTHER operand for a NaN: a track with a
+// non-finite response would come out as a finite box)
+__device__ __forceinline__ float relu_nan(float v) { return v < 0.0f ? 0.0f : v; }
 __device__ __forceinline__ float max_nan(float a, float b) {
     return (a != a) ? a : ((b != b) ? b : fmaxf(a, b));
 }

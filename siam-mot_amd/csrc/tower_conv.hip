@@ -129,7 +129,7 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
         for (int t = 0; t < G::NTW; ++t)
             if (valid[t]) {
                 const float v = (acc[t][r] - mean[r]) * rstd[r] * ga + be;
-                hp[oc * G::PLANE + (boff[t] - kq * G::PLANE) + G::PW + 1] = fmaxf(v, 0.0f);
+                hp[oc * G::PLANE + (boff[t] - kq * G::PLANE) + G::PW + 1] = relu_nan(v);
             }
     }
     __syncthreads();
@@ -379,7 +379,7 @@ heads_combine_hw_kernel(const float* __restrict__ part, int tpt, int HW, int pla
             if (t0 + t < tpt) s += v[t];
     }
     s += (ch < 2) ? cls_b[ch] : ((ch == 2) ? center_b[0] : reg_b[ch - 3]);
-    if (side) s = fmaxf(s, 0.0f);
+    if (side) s = relu_nan(s);
     logits[((size_t)n * 7 + ch) * HW + pos] = s;
 }
 

@@ -749,7 +749,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float v = (y[t][a][b] - mean) * rstd * ga + be;
-                    pl[(2 * ty + a + 1) * 18 + 2 * tx + b + 1] = fmaxf(v, 0.0f);
+                    pl[(2 * ty + a + 1) * 18 + 2 * tx + b + 1] = relu_nan(v);
                 }
         }
     }

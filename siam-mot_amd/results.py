@@ -210,23 +210,44 @@ class FrameSequenceRunner(object):
         out = self.loop(features, detections)
         return to_original_xywh(out, (orig_w, orig_h))
 
-    def process_frame_sequence(self, frame_iterator):
+    def process_frame_sequence(self, frame_iterator, lookahead=False):
         """``frame_iterator``: what calling a video iterator returns.  Yields ``(frame_id, BoxList)`` like the
-        reference; the track pool is reset first (rcnn.py:37-39)."""
-        self.loop.reset()
-        for frame_id, frame in frame_iterator:
-            yield frame_id, self.process(frame)
+        reference; the track pool is reset first (rcnn.py:37-39).
 
-    def run_video(self, sample_id, video_iterator, fps=None, prefetch_depth=2):
-        """-> ResultSample with one entity per tracked / detected box per frame (do_inference)."""
+        ``lookahead``: the detector runs one frame ahead of the tracker and every tracker call is shown the next frame's
+        feature maps (``TrackingLoop.forward(..., next_features=)``: the next frame's head is enqueued behind this frame's
+        extraction while the host still waits for this frame's record).  Same results frame for frame; each frame's
+        result arrives one detector pass later."""
+        self.loop.reset()
+        if not lookahead:
+            for frame_id, frame in frame_iterator:
+                yield frame_id, self.process(frame)
+            return
+        pending = None                      # (frame_id, (w, h), features, detections) of the frame the tracker takes next
+        for frame_id, frame in frame_iterator:
+            size = (int(frame.shape[1]), int(frame.shape[0]))
+            features, detections = self.detector(self.preprocess(frame))
+            if pending is not None:
+                pid, psize, pf, pd = pending
+                yield pid, to_original_xywh(self.loop(pf, pd, next_features=features), psize)
+            pending = (frame_id, size, features, detections)
+        if pending is not None:
+            pid, psize, pf, pd = pending
+            yield pid, to_original_xywh(self.loop(pf, pd), psize)
+
+    def run_video(self, sample_id, video_iterator, fps=None, prefetch_depth=2, lookahead=False):
+        """-> ResultSample with one entity per tracked / detected box per frame (do_inference).  ``lookahead``: see
+        ``process_frame_sequence``."""
         from .video import prefetch
-        result = None
-        for frame_id, frame in prefetch(video_iterator(), prefetch_depth):
-            if result is None:
-                result = ResultSample(sample_id, int(frame.shape[1]), int(frame.shape[0]), fps)
-                self.loop.reset()
-            boxes = self.process(frame)
+        result = [None]
+
+        def frames():
+            for frame_id, frame in prefetch(video_iterator(), prefetch_depth):
+                if result[0] is None:
+                    result[0] = ResultSample(sample_id, int(frame.shape[1]), int(frame.shape[0]), fps)
+                yield frame_id, frame
+        for frame_id, boxes in self.process_frame_sequence(frames(), lookahead=lookahead):
             t = frame_id / fps if fps else None
             for e in boxlists_to_entities([boxes], frame_id, [t], self.class_table):
-                result.add_entity(e)
-        return result if result is not None else ResultSample(sample_id, None, None, fps)
+                result[0].add_entity(e)
+        return result[0] if result[0] is not None else ResultSample(sample_id, None, None, fps)

@@ -596,7 +596,9 @@ class TrackingLoop(torch.nn.Module):
     def forward(self, features, detections, next_features=None):
         if self._lean_ok(detections):
             if self._native_ok(detections):
-                return self._step_native(features, detections, next_features)
+                if next_features is None:
+                    return self._step_native(features, detections)
+                return self._step_native(features, detections, next_features=next_features)
             return self._step_lean(features, detections)
         ops.FALLBACKS["general_frame"] += 1
         _, tracks, _ = self.track(features, track_memory=self.track_memory)        # roi_heads.py:38

@@ -214,6 +214,12 @@ def test_frame_sequence_runner_over_an_image_folder(tmp_path):
     assert len(again.entities) == len(res.entities)
     ids = [fid for fid, _ in runner.process_frame_sequence(ImageFolderIterator(str(tmp_path), frame_idxs=[0, 2])())]
     assert ids == [0, 2]
+    # the same video with the detector one frame ahead of the tracker (every tracker call is shown the next frame's
+    # features: the next head is launched speculatively): the same entities, field for field
+    ahead = runner.run_video("folder", ImageFolderIterator(str(tmp_path)), fps=30.0, lookahead=True)
+    assert len(ahead.entities) == len(res.entities)
+    for e, w in zip(ahead.entities, res.entities):
+        assert (e.id, e.frame_num, e.bbox, e.confidence, e.labels) == (w.id, w.frame_num, w.bbox, w.confidence, w.labels)
 
 
 # ---- the wire format against the reference's own code (tests/golden/results_wire.json, oracle/gen_golden_results.py) -------
