@@ -33,7 +33,9 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-#define SMOT_ABI_VERSION 9
+/* 10: the image of smot_emm_tower_pack grew (fp32 image + three-part bf16 image: ask smot_emm_tower_pack_floats), an image
+ *     packed by a version-9 library is too short for this one; smot_emm_tower_form added.  (9: order-hint entries of 528 floats) */
+#define SMOT_ABI_VERSION 10
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);

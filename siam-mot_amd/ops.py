@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
