@@ -190,7 +190,7 @@ class TrackingLoop(torch.nn.Module):
         # per-frame caches (ctypes blocks, library handles, the trusted-memory marker) are rebuilt on demand: a copy or a
         # pickle of the loop carries none of them
         d = self.__dict__.copy()
-        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head"):
+        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head", "_prev_n_trk"):
             d.pop(k, None)
         return d
 
@@ -501,7 +501,10 @@ class TrackingLoop(torch.nn.Module):
             head_ptrs = (tbb.data_ptr(), srb.data_ptr(), z.data_ptr(), ids_t.data_ptr(), lab_t.data_ptr(),
                          hint.data_ptr() if hint is not None else 0)
         spec = self.__dict__.pop("_spec_head", None)
+        # (usable only while the memory is the unbuilt lazy one: once somebody has looked at its tensors they may have been
+        # edited in place, and the speculative head read what was there before)
         if spec is not None and not (head_ptrs is not None and not repack and spec[0] is mem and spec[1] == n_trk
+                                     and type(mem) is _LazyMemory and mem._val is None
                                      and spec[2] is features and spec[3] == blk.a_pp):
             spec = None                                   # the guess did not hold: the head runs again, below
             ops.SPECULATION["discarded"] += 1
@@ -570,7 +573,11 @@ class TrackingLoop(torch.nn.Module):
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
         spec_tf = None
-        if (next_features is not None and n_trk >= 1 and type(mem) is _LazyMemory and detections.__class__ is BoxList
+        # (a wrong guess costs the GPU a whole head: the guess is made only while the count has been holding — this frame
+        # had as many tracks as the frame before)
+        steady = self.__dict__.get("_prev_n_trk") == n_trk
+        self.__dict__["_prev_n_trk"] = n_trk
+        if (next_features is not None and steady and n_trk >= 1 and type(mem) is _LazyMemory and detections.__class__ is BoxList
                 and self.__dict__.get("lazy_memory", True) and ops._geometry_refresh(P.g, next_features, dev)):
             # the next frame's head on this frame's outputs, guessing that n_trk rows stay active (the steady state: the
             # memory of this frame was the previous frame's active rows, untouched): rows 0 .. n_trk-1 of act_boxes / ids /
@@ -590,6 +597,8 @@ class TrackingLoop(torch.nn.Module):
             m2 = self.__dict__.get("track_memory")
             if type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk:
                 self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf)
+            else:
+                ops.SPECULATION["discarded"] += 1        # the row count changed, or dormant rows joined the memory
         return out
 
     @torch.no_grad()

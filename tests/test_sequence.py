@@ -142,7 +142,7 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     if ahead:
         sp = dict(ops_a.SPECULATION)
         print("speculative heads:", sp)
-        assert sp.get("used", 0) + sp.get("discarded", 0) <= sp.get("launched", 0)
+        assert sp.get("used", 0) + sp.get("discarded", 0) == sp.get("launched", 0)
     if lean:
         assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken
     # (frames whose memory was merged with dormant tracks' rows carry no hint — most frames of these sequences; the steady

@@ -548,3 +548,55 @@ def test_lean_step_equals_general_path(native):
                 assert tid in ca and torch.equal(ca[tid][0], cb[tid][0]) and torch.equal(ca[tid][1].bbox, cb[tid][1].bbox)
         seen_dormant |= bool(pa.get_dormant_ids())
     assert len(lean_frames) == 16 and seen_dormant and loops[0].solver.track_pool._kill_ids
+
+
+@pytest.mark.gpu
+def test_next_frame_shown_equals_the_synchronous_loop_on_random_traffic():
+    """``TrackingLoop.forward(..., next_features=)`` launches the next frame's head a call early, guessing that the track
+    count holds.  Against a second loop that is never shown the next frame, on 60 frames of random traffic (detections
+    drop out, false positives start tracks, tracks go dormant, resume and expire — the guess fails often): outputs
+    identical in every frame, memory and pool identical whenever they are compared (every fifth frame: looking at the
+    memory builds it, which makes the loop discard that frame's speculative head — exercised on purpose), and both
+    outcomes of the guess occur."""
+    import golden_inputs as gi
+    import siammot_amd.ops as ops_
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    # (speculation needs a memory that is the extraction's own output: frames without dormant tracks.  A low track
+    # threshold and one dormant frame keep such frames common while tracks still start, get lost, come back and expire)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 1
+    cfg.MODEL.TRACK_HEAD.TRACK_THRESH = float(__import__("os").environ.get("SMOT_TEST_TT", "0.35"))
+    cfg.MODEL.TRACK_HEAD.RESUME_TRACK_THRESH = 0.5
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    with torch.no_grad():
+        for name in ("cls", "center", "reg"):
+            getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
+    loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+    for lp in loops:
+        lp.native_frame = True
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(9)
+    frames = 60
+    feats = [tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes) for _ in range(6)]
+    rs = [np.random.RandomState(5), np.random.RandomState(5)]
+    ops_.SPECULATION.clear()
+    for f in range(frames):
+        fa, fb = feats[f % 6], feats[(f + 1) % 6]
+        a = loops[0](fa, detections(rs[0], f % 40).to(dev), next_features=fb if f + 1 < frames else None)
+        b = loops[1](fa, detections(rs[1], f % 40).to(dev))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")), "frame %d" % f
+        pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids and pa._max_id == pb._max_id
+        if f % 5 == 4:
+            ma, mb = loops[0].track_memory, loops[1].track_memory
+            assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox) and torch.equal(ma[2][0].bbox, mb[2][0].bbox)
+            assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids"))
+    sp = dict(ops_.SPECULATION)
+    print("speculative heads on random traffic:", sp)
+    assert sp.get("launched", 0) >= 4 and sp.get("used", 0) >= 1 and sp.get("discarded", 0) >= 1, sp
+    assert sp.get("used", 0) + sp.get("discarded", 0) == sp["launched"]
+
