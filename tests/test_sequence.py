@@ -63,8 +63,11 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
     # seconds per frame at 30-40 rows; the device test runs every frame)
     frames = 10 if name == "amodal" else None
     with torch.no_grad():
+        # ("plain" is replayed with every call shown the next frame's features: on the general path — no device, no
+        # one-launch frame — the argument is accepted and changes nothing)
         stats = SR.replay(loop, inp, golden, "cpu", probe=SR.probe_tracker(emm), frames=frames,
-                          box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None)
+                          box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None,
+                          prefetch=(name == "plain"))
     assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
     floor = {"plain": 300, "refine": 300, "aot": 60, "amodal": 100}[name]
     assert stats["tracked_rows"] > floor and stats["raw_rows"] > floor, stats
