@@ -399,7 +399,7 @@ int smot_box_refine_post_fwd(const float* head_out, int ld, int num_classes, int
  *   the roi itself, no padding); pooled = POOLER_RESOLUTION (7; 15 and 30 also run), sampling_ratio 2;
  *   fc6_w [dim6, C*pooled^2], fc7_w [dim7, dim6], cls_w [num_classes, dim7], reg_w [4*reg_classes, dim7] (+ biases) as
  *   the state_dict holds them; the remaining arguments as smot_box_refine_post_fwd.
- *   ws: device fp32 [smot_box_refine_ws_floats(...)], 16-byte aligned.   N <= 64.
+ *   ws: device fp32 [smot_box_refine_ws_floats(...)], 16-byte aligned.   N <= 128.
  * SMOT_ERR_UNSUPPORTED: another pooler shape or layer widths that are not multiples of 4 (use the stage-wise entries).
  */
 long long smot_box_refine_ws_floats(int N, int C, int pooled, int dim6, int dim7, int num_classes, int reg_classes);

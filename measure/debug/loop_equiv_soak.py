@@ -43,7 +43,7 @@ rs_f = np.random.RandomState(9)
 rs = [np.random.RandomState(5) for _ in loops]
 taken = [0, 0]
 n0, n1 = loops[0]._step_native, loops[1]._step_lean
-loops[0]._step_native = lambda f, d: (taken.__setitem__(0, taken[0] + 1), n0(f, d))[1]
+loops[0]._step_native = lambda f, d, next_features=None: (taken.__setitem__(0, taken[0] + 1), n0(f, d, next_features=next_features))[1]
 loops[1]._step_lean = lambda f, d: (taken.__setitem__(1, taken[1] + 1), n1(f, d))[1]
 dormant_frames = kills = 0
 switch = os.environ.get("SWITCH") is not None      # loop 0 changes its path at random from frame to frame
@@ -57,8 +57,15 @@ for f in range(frames):
         loops[0].native_frame = mode == 0
         loops[0]._lean_ok = lean_ok0 if mode < 2 else (lambda d: False)
         loops[0].solver._device_path = dev_path0 if mode < 3 else (lambda *a, **k: False)
-    feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
-    outs = [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops, rs)]
+    if f == 0:
+        feats_next = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+    feats = feats_next
+    feats_next = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+    if os.environ.get("AHEAD") is not None:      # loop 0 is shown the next frame's features (speculative next-frame head)
+        outs = [loops[0](feats, detections(rs[0], f % 40).to(dev), next_features=feats_next)] + \
+               [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops[1:], rs[1:])]
+    else:
+        outs = [lp(feats, detections(r, f % 40).to(dev)) for lp, r in zip(loops, rs)]
     for k in range(1, len(loops)):
         a, b = outs[0], outs[k]
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), (f, k)
@@ -95,5 +102,7 @@ for f in range(frames):
     dormant_frames += bool(loops[0].solver.track_pool.get_dormant_ids())
 if switch:
     print("path switching: frames per mode (entry point, composed, general+device solver, general+host solver):", modes)
+import siammot_amd.ops as _ops
+print("speculative heads:", dict(_ops.SPECULATION))
 print("frames %d: identical on all three paths; native frames %d, lean frames %d, frames with dormant tracks %d, ids started %d, killed %d"
       % (frames, taken[0], taken[1], dormant_frames, loops[0].solver.track_pool._max_id + 1, len(loops[0].solver.track_pool._kill_ids)))

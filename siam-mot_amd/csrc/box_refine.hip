@@ -44,7 +44,7 @@ struct BoxRefineArgs {
     const float* cls_b;      // [K] or nullptr
     const float* reg_b;      // [4*KR] or nullptr
 };
-constexpr int BR_PART_ROWS = 64, BR_PART_COLS = 64;
+constexpr int BR_PART_ROWS = 128, BR_PART_COLS = 64;
 
 template <bool PART>
 __global__ void __launch_bounds__(BR_MAXN) box_refine_post_kernel(BoxRefineArgs A, int N) {
@@ -206,7 +206,7 @@ static inline size_t br_align4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 extern "C" long long smot_box_refine_ws_floats(int N, int C, int pooled, int dim6, int dim7, int num_classes,
                                                int reg_classes) {
-    if (N <= 0 || N > 64) return 0;
+    if (N <= 0 || N > 128) return 0;
     const int K0 = C * pooled * pooled, NH = num_classes + 4 * reg_classes;
     long long g = smot_linear_rows_ws_floats(N, K0, dim6);
     const long long g7 = smot_linear_rows_ws_floats(N, dim6, dim7), gh = smot_linear_rows_ws_floats(N, dim7, num_classes + 4 * reg_classes);
@@ -226,7 +226,7 @@ extern "C" int smot_box_refine_fwd(const float* const* feats, const int* heights
                                    float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
                                    smot_stream_t stream) {
     using namespace smot;
-    SMOT_REQUIRE(N >= 0 && N <= 64, "box_refine: N=%d not in [0,64] (use the stage-wise entries)", N);
+    SMOT_REQUIRE(N >= 0 && N <= 128, "box_refine: N=%d not in [0,128] (use the stage-wise entries)", N);
     const int K0 = C * pooled * pooled;
     if (!((pooled == 7 || pooled == 15 || pooled == 30) && sampling_ratio == 2 && (K0 & 3) == 0 && (dim6 & 3) == 0 &&
           (dim7 & 3) == 0)) {

@@ -15,7 +15,8 @@
 //     shuffles);
 //   * the partial sums of the K slices are written out and a second, tiny launch adds them in slice order (+ bias,
 //     ReLU): deterministic, and the kernel boundary is the cross-XCD visibility point (no atomics).
-// Rows: up to 64 (1..4 row tiles of 16); K must be a multiple of 4 (the wrapper falls back to the library otherwise).
+// Rows: up to 128 (1..8 row tiles of 16; round 4: 64 -> 128, so that 100 propagated tracks — BASELINE.json configs[2] —
+// stay on this path instead of the library GEMM); K must be a multiple of 4 (the wrapper falls back to the library otherwise).
 #include "smot_common.h"
 #include "tower_common.h"
 
@@ -34,7 +35,7 @@ linear_rows_partial_kernel(const float* __restrict__ x, int M, int K, const floa
     // A workgroup lives for a few microseconds, so its loads must not be a chain of round trips: the slice is walked
     // in "quads" of QS steps and ALL loads of a quad — QS x 4 float4 of weights per lane, the x chunks of its steps —
     // are issued before the first use (one HBM latency per quad; the usual slice is one quad).
-    constexpr int QS = MT <= 2 ? 4 : 2;          // steps per quad (LDS: QS x MT*16 x 68 floats)
+    constexpr int QS = MT <= 2 ? 4 : (MT <= 4 ? 2 : 1);       // steps per quad (LDS: QS x MT*16 x 68 floats <= 35 KB)
     __shared__ __attribute__((aligned(16))) float xs[QS][MT * 16][LR_XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = blockIdx.x, s = blockIdx.y;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256)
 linear_rows_partial_xpart_kernel(const float* __restrict__ xp, int SX, int nblk_x, const float* __restrict__ bx, int relu_x,
                                  int M, int K, const float* __restrict__ W, int N, const float* __restrict__ W2, int N1,
                                  float* __restrict__ part) {
-    constexpr int SMAX = 16;                       // slices of the previous layer summed per load batch
+    constexpr int SMAX = MT <= 4 ? 16 : 4;         // slices of the previous layer summed per load batch (registers: MT x SMAX float4)
     __shared__ __attribute__((aligned(16))) float xs[MT * 16][LR_XS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nb = blockIdx.x, s = blockIdx.y;
@@ -270,7 +271,11 @@ int launch_linear_rows2(const float* x, int M, int K, const float* W, const floa
         case 1: hipLaunchKernelGGL(linear_rows_partial_kernel<1>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
         case 2: hipLaunchKernelGGL(linear_rows_partial_kernel<2>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
         case 3: hipLaunchKernelGGL(linear_rows_partial_kernel<3>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
-        default: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 4: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 5: hipLaunchKernelGGL(linear_rows_partial_kernel<5>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 6: hipLaunchKernelGGL(linear_rows_partial_kernel<6>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        case 7: hipLaunchKernelGGL(linear_rows_partial_kernel<7>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_kernel<8>, grid, dim3(256), 0, st, x, M, K, W, N, W2, N1, P.kslice, ws); break;
     }
     // y == nullptr: the consumer adds the K slices itself while it loads (linear_rows_layout tells it where they are;
     // box_refine_post_kernel does for cls_score | bbox_pred: one launch fewer on a chain of 3-4 us kernels)
@@ -296,13 +301,21 @@ int launch_linear_rows_chain(const float* x, int M, int K, const float* WA, cons
         case 1: hipLaunchKernelGGL(linear_rows_partial_kernel<1>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
         case 2: hipLaunchKernelGGL(linear_rows_partial_kernel<2>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
         case 3: hipLaunchKernelGGL(linear_rows_partial_kernel<3>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
-        default: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 4: hipLaunchKernelGGL(linear_rows_partial_kernel<4>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 5: hipLaunchKernelGGL(linear_rows_partial_kernel<5>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 6: hipLaunchKernelGGL(linear_rows_partial_kernel<6>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        case 7: hipLaunchKernelGGL(linear_rows_partial_kernel<7>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_kernel<8>, ga, dim3(256), 0, st, x, M, K, WA, NA, (const float*)nullptr, NA, PA.kslice, ws_a); break;
     }
     switch (PA.mt) {
         case 1: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<1>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
         case 2: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<2>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
         case 3: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<3>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
-        default: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<4>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 4: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<4>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 5: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<5>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 6: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<6>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        case 7: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<7>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
+        default: hipLaunchKernelGGL(linear_rows_partial_xpart_kernel<8>, gb, dim3(256), 0, st, (const float*)ws_a, PA.S, PA.nblk, bA, reluA, M, NA, WB, NB, WB2, N1, ws_b); break;
     }
     *rc = check_launch("linear_rows_chain");
     return 1;
@@ -324,17 +337,17 @@ int launch_linear_rows(const float* x, int M, int K, const float* W, const float
 
 }  // namespace smot
 
-extern "C" int smot_linear_rows_max_rows(void) { return 64; }
+extern "C" int smot_linear_rows_max_rows(void) { return 128; }
 
 extern "C" long long smot_linear_rows_ws_floats(int M, int K, int N) {
-    if (M <= 0 || M > 64 || K <= 0 || N <= 0) return 0;
+    if (M <= 0 || M > 128 || K <= 0 || N <= 0) return 0;
     return (long long)smot::linear_rows_plan(M, K, N).part_floats;
 }
 
 extern "C" int smot_linear_rows_fwd(const float* x, int M, int K, const float* W, const float* bias, int N, int relu,
                                     float* ws, float* y, int ldy, smot_stream_t stream) {
     using namespace smot;
-    SMOT_REQUIRE(M >= 0 && M <= 64 && K > 0 && N > 0 && ldy >= N, "linear_rows: bad sizes M=%d K=%d N=%d ldy=%d", M, K, N, ldy);
+    SMOT_REQUIRE(M >= 0 && M <= 128 && K > 0 && N > 0 && ldy >= N, "linear_rows: bad sizes M=%d K=%d N=%d ldy=%d", M, K, N, ldy);
     if ((K & 3) != 0) {
         set_error("linear_rows: K=%d is not a multiple of 4 (use the library GEMM)", K);
         return SMOT_ERR_UNSUPPORTED;

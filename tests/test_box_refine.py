@@ -141,7 +141,7 @@ def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(trac
     feats = [torch.from_numpy(f).to(dev) for f in inp["features"]]
     refine = RefineTracks(head, tracktor=tracktor)
     assert refine.raw_ok(7)
-    if not one_call:          # the stage-wise form (more than 64 rows, other layer widths): library GEMMs + post kernel
+    if not one_call:          # the stage-wise form (more than 128 rows, other layer widths): library GEMMs + post kernel
         import siammot_amd.ops as ops_
         monkeypatch.setattr(ops_, "linear_rows_max_rows", lambda: 0)
     args = [torch.from_numpy(inp[k].copy()).to(dev) for k in ("track_boxes", "track_scores", "track_ids", "track_labels")]
@@ -167,11 +167,13 @@ def test_refine_raw_one_launch_post_processing_matches_the_reference_golden(trac
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,K,N,relu", [(30, 6272, 1024, True), (30, 1024, 1024, True), (7, 1024, 10, False),
-                                        (64, 6272, 64, False), (1, 64, 3, True), (33, 100, 130, False), (16, 36, 2, False)])
+                                        (64, 6272, 64, False), (1, 64, 3, True), (33, 100, 130, False), (16, 36, 2, False),
+                                        (100, 6272, 1024, True), (128, 1024, 1024, True), (65, 1024, 10, False), (97, 200, 70, True)])
 def test_linear_rows_matches_the_library_gemm(M, K, N, relu):
     """``smot_linear_rows_fwd`` (split-K weight streaming on the fp32 matrix cores + slice-ordered reduction) against a
     float64 reference: the box head's layers at the sizes of DLA_34_FPN_EMM.yaml (fc6 6272 -> 1024, fc7, predictor) and
-    edge shapes (one row, 64 rows, K not a multiple of the step, N below a tile, a column-block output)."""
+    edge shapes (one row, 64 rows, more than 64 rows — five to eight row tiles, the 100 tracks of BASELINE.json configs[2]
+    and the 128-row capacity —, K not a multiple of the step, N below a tile, a column-block output)."""
     import siammot_amd.ops as ops
     g = torch.Generator().manual_seed(M * 1000 + N)
     x = torch.randn((M, K), generator=g).cuda()
@@ -195,7 +197,8 @@ def test_linear_rows_matches_the_library_gemm(M, K, N, relu):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,dim6,dim7,classes", [(30, 1024, 1024, 2), (64, 1024, 1024, 2), (1, 1024, 1024, 2), (17, 128, 64, 3),
-                                                 (30, 96, 100, 2), (9, 256, 1024, 14), (30, 64, 128, 16)])
+                                                 (30, 96, 100, 2), (9, 256, 1024, 14), (30, 64, 128, 16),
+                                                 (100, 1024, 1024, 2), (128, 1024, 1024, 2), (71, 128, 64, 3)])
 def test_one_call_refinement_equals_the_stage_wise_composition_bitwise(n, dim6, dim7, classes):
     """``smot_box_refine_fwd`` skips two reduction launches where the layer shapes allow (the head's launch adds fc7's K
     slices while it loads, the post-processing kernel adds the head's): the slices are added in the order and with the
