@@ -143,7 +143,9 @@ int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, 
  *   (z = templates [N,C,rz,rz]); resp [N,C,Ho,Ho].  x_debug: NULL, or a [N,C,rx,rx] buffer that
  *   receives the pooled planes (tests).  Responses are bit-identical to smot_xcorr_dw_fwd applied to the
  *   pooled planes; the pooling itself is separable (fp32-rounding-level differences to ROIAlign).
- * SMOT_ERR_UNSUPPORTED unless rx == 30, rz == 15, sampling_ratio == 2 (use the two unfused calls).
+ *   rx == 35, rz == 7 (the second yaml family; x_debug must be NULL): the generic ROIAlign kernel's gathers and the
+ *   row-patch correlation in one kernel — bit-identical to smot_roi_align_levels_fwd + smot_xcorr_dw_fwd.
+ * SMOT_ERR_UNSUPPORTED for other shapes or sampling_ratio != 2 (use the two unfused calls).
  */
 int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
                             const int* pad_cells, const float* scales, int num_levels, int C,

@@ -28,6 +28,9 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
                         hipStream_t st);
+int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
+                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
+                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st);
 }  // namespace smot
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
@@ -64,6 +67,11 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
         // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
         rc = sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
                                  nullptr, order_hint, (hipStream_t)stream);
+        if (rc) return rc;
+    } else if (rx == 35 && rz == 7 && sampling_ratio == 2 && !no_fuse) {
+        // the second yaml family's shape: gathers + correlation in one kernel (sr_xcorr_small.hip), same arithmetic
+        rc = sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
+                                  sampling_ratio, resp, (hipStream_t)stream);
         if (rc) return rc;
     } else {
         rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,

@@ -809,7 +809,34 @@ def test_fused_sr_pool_xcorr(ops, golden_dir):
     _assert_close(p, pr, 1e-5, 1e-5, "fused pooling, wide window")
     assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
     with pytest.raises(RuntimeError, match="only Rx=30"):
-        ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 35, 7, cfg.scales, 2, 512)
+        ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 20, 5, cfg.scales, 2, 512)
+
+
+@pytest.mark.parametrize("n,c", [(1, 4), (7, 30), (30, 128), (3, 2)])
+def test_fused_gather_kernel_of_the_second_yaml_family_equals_the_two_kernel_form_bitwise(ops, n, c):
+    """Round 4: search-region pooling + correlation of the 35 / 7 shape in ONE kernel
+    (sr_xcorr_small.hip) — the generic ROIAlign kernel's and the row-patch correlation's arithmetic operation for
+    operation, so the responses must equal ``roi_align_levels`` + ``xcorr_depthwise`` bit for bit: random boxes of all
+    sizes (windows inside, across and outside the map's border — pad 256, search regions x5), channel counts that are
+    not multiples of the workgroup's four, a box whose search region lies in the virtual border entirely."""
+    rs = np.random.RandomState(350 + n)
+    g = torch.Generator().manual_seed(n)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    feats = tuple(torch.randn((1, c, 704 // s_, 1280 // s_), generator=g).to(DEV) for s_ in (4, 8, 16, 32))
+    wh = np.exp(rs.uniform(np.log(12), np.log(400), (n, 1))) * np.array([[1.0, 1.6]])
+    xy = rs.uniform(-0.1, 1.0, (n, 2)) * np.array([1280.0, 704.0])
+    boxes_np = np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    if n >= 3:
+        boxes_np[2] = [-3000.0, -3000.0, -2990.0, -2980.0]
+    boxes = _d(boxes_np)
+    sr = ops.search_region(boxes, 256, 2.0, 0)
+    z = _d(rs.standard_normal((n, c, 7, 7)).astype(np.float32))
+    x = ops.roi_align_levels(feats, sr, boxes, 35, scales, 2, [64, 32, 16, 8])
+    want = ops.xcorr_depthwise(x, z)
+    got = ops.sr_xcorr_fused(feats, boxes, sr, z, 35, 7, scales, 2, 256)
+    assert got.shape == (n, c, 29, 29) and torch.equal(got, want), "max diff %g" % float((got - want).abs().max())
+    if n >= 3:
+        assert float(got[2].abs().max()) == 0.0
 
 
 def test_generic_roi_kernel_still_matches(ops, golden_dir, monkeypatch):
