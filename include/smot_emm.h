@@ -143,15 +143,24 @@ int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, 
  *   (z = templates [N,C,rz,rz]); resp [N,C,Ho,Ho].  x_debug: NULL, or a [N,C,rx,rx] buffer that
  *   receives the pooled planes (tests).  Responses are bit-identical to smot_xcorr_dw_fwd applied to the
  *   pooled planes; the pooling itself is separable (fp32-rounding-level differences to ROIAlign).
- *   rx == 35, rz == 7 (the second yaml family; x_debug must be NULL): the generic ROIAlign kernel's gathers and the
- *   row-patch correlation in one kernel — bit-identical to smot_roi_align_levels_fwd + smot_xcorr_dw_fwd.
- * SMOT_ERR_UNSUPPORTED for other shapes or sampling_ratio != 2 (use the two unfused calls).
+ * SMOT_ERR_UNSUPPORTED unless rx == 30, rz == 15, sampling_ratio == 2 (35 / 7: smot_sr_xcorr_gather_fwd; otherwise the two
+ * unfused calls).
  */
 int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* heights, const int* widths,
                             const int* pad_cells, const float* scales, int num_levels, int C,
                             const float* boxes, const float* sr, const float* templates, int N,
                             int rx, int rz, int sampling_ratio,
                             float* resp, float* x_debug, smot_stream_t stream);
+
+/*
+ * The same for the reference's second yaml family (DLA_34_FPN_EMM_AOT.yaml: rx == 35, rz == 7, sampling_ratio == 2): the
+ * generic ROIAlign kernel's gathers and the row-patch correlation in one kernel — responses bit-identical to
+ * smot_roi_align_levels_fwd + smot_xcorr_dw_fwd; the [N,C,35,35] tensor stays on chip.  SMOT_ERR_UNSUPPORTED otherwise.
+ */
+int smot_sr_xcorr_gather_fwd(const float* const* feats, const int* heights, const int* widths,
+                             const int* pad_cells, const float* scales, int num_levels, int C,
+                             const float* boxes, const float* sr, const float* templates, int N, int rx, int rz,
+                             int sampling_ratio, float* resp, smot_stream_t stream);
 
 /*
  * EMM prediction tower + heads.

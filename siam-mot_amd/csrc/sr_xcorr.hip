@@ -953,12 +953,6 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
 }
 }  // namespace smot
 
-namespace smot {
-int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
-                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
-                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st);
-}
-
 #ifdef SMOT_DEBUG
 // measurement library only: the stand-alone pooling + correlation launch WITH an order hint (phase traces / A/B runs of
 // the kernel alone; the product passes hints through smot_emm_track_fwd)
@@ -984,15 +978,9 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
                                        smot_stream_t stream) {
     using namespace smot;
     SMOT_REQUIRE(N >= 0 && C > 0, "sr_xcorr_fused: bad sizes N=%d C=%d", N, C);
-    if (rx == 35 && rz == 7 && sampling_ratio == 2 && x_debug == nullptr) {      // the second yaml family: sr_xcorr_small.hip
-        if (N == 0) return SMOT_OK;
-        SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_fused: null pointer");
-        return sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
-                                    sampling_ratio, resp, (hipStream_t)stream);
-    }
     if (!(rx == 30 && rz == 15 && sampling_ratio == 2)) {
-        set_error("sr_xcorr_fused: only Rx=30 / Rz=15 and Rx=35 / Rz=7 (without the pooled planes) at sampling_ratio=2 are fused "
-                  "(got %d, %d, %d); use smot_roi_align_levels_fwd + smot_xcorr_dw_fwd", rx, rz, sampling_ratio);
+        set_error("sr_xcorr_fused: only Rx=30, Rz=15, sampling_ratio=2 is fused (got %d, %d, %d); use "
+                  "smot_roi_align_levels_fwd + smot_xcorr_dw_fwd", rx, rz, sampling_ratio);
         return SMOT_ERR_UNSUPPORTED;
     }
     if (N == 0) return SMOT_OK;

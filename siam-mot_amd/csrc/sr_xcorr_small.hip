@@ -134,10 +134,12 @@ sr_xcorr_gather_kernel(LevelParams P, int C, const float* __restrict__ rois, con
     // instead of the next plane or, behind the last channel, unmapped memory
     auto plane_rsrc = [&](int c) __attribute__((always_inline)) {
         const unsigned long long fa = reinterpret_cast<unsigned long long>(f + (size_t)c * H * W);
-        return __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>(((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(fa >> 32)) << 32) |
-                                    __builtin_amdgcn_readfirstlane((unsigned)fa)),
-            0, (int)((unsigned)(H * W) * 4u), 0x00020000);
+        // (readfirstlane returns a signed int: through `unsigned`, or a low word with bit 31 set sign-extends into the
+        // high word and the resource points into unmapped space)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fa);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(fa >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 (int)((unsigned)(H * W) * 4u), 0x00020000);
     };
     typedef int v2i_t __attribute__((ext_vector_type(2)));
     for (int t0 = 0; t0 < RX * RX; t0 += 256) {
@@ -273,3 +275,21 @@ int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const in
 }
 
 }  // namespace smot
+
+// The C entry of the 35 / 7 shape (smot_sr_xcorr_fused_fwd covers 30 / 15): arguments as there, no pooled-plane output.
+extern "C" int smot_sr_xcorr_gather_fwd(const float* const* feats, const int* heights, const int* widths,
+                                        const int* pad_cells, const float* scales, int num_levels, int C,
+                                        const float* boxes, const float* sr, const float* templates, int N, int rx, int rz,
+                                        int sampling_ratio, float* resp, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(N >= 0 && C > 0, "sr_xcorr_gather: bad sizes N=%d C=%d", N, C);
+    if (!(rx == 35 && rz == 7 && sampling_ratio == 2)) {
+        set_error("sr_xcorr_gather: only Rx=35, Rz=7, sampling_ratio=2 (got %d, %d, %d); use smot_sr_xcorr_fused_fwd (30 / 15) or "
+                  "smot_roi_align_levels_fwd + smot_xcorr_dw_fwd", rx, rz, sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    if (N == 0) return SMOT_OK;
+    SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_gather: null pointer");
+    return sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
+                                sampling_ratio, resp, (hipStream_t)stream);
+}

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "smot_emm_decode_ws_floats": (ctypes.c_int, [_i, _i]),
     "smot_sr_xcorr_fused_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i,
                                                _vp, _vp, _vp]),
+    "smot_sr_xcorr_gather_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "smot_preprocess_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
     "smot_nms_ws_bytes": (ctypes.c_longlong, [_i]),
     "smot_nms_fwd": (ctypes.c_int, [_vp, _i, _f, _vp, _vp, _vp]),
@@ -798,9 +799,14 @@ def sr_xcorr_fused(features, boxes, sr, templates, rx, rz, scales, sampling_rati
     resp = torch.empty((N, C, ho, ho), dtype=torch.float32, device=boxes.device)
     pooled = torch.empty((N, C, rx, rx), dtype=torch.float32, device=boxes.device) if return_pooled else None
     with _Launch(boxes, sr, templates, *feats) as ln:
-        rc = lib.smot_sr_xcorr_fused_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
-                                         _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
-                                         _ptr(resp), _ptr(pooled), ln.stream)
+        if (int(rx), int(rz)) == (35, 7) and pooled is None:        # the second yaml family's shape: its own entry
+            rc = lib.smot_sr_xcorr_gather_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
+                                              _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
+                                              _ptr(resp), ln.stream)
+        else:
+            rc = lib.smot_sr_xcorr_fused_fwd(_cast(fp), _cast(hs), _cast(ws_), _cast(pc), _cast(sc), L, C, _ptr(boxes),
+                                             _ptr(sr), _ptr(templates), N, int(rx), int(rz), int(sampling_ratio),
+                                             _ptr(resp), _ptr(pooled), ln.stream)
     _check(rc, "sr_xcorr_fused")
     return (resp, pooled) if return_pooled else resp
 
