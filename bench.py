@@ -275,7 +275,8 @@ def hipgraph_loop_throughput(emm, feats, det, state, steps):
             "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
 
 
-def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None, ahead=False):
+def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None, ahead=False, dormant=0,
+                             device_carry=True):
     """The whole tracker around the head (siammot_amd.track_head.TrackingLoop): EMM.forward -> [box-head refinement of
     the propagated boxes, roi_heads.py:60-84] -> merge with this frame's detections -> solver (score-banded NMS, id life
     cycle, ONE host sync) -> EMM.extract_cache + track memory.  Fixed track count: the n boxes sit on a
@@ -283,7 +284,12 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     START_TRACK_THRESH = 2 after the first frame, so the unchanged solver never suspends or starts a track;
     ``tracked_in_last_frame`` must equal n (``track_count_held``).  Informational (not part of the metric).
     ``ahead``: every call is also shown the NEXT frame's feature maps (a streaming caller has them): the loop launches the
-    next frame's head speculatively behind this frame's extraction (``TrackingLoop.forward(..., next_features=)``)."""
+    next frame's head speculatively behind this frame's extraction (``TrackingLoop.forward(..., next_features=)``).
+    ``dormant``: that many of the n tracks are made dormant in frame 1 (stronger detections on top of them: the solver's
+    NMS removes their propagated rows, track_solver.py:82-86) and stay dormant (never resumed, never expired — the MOT17
+    yaml keeps them for 30 frames): the memory is n - dormant active rows + dormant carried rows, the head still tracks n
+    rows per frame.  ``device_carry=False``: the reference's form of that memory (concatenated on the host every frame,
+    track_head.py:77-97) instead of the device copy (``smot_memory_carry_fwd``)."""
     from siammot_amd.box_refine import build_refine_tracks
     from siammot_amd.config import get_default_cfg
     from siammot_amd.structures import BoxList
@@ -319,6 +325,10 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
             head.predictor.bbox_pred.weight.zero_()             # zero deltas decode to the proposal itself: tracks hold
             head.predictor.cls_score.weight.mul_(0.2)
     loop = build_tracking_loop(cfg, device=dev, refine_tracks=refine_fn)
+    if dormant:
+        loop.solver.track_pool._max_dormant_frames = 1 << 30
+        loop.solver.resume_track_thresh = 2.0
+        loop.device_carry = bool(device_carry)
     init_predictor(loop.track.tracker.predictor, boxes.cpu())
     with torch.no_grad():
         # A tracker that HOLDS its tracks, as a trained head does on a static scene (random head weights move every box
@@ -347,12 +357,18 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     if loop_hint is not None:
         loop.loop_order_hint = bool(loop_hint)          # A/B (measure/loop_hint_ab2.py): the extraction's order hint in the loop
 
+    suspended = []
+
     def dets(k):
         b, ids, labels = pre[k & 1]
         d = BoxList(b, image_wh, mode="xyxy")
         d.add_field("ids", ids)
         d.add_field("labels", labels)
-        d.add_field("scores", fresh_scores.pop())
+        sc = fresh_scores.pop()
+        if dormant and k == 1 and not suspended:
+            suspended.append(1)
+            sc[n - dormant:] = 3.5             # above every propagated row's band: these tracks lose their rows in the NMS
+        d.add_field("scores", sc)
         return d
     out = loop(feats[0], dets(0))                     # frame 0: the n detections start n tracks
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n
@@ -397,8 +413,13 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tracked = int((out.get_field("ids") >= 0).sum().item())
+    pool = loop.solver.track_pool
     return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
+            "active_tracks": len(pool.get_active_ids()), "dormant_tracks": len(pool._dormant_ids),
+            "memory_rows": len(loop.track_memory[2][0]) if loop.track_memory is not None else 0,
+            "dormant_rows": (("copied on the device (smot_memory_carry_fwd)" if device_carry else
+                              "concatenated on the host (the reference's form)") if dormant else None),
             "refine_tracks": "TrackBoxHead (7x7 HIP pooler, 1024-1024 MLP, one-launch post-processing)" if refine else None,
             "one_launch_path_frames": lean[0], "frame_entry_point_frames": lean[1], "frames": steps,
             "speculative_heads": dict(_ops.SPECULATION) if ahead else None,
@@ -729,6 +750,18 @@ def main():
         loop_stats["next_frame_shown"]["with_refinement"] = {
             k: v for k, v in tracking_loop_throughput(n, dev, feats, refine=True, ahead=True).items()
             if k in ("value", "unit", "ms_per_frame", "tracked_in_last_frame", "track_count_held", "speculative_heads")}
+        # the same head workload (n rows per frame) with dormant tracks in the memory, as MOT sequences have them all the
+        # time (DLA_34_FPN_EMM_MOT17.yaml keeps a lost track for 30 frames): a fifth of the tracks dormant; their rows
+        # copied on the device / concatenated on the host as the reference does / copied with the next frame shown
+        keep = ("value", "unit", "ms_per_frame", "tracked_in_last_frame", "track_count_held", "active_tracks", "dormant_tracks",
+                "memory_rows", "dormant_rows", "frame_entry_point_frames", "frames", "speculative_heads")
+        nd = max(1, n // 5)
+        wd = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd).items() if k in keep}
+        wd["host_form"] = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd, device_carry=False).items()
+                           if k in keep}
+        wd["next_frame_shown"] = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd, ahead=True).items()
+                                  if k in keep}
+        loop_stats["with_dormant_tracks"] = wd
     # host cost of a step: the time to ENQUEUE frame pairs (no synchronisation), measured outside the timed region on
     # a burst short enough for the stream's queue; next to the GPU time per step it says how much host headroom a
     # rank has (eight ranks share one host)

@@ -35,7 +35,7 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_MAX_LEVELS 8
 /* 10: the image of smot_emm_tower_pack grew (fp32 image + three-part bf16 image: ask smot_emm_tower_pack_floats), an image
  *     packed by a version-9 library is too short for this one; smot_emm_tower_form added.  (9: order-hint entries of 528 floats) */
-#define SMOT_ABI_VERSION 10
+#define SMOT_ABI_VERSION 11
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -560,6 +560,26 @@ typedef struct smot_frame_args {
 } smot_frame_args;
 
 int smot_track_frame_fwd(const smot_frame_args* args, smot_stream_t stream);
+
+/*
+ * Dormant rows of the track memory, carried on the device.
+ *
+ * Replaces: TrackHead._update_memory_with_dormant_track (track_head/track_head.py:77-97: torch.cat of the templates +
+ *   two cat_boxlist calls per frame).  A dormant track's (template, search region, box, id, label, score) never changes
+ *   while it is dormant and is a row of the memory the frame's head just ran on: D rows `rows[j]` (host array, indices
+ *   into the source memory of `src_rows_total` rows) are copied to rows dst_row0 + j of the destination buffers
+ *   (`dst_capacity` rows each; templates [*, row_floats], boxes / sr [*,4], ids / labels int64 [*], scores [*]).
+ *   dst_row0_dev != NULL: the first destination row is read from that device word instead (the solver's pool state
+ *   word 4 = the number of active rows: a launch enqueued before the host has read the frame's record); rows at or
+ *   beyond dst_capacity are then dropped.  D <= smot_memory_carry_max_rows().  Pure copies (bit-exact).
+ */
+int smot_memory_carry_max_rows(void);
+int smot_memory_carry_fwd(const float* src_templates, const float* src_boxes, const float* src_sr,
+                          const int64_t* src_ids, const int64_t* src_labels, const float* src_scores,
+                          int src_rows_total, float* dst_templates, float* dst_boxes, float* dst_sr,
+                          int64_t* dst_ids, int64_t* dst_labels, float* dst_scores, int dst_capacity,
+                          const int* rows, int D, int dst_row0, const int* dst_row0_dev, int row_floats,
+                          smot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ LIB_DEBUG = os.path.join(CSRC, "libsmot_emm_debug.so")
 MEASURE_CSRC = os.path.join(os.path.dirname(HERE), "measure", "csrc")      # measurement-only sources (not product)
 DEBUG_ONLY_SOURCES = ["xcorr_variants.hip", "sr_xcorr_plan.hip"]
 SOURCES = ["common.hip", "roi_align.hip", "xcorr.hip", "predictor.hip", "decode.hip", "sr_xcorr.hip", "sr_xcorr_small.hip", "nms.hip", "tower_wino.hip", "tower_conv.hip", "preprocess.hip",
-           "emm_fused.hip", "track_solver.hip", "box_refine.hip", "linear_rows.hip"]
+           "emm_fused.hip", "track_solver.hip", "box_refine.hip", "linear_rows.hip", "memory_carry.hip"]
 ARCH = "gfx950"
 # -fno-slp-vectorize: keeps the xcorr FMA stream as v_fma_f32 with an SGPR tap operand instead of
 # v_pk_fma_f32 + register shuffles (measured: 450 pk_fma + 204 movs vs 900 fma + 4 movs).

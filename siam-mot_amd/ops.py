@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -82,6 +82,9 @@ _SIGNATURES = {
     "smot_linear_rows_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "smot_track_frame_fwd": (ctypes.c_int, [_vp, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
+    "smot_memory_carry_max_rows": (ctypes.c_int, []),
+    "smot_memory_carry_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
+                                             _vp, _i, _vp]),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
@@ -1214,6 +1217,35 @@ def track_frame_addr(lib, addr, dev, stream):
         rc = lib.smot_track_frame_fwd(addr, stream)
     if rc:
         _check(rc, "track_frame")
+
+
+# dormant rows of the track memory copied on the device (TrackingLoop): launches, and frames on which the rows had been
+# copied a call early on the guess that nothing changed ("ahead": kept as they were / redone)
+MEMORY_CARRY = _collections.Counter()
+MEMORY_CARRY_MAX_ROWS = 256
+_carry_rows_t = ctypes.c_int * MEMORY_CARRY_MAX_ROWS
+
+
+def memory_carry(src, src_rows_total, dst, dst_capacity, rows, dst_row0, row_floats, dev, stream, dst_row0_dev=0, lib=None):
+    """``smot_memory_carry_fwd`` on bare device addresses: ``src`` / ``dst`` = (templates, boxes, search regions, ids,
+    labels, scores) of the memory the frame's head ran on / of the memory being built; ``rows`` the source rows of the
+    dormant tracks in the order they are appended (track_head.py:83-86), to rows ``dst_row0`` .. of the destination."""
+    lib = lib or _lib or load_library()
+    D = len(rows)
+    arr = _carry_rows_t(*rows)
+    cur = torch.cuda.current_device()
+    if cur != dev.index:
+        torch.cuda.set_device(dev.index)
+    try:
+        rc = lib.smot_memory_carry_fwd(src[0], src[1], src[2], src[3], src[4], src[5], int(src_rows_total), dst[0], dst[1], dst[2],
+                                       dst[3], dst[4], dst[5], int(dst_capacity), arr, D, int(dst_row0), dst_row0_dev,
+                                       int(row_floats), stream)
+    finally:
+        if cur != dev.index:
+            torch.cuda.set_device(cur)
+    if rc:
+        _check(rc, "memory_carry")
+    MEMORY_CARRY["launched"] += 1
 
 
 def _check_segment(b, s_, i_, l_, dev):

@@ -18,6 +18,8 @@ box head with the reference's call signature.
 """
 import copy
 
+import numpy as np
+
 import torch
 
 from . import ops
@@ -113,17 +115,22 @@ class TrackHead(torch.nn.Module):
 
 
 class _LazyMemory(object):
-    """The track memory ``(templates, [search-region BoxList], [template-box BoxList])`` of a frame whose active rows are
-    the whole memory (no dormant track), as the tracking loop leaves it for the next frame: the tuple's six view tensors
-    and two BoxLists are built on first access.  The next frame's head only needs five POINTERS into the solver's output
-    buffers and the extraction's outputs (``pointers``) — building the views costs ~8 us of host time on the frame's
-    serial chain and, frame after frame, nobody looks at them.  Indexing / iterating / ``len`` behave like the tuple."""
-    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls", "hint_ptr")
+    """The track memory ``(templates, [search-region BoxList], [template-box BoxList])`` as the tracking loop leaves it for
+    the next frame — rows 0 .. n_act-1 the frame's active rows (the solver's and the masked extraction's own outputs), rows
+    n_act .. A-1 the dormant tracks' rows, copied behind them on the device (``TrackingLoop._carry_dormant``) —: the tuple's
+    six view tensors and two BoxLists are built on first access.  The next frame's head only needs five POINTERS into the
+    solver's output buffers and the extraction's outputs (``pointers``) — building the views costs ~8 us of host time on the
+    frame's serial chain and, frame after frame, nobody looks at them.  Indexing / iterating / ``len`` behave like the
+    tuple."""
+    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls", "hint_ptr",
+                 "n_act", "dormant")
 
-    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls, hint_ptr=0):
+    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls, hint_ptr=0, n_act=None, dormant=()):
         self._val = None
         self.fbuf, self.ibuf, self.templates, self.sr_rows = fbuf, ibuf, templates, sr_rows
         self.M, self.A, self.size, self.sr_size, self.host_ids, self.cls = M, A, size, sr_size, host_ids, cls
+        self.n_act = A if n_act is None else n_act          # rows 0 .. n_act-1 are active tracks, the rest dormant ones
+        self.dormant = dormant                              # ids of rows n_act .. A-1, in row order
         # device address of the order hint the masked extraction wrote for exactly rows 0 .. A-1 (it lives behind the
         # frame's float outputs in `fbuf`), or 0.  It needs no host object: the memory IS the extraction's output, untouched
         # — the condition under which this class is used at all — so the hint is valid by construction.
@@ -133,6 +140,11 @@ class _LazyMemory(object):
         """(template boxes, search regions, templates, ids, labels, order hint or 0) of rows 0 .. A-1 as device addresses."""
         fp, ip, M = self.fbuf.data_ptr(), self.ibuf.data_ptr(), self.M
         return fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M, self.hint_ptr
+
+    def carry_pointers(self):
+        """(templates, boxes, search regions, ids, labels, scores) as device addresses: ``ops.memory_carry``'s order."""
+        fp, ip, M = self.fbuf.data_ptr(), self.ibuf.data_ptr(), self.M
+        return self.templates.data_ptr(), fp + 16 * M, self.sr_rows.data_ptr(), ip + 16 * M, ip + 24 * M, fp + 36 * M
 
     def _materialise(self):
         v = self._val
@@ -280,7 +292,76 @@ class TrackingLoop(torch.nn.Module):
         ring.wait(rec_host)                                                        # the frame's one synchronisation
         return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre)
 
-    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None, hint_ptr=0):
+    def _carry_dormant(self, prev, pool, fbuf, ibuf, templates, sr_rows, M, A, ahead=None):
+        """The dormant tracks' rows of the next memory, copied on the device from the memory this frame's head ran on
+        (``prev``) to rows A .. of the frame's output buffers: one launch instead of the reference's ``torch.cat`` +
+        two ``cat_boxlist`` per frame (track_head.py:77-97; ``TrackHead._update_memory_with_dormant_track`` is the general
+        form).  Which rows: the reference appends ``cache[id]`` for every id of ``get_dormant_ids()`` — in that set's
+        iteration order — that has a cache entry; an entry never changes while its track is dormant, and ``prev`` holds
+        it: as an active row when the track went dormant in this frame (``TrackPool._mirror`` made exactly that row its
+        entry), as a carried row otherwise.  Returns (ids, source rows, copied ahead) or None: the general form applies
+        (no previous memory this code can address, an entry that is not a row of it, more rows than one launch takes).
+        ``ahead`` = (source rows, first destination row) of a copy that was enqueued before the record was read."""
+        if prev is None or not self.__dict__.get("device_carry", True):
+            return None
+        order = list(pool.get_dormant_ids())                    # a fresh set of the dict's keys, as track_head.py:83 iterates
+        lazy = type(prev) is _LazyMemory
+        if lazy and prev.dormant == order:
+            # the usual frame with dormant tracks: the same ones as in the last frame, rows n_act .. of the previous memory
+            ids, rows = order, list(range(prev.n_act, prev.A))
+        else:
+            cache, pend = pool._cache, pool.__dict__.get("_pending")
+            if lazy:
+                prev_ids = prev.host_ids
+            else:
+                if prev[0].numel() == 0:
+                    return None
+                prev_ids = getattr(prev[2][0], "host_ids", None)
+                if prev_ids is None:
+                    return None
+            idx = {int(t): i for i, t in enumerate(prev_ids)}
+            pend_ids = idx if (pend is not None and pend[0] is prev) else (
+                set(int(t) for t in pend[1]) if pend is not None else ())
+            ids, rows = [], []
+            for d in order:
+                if d in cache or d in pend_ids:                                    # track_head.py:84-86
+                    r = idx.get(d)
+                    if r is None:
+                        return None
+                    ids.append(d)
+                    rows.append(r)
+        D = len(rows)
+        if D == 0:
+            return ids, rows, False
+        if D > ops.MEMORY_CARRY_MAX_ROWS or A + D > M:
+            return None
+        if ahead is not None and ahead[0] == rows and ahead[1] == A:
+            ops.MEMORY_CARRY["ahead_kept"] += 1
+            return ids, rows, True
+        if ahead is not None:
+            ops.MEMORY_CARRY["ahead_redone"] += 1
+        if lazy:
+            src, n_prev = prev.carry_pointers(), prev.A
+        else:
+            z, sr0, tb0 = prev[0], prev[1][0], prev[2][0]
+            n_prev = len(prev_ids)
+            if not (tb0.has_field("ids") and tb0.has_field("labels") and tb0.has_field("scores")):
+                return None
+            t = (z, tb0.bbox, sr0.bbox, tb0.get_field("ids"), tb0.get_field("labels"), tb0.get_field("scores"))
+            want = (torch.float32, torch.float32, torch.float32, torch.int64, torch.int64, torch.float32)
+            for x, dt in zip(t, want):
+                if not (x.is_cuda and x.device == fbuf.device and x.dtype is dt and x.is_contiguous() and x.shape[0] == n_prev):
+                    return None
+            if z[0].numel() != templates[0].numel() or tb0.bbox.shape[1] != 4 or sr0.bbox.shape[1] != 4:
+                return None
+            src = tuple(x.data_ptr() for x in t)
+        fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
+        dev = fbuf.device
+        ops.memory_carry(src, n_prev, (templates.data_ptr(), fp + 16 * M, sr_rows.data_ptr(), ip + 16 * M, ip + 24 * M,
+                                       fp + 36 * M), M, rows, A, templates[0].numel(), dev, ops._stream(dev))
+        return ids, rows, False
+
+    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None, hint_ptr=0, carried_ahead=None):
         """After the record arrived: mirror the pool, slice the outputs, build the next track memory.  This is host work on
         the frame's serial chain: ten strided views straight off the two output buffers (no intermediate splits), the
         record through the ring's numpy view, BoxLists of this package's own class without re-validation."""
@@ -307,16 +388,29 @@ class TrackingLoop(torch.nn.Module):
             out.add_field("labels", ol)
         out.host_ids = rec[8 + M:8 + M + K]
         hint = pre[2] if pre is not None and len(pre) > 2 else None
-        if own and A > 0 and pre is not None and hint is None and not pool._dormant_ids and self.__dict__.get("lazy_memory", True):
-            # the usual frame: the active rows ARE the next memory — left unbuilt (see _LazyMemory); `out.active_rows` (read by
-            # the general path's TrackHead._get_track_targets only) is not needed either
-            pad2 = emm.track_utils.pad_pixels * 2
-            memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A, size, [int(size[0] + pad2), int(size[1] + pad2)],
-                                 rec[8 + 2 * M:8 + 2 * M + A], cls, hint_ptr if A >= 2 else 0)
-            pool.note_memory(memory, memory.host_ids)
-            self.__dict__["track_memory"] = memory
-            self.__dict__["_own_memory"] = memory
-            return out
+        self.__dict__["_carry_ahead_kept"] = False
+        if own and A > 0 and pre is not None and hint is None and self.__dict__.get("lazy_memory", True):
+            # the usual frame: the active rows — with the dormant tracks' rows copied behind them on the device — ARE the next
+            # memory, left unbuilt (see _LazyMemory); `out.active_rows` (read by the general path's
+            # TrackHead._get_track_targets only) is not needed either
+            carried = ((), (), False)
+            if pool._dormant_ids:
+                carried = self._carry_dormant(self.__dict__.get("track_memory"), pool, fbuf, ibuf, pre[0], pre[1], M, A,
+                                              carried_ahead)
+            if carried is not None:
+                dormant, D = carried[0], len(carried[0])
+                host_ids = rec[8 + 2 * M:8 + 2 * M + A]
+                if D:
+                    host_ids = np.concatenate([host_ids, np.asarray(dormant, dtype=host_ids.dtype)])
+                    self.__dict__["_carry_ahead_kept"] = carried[2]
+                pad2 = emm.track_utils.pad_pixels * 2
+                memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A + D, size, [int(size[0] + pad2), int(size[1] + pad2)],
+                                     host_ids, cls, hint_ptr if (A >= 2 and D == 0) else 0, A, list(dormant))
+                pool.note_memory(memory, memory.host_ids)
+                self.__dict__["track_memory"] = memory
+                self.__dict__["_own_memory"] = memory
+                return out
+            ops.FALLBACKS["dormant_rows_on_the_host"] += 1
         ab, ai, asc, al = (st(fbuf, (A, 4), (4, 1), 4 * M), st(ibuf, (A,), (1,), 2 * M), st(fbuf, (A,), (1,), 9 * M),
                            st(ibuf, (A,), (1,), 3 * M))
         if own:
@@ -572,7 +666,7 @@ class TrackingLoop(torch.nn.Module):
                 if hook is not None:
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
-        spec_tf = None
+        spec_tf = carried_ahead = None
         # (a wrong guess costs the GPU a whole head: the guess is made only while the count has been holding — this frame
         # had as many tracks as the frame before)
         steady = self.__dict__.get("_prev_n_trk") == n_trk
@@ -583,19 +677,30 @@ class TrackingLoop(torch.nn.Module):
             # memory of this frame was the previous frame's active rows, untouched): rows 0 .. n_trk-1 of act_boxes / ids /
             # labels, of the extraction's search regions and templates, and its order hint
             need = P.ws_need[n_trk]
+            if mem.A > mem.n_act:
+                # ... and that the dormant tracks stay the ones they were: their rows of this frame's memory go behind the
+                # active rows now, the first destination row read from the solver's count on the device
+                rows = list(range(mem.n_act, mem.A))
+                ops.memory_carry(mem.carry_pointers(), mem.A, (templates.data_ptr(), fp + 16 * M, sr_next.data_ptr(), ip + 16 * M,
+                                                               ip + 24 * M, fp + 36 * M), M, rows, mem.n_act,
+                                 templates[0].numel(), dev, stream, dst_row0_dev=state.data_ptr() + 16, lib=P.lib)
+                carried_ahead = (rows, mem.n_act)
             spec_tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = spec_tf.data_ptr()
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
-                                templates.data_ptr(), hint_ptr if n_trk >= 2 else 0, ip + 16 * M, ip + 24 * M, p, p + 16 * n_trk),
-                               n_trk, ops.STAGE_HEAD)
+                                templates.data_ptr(), hint_ptr if (n_trk >= 2 and carried_ahead is None) else 0, ip + 16 * M,
+                                ip + 24 * M, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)
             ops.SPECULATION["launched"] += 1
         ring.wait(rec_host, event=False)                                           # the frame's one synchronisation
-        out = self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P, hint_ptr=hint_ptr)
+        out = self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P, hint_ptr=hint_ptr,
+                                 carried_ahead=carried_ahead)
         if spec_tf is not None:
             # valid for exactly the memory _finish_frame just built, if it is the lazy one over these buffers with n_trk rows
+            # — and its dormant rows, if any, are the ones that were copied before that head was enqueued
             m2 = self.__dict__.get("track_memory")
-            if type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk:
+            if (type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk
+                    and (m2.A == m2.n_act or self.__dict__.get("_carry_ahead_kept"))):
                 self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf)
             else:
                 ops.SPECULATION["discarded"] += 1        # the row count changed, or dormant rows joined the memory

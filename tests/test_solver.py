@@ -200,6 +200,158 @@ def test_mirror_keeps_the_reference_order_of_dormant_ids():
     assert multi >= 5 and pool_a._max_id > 100       # several frames suspended more than one id at once
 
 
+class _HostEmulation(object):
+    """The device side of ``TrackingLoop._step_lean`` on CPU tensors — test infrastructure: the one-launch solver's buffers
+    and record (include/smot_emm.h, smot_track_solve_fwd) written by a twin host solver on a twin pool, the masked
+    extraction by the fake tracker, ``smot_memory_carry_fwd`` by byte copies between the same addresses.  What runs
+    unmodified is the loop's host logic: the pool mirror, the lazy cache, the row bookkeeping of the carried memory."""
+
+    def __init__(self, loop, thresholds, max_dormant_frames):
+        from siammot_amd.solver import TrackPool, TrackSolver
+        self.loop = loop
+        self.pool = TrackPool(max_dormant_frames=max_dormant_frames)
+        self.solver = TrackSolver(self.pool, *thresholds, nms_mask_fn=_numpy_mask)
+        self.carries = 0
+
+    class Ring(object):
+        bufs = (None, None)
+
+        def record_event(self):
+            pass
+
+        def wait(self, rec, event=True):
+            pass
+
+    def track_solve(self, det, trk, bias, thresholds, nms_thresh, max_dormant, state, cap, host_record=False):
+        from siammot_amd.structures import BoxList
+        segs = [x for x in (det, (trk[0], trk[1] + bias, trk[2], trk[3]) if trk is not None else None) if x is not None]
+        boxes = torch.cat([x[0] for x in segs])
+        scores = torch.cat([x[1] for x in segs]).clone()
+        ids = torch.cat([x[2] for x in segs]).clone()
+        labels = torch.cat([x[3] for x in segs])
+        M = boxes.shape[0]
+        active_before = self.pool.get_active_ids()
+        banded = scores + torch.tensor([float(int(t) in active_before) for t in ids])
+        rows = np.nonzero(_numpy_mask(boxes, banded, nms_thresh).numpy())[0]
+        bl = BoxList(boxes, (1280, 704), mode="xyxy")
+        bl.add_field("ids", ids)
+        bl.add_field("scores", scores)
+        bl.add_field("labels", labels)
+        in_ids = ids.numpy().copy()
+        out = self.solver([bl])[0]
+        K = len(out)
+        assert K == len(rows) and np.array_equal(out.bbox.numpy(), boxes.numpy()[rows])
+        final = out.get_field("ids").numpy()
+        active = self.pool.get_active_ids()
+        act = [p for p in range(K) if int(final[p]) in active]
+        A = len(act)
+        fbuf = torch.full((10 * M,), float("nan"))
+        ibuf = torch.full((4 * M,), -99, dtype=torch.int64)
+        fbuf[:4 * K] = out.bbox.reshape(-1)
+        fbuf[4 * M:4 * M + 4 * A] = out.bbox[act].reshape(-1)
+        fbuf[8 * M:8 * M + K] = out.get_field("scores")
+        fbuf[9 * M:9 * M + A] = out.get_field("scores")[act]
+        ibuf[:K] = out.get_field("ids")
+        ibuf[M:M + K] = out.get_field("labels")
+        ibuf[2 * M:2 * M + A] = out.get_field("ids")[act]
+        ibuf[3 * M:3 * M + A] = out.get_field("labels")[act]
+        rec = np.zeros(8 + 4 * M + 3 * cap, dtype=np.int32)
+        pool = self.pool
+        rec[0], rec[1], rec[2], rec[3] = K, A, pool._max_id, pool._frame_idx
+        rec[4], rec[5], rec[7] = len(pool._active_ids), len(pool._dormant_ids), M
+        rec[8:8 + K] = rows
+        rec[8 + M:8 + M + K] = final
+        rec[8 + 2 * M:8 + 2 * M + A] = final[act]
+        base = 8 + 3 * M
+        rec[base:base + rec[4]] = sorted(pool._active_ids)
+        d = sorted(pool._dormant_ids.items())
+        rec[base + cap:base + cap + len(d)] = [k for k, _ in d]
+        rec[base + 2 * cap:base + 2 * cap + len(d)] = [v for _, v in d]
+        rec[8 + 3 * M + 3 * cap:] = in_ids
+        return fbuf, ibuf, torch.from_numpy(rec), M
+
+    def memory_carry(self, src, n_src, dst, cap, rows, row0, row_floats, dev, stream, dst_row0_dev=0, lib=None):
+        import ctypes
+        assert dst_row0_dev == 0 and row0 + len(rows) <= cap and all(0 <= r < n_src for r in rows)
+        for j, r in enumerate(rows):
+            for k, nbytes in enumerate((4 * row_floats, 16, 16, 8, 8, 4)):
+                ctypes.memmove(dst[k] + (row0 + j) * nbytes, src[k] + r * nbytes, nbytes)
+        self.carries += 1
+
+
+def test_lean_frame_bookkeeping_with_carried_dormant_rows_equals_the_general_path_on_cpu(monkeypatch):
+    """The host logic of the lean per-frame step — record -> pool mirror -> lazy cache -> which rows of the memory the
+    head just ran on are the dormant tracks' rows of the next one (``TrackingLoop._carry_dormant``; the reference
+    re-concatenates them from its cache, track_head.py:77-97) — with the device side emulated on CPU tensors, against the
+    general path (TrackHead / TrackSolver / TrackPool, pinned to the reference's classes by the test above) on 120 frames in
+    which tracks start, go dormant, are carried for several frames, resume and expire: outputs, memory (templates, boxes,
+    search regions, ids, labels, scores, row order), pool and cache identical in every frame."""
+    import types
+    import siammot_amd.ops as ops_
+    from fake_tracker import FakeTracker, detections
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.track_head import TrackHead, TrackingLoop, _LazyMemory
+    pad, thresholds, max_dormant = 512, (0.4, 0.6, 0.4), 4
+
+    class LeanFake(FakeTracker):
+        rz = 15
+
+        def __init__(self):
+            super(LeanFake, self).__init__(pad)
+            self.track_utils = types.SimpleNamespace(pad_pixels=pad)
+
+        def track_raw(self, features, boxes, sr, z, size, sr_boxlist):
+            assert torch.allclose(z[:, :, 0, 0], sr - pad + 1000.0, atol=1e-2)              # carried rows stay in step
+            ids = sr_boxlist.get_field("ids")
+            return boxes + 2.0, (((ids * 37) % 100).to(torch.float32) / 100.0) * 0.9 + 0.05
+
+        def extract_cache_rows(self, features, boxes, n_valid):
+            return (boxes + 1000.0)[:, :, None, None].clone(), boxes + pad
+
+    loops = []
+    for lean in (True, False):
+        pool = TrackPool(max_dormant_frames=max_dormant)
+        head = TrackHead(LeanFake(), types.SimpleNamespace(pad_pixels=pad), pool).eval()
+        loops.append(TrackingLoop(head, TrackSolver(pool, *thresholds, nms_mask_fn=_numpy_mask)).eval())
+    emu = _HostEmulation(loops[0], thresholds, max_dormant)
+    monkeypatch.setattr(ops_, "track_solve", emu.track_solve)
+    monkeypatch.setattr(ops_, "memory_carry", emu.memory_carry)
+    monkeypatch.setattr(ops_, "_stream", lambda dev=None: None)
+    pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+    monkeypatch.setattr(pa, "device_state", lambda dev: torch.zeros(8, dtype=torch.int32), raising=False)
+    monkeypatch.setattr(pa, "host_record_ring", lambda dev: _HostEmulation.Ring(), raising=False)
+    fb0 = ops_.FALLBACKS["dormant_rows_on_the_host"]
+    rs = [np.random.RandomState(21), np.random.RandomState(21)]
+    feats = (torch.zeros(1),)
+    carried_frames = lazy_frames = resumed = 0
+    for f in range(120):
+        a = loops[0]._step_lean(feats, detections(rs[0], f))
+        b = loops[1](feats, detections(rs[1], f))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+        ma, mb = loops[0].track_memory, loops[1].track_memory
+        lazy = type(ma) is _LazyMemory
+        lazy_frames += lazy
+        carried_frames += lazy and ma.A > ma.n_act
+        assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
+        assert torch.equal(ma[2][0].bbox, mb[2][0].bbox)
+        for fld in ("ids", "labels", "scores"):
+            assert torch.equal(ma[2][0].get_field(fld), mb[2][0].get_field(fld)), "memory %s, frame %d" % (fld, f)
+            assert torch.equal(ma[1][0].get_field(fld), mb[1][0].get_field(fld))
+        assert [int(t) for t in ma[2][0].host_ids] == mb[2][0].get_field("ids").tolist()
+        assert pa.get_active_ids() == pb.get_active_ids() and list(pa._dormant_ids.items()) == list(pb._dormant_ids.items())
+        assert pa._kill_ids == pb._kill_ids and pa._max_id == pb._max_id
+        if f % 7 == 3:                                    # (a full flush of the lazy cache: every 7th frame only)
+            ca, cb = pa.get_cache(), pb.get_cache()
+            for tid in pa.get_dormant_ids():
+                if tid in cb:
+                    assert tid in ca and torch.equal(ca[tid][0], cb[tid][0]) and torch.equal(ca[tid][1].bbox, cb[tid][1].bbox)
+                    assert torch.equal(ca[tid][2].bbox, cb[tid][2].bbox)
+    assert carried_frames >= 40 and emu.carries >= 40 and pa._kill_ids and pa._max_id > 25, (carried_frames, emu.carries)
+    # every frame with active rows leaves the memory unbuilt; no frame fell back to the host form
+    assert ops_.FALLBACKS["dormant_rows_on_the_host"] == fb0 and lazy_frames >= 110, (lazy_frames,)
+
+
 @pytest.mark.gpu
 def test_solver_on_the_device_with_the_hip_nms():
     _run("cuda:0", None)
@@ -498,6 +650,47 @@ def test_a_frame_on_the_host_solver_between_one_launch_frames_keeps_the_dormant_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("row_shape", [(32, 15, 15), (128, 7, 7), (3, 7, 7)])
+def test_memory_carry_copies_the_named_rows(row_shape):
+    """``smot_memory_carry_fwd``: D rows of a source memory (templates, boxes, search regions, ids, labels, scores) to rows
+    dst_row0 .. of the destination buffers — first row by value and read from a device word; rows beyond the capacity are
+    dropped; nothing else is written (16-byte and scalar copy forms)."""
+    import siammot_amd.ops as ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    n_src, cap = 23, 17
+    rf = int(np.prod(row_shape))
+    src = [torch.randn((n_src,) + row_shape, generator=g), torch.randn(n_src, 4, generator=g), torch.randn(n_src, 4, generator=g),
+           torch.randint(0, 1 << 40, (n_src,), generator=g), torch.randint(0, 9, (n_src,), generator=g), torch.rand(n_src, generator=g)]
+    src = [t.to(dev) for t in src]
+
+    def fresh():
+        return [torch.full((cap,) + row_shape, -7.0, device=dev), torch.full((cap, 4), -7.0, device=dev),
+                torch.full((cap, 4), -7.0, device=dev), torch.full((cap,), -7, dtype=torch.int64, device=dev),
+                torch.full((cap,), -7, dtype=torch.int64, device=dev), torch.full((cap,), -7.0, device=dev)]
+    rows = [22, 0, 5, 5, 11]
+    for row0, on_device in ((4, False), (9, True), (14, True)):
+        dst = fresh()
+        want = [t.clone() for t in dst]
+        for j, r in enumerate(rows):
+            if row0 + j < cap:
+                for w, s_ in zip(want, src):
+                    w[row0 + j] = s_[r]
+        word = torch.tensor([0, 0, 0, 0, row0, 0], dtype=torch.int32, device=dev)
+        ops.memory_carry([t.data_ptr() for t in src], n_src, [t.data_ptr() for t in dst], cap, rows, 0 if on_device else row0, rf,
+                         dev, ops._stream(dev), dst_row0_dev=(word.data_ptr() + 16) if on_device else 0)
+        torch.cuda.synchronize()
+        for w, d in zip(want, dst):
+            assert torch.equal(w, d)
+    with pytest.raises(RuntimeError):                    # by value, the rows must fit
+        ops.memory_carry([t.data_ptr() for t in src], n_src, [t.data_ptr() for t in fresh()], cap, rows, 14, rf, dev,
+                         ops._stream(dev))
+    with pytest.raises(RuntimeError):                    # a source row that does not exist
+        ops.memory_carry([t.data_ptr() for t in src], n_src, [t.data_ptr() for t in fresh()], cap, [23], 0, rf, dev,
+                         ops._stream(dev))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_lean_step_equals_general_path(native):
     """TrackingLoop's lean per-frame step (raw tensors, masked template extraction before the synchronisation, lazy
@@ -520,6 +713,8 @@ def test_lean_step_equals_general_path(native):
             getattr(loops[0].track.tracker.predictor, name).weight.mul_(20.0)
     loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
     loops[1]._lean_ok = lambda d: False                     # general path
+    import siammot_amd.ops as ops_
+    carried0 = ops_.MEMORY_CARRY["launched"]
     lean_frames = []
     loops[0].native_frame = native              # one library call per frame (smot_track_frame_fwd) / composed in Python
     which = "_step_native" if native else "_step_lean"
@@ -539,6 +734,10 @@ def test_lean_step_equals_general_path(native):
         assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
         assert torch.equal(ma[2][0].bbox, mb[2][0].bbox)
         assert torch.equal(ma[2][0].get_field("ids"), mb[2][0].get_field("ids"))
+        for fld in ("labels", "scores"):                    # (dormant rows are copied on the device on the lean paths)
+            assert torch.equal(ma[2][0].get_field(fld), mb[2][0].get_field(fld)), "memory %s, frame %d" % (fld, f)
+            assert torch.equal(ma[1][0].get_field(fld), mb[1][0].get_field(fld)), "memory sr %s, frame %d" % (fld, f)
+        assert [int(t) for t in ma[2][0].host_ids] == mb[2][0].get_field("ids").tolist()
         pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
         assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids
         assert pa._kill_ids == pb._kill_ids and pa._max_id == pb._max_id
@@ -548,6 +747,8 @@ def test_lean_step_equals_general_path(native):
                 assert tid in ca and torch.equal(ca[tid][0], cb[tid][0]) and torch.equal(ca[tid][1].bbox, cb[tid][1].bbox)
         seen_dormant |= bool(pa.get_dormant_ids())
     assert len(lean_frames) == 16 and seen_dormant and loops[0].solver.track_pool._kill_ids
+    import siammot_amd.ops as ops_
+    assert ops_.MEMORY_CARRY["launched"] > carried0, "no frame copied its dormant rows on the device"
 
 
 @pytest.mark.gpu
