@@ -361,15 +361,23 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
 
     def dets(k):
         b, ids, labels = pre[k & 1]
+        sc = fresh_scores.pop()
+        if dormant and k == 2 and not suspended:
+            # detections stronger than any propagated row (band (2, 3]) exactly on the boxes the last `dormant` tracks were
+            # propagated to in the previous frame (they hold): the NMS removes those tracks' rows, the solver suspends them
+            suspended.append(1)
+            lo, li = last[0].bbox, last[0].get_field("ids")
+            sel = lo[li >= n - dormant]
+            if sel.shape[0] == dormant:
+                b = b.clone()
+                b[n - dormant:] = sel
+                sc[n - dormant:] = 3.5
         d = BoxList(b, image_wh, mode="xyxy")
         d.add_field("ids", ids)
         d.add_field("labels", labels)
-        sc = fresh_scores.pop()
-        if dormant and k == 1 and not suspended:
-            suspended.append(1)
-            sc[n - dormant:] = 3.5             # above every propagated row's band: these tracks lose their rows in the NMS
         d.add_field("scores", sc)
         return d
+    last = [None]
     out = loop(feats[0], dets(0))                     # frame 0: the n detections start n tracks
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n
     # tracks live on, every frame's n detections compete with them in NMS
@@ -388,9 +396,13 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     loop._step_lean, loop._step_native = counted, counted_native
     import siammot_amd.ops as _ops
     if ahead:
-        step = lambda k: loop(feats[k & 1], dets(k), next_features=feats[(k + 1) & 1])
+        step0 = lambda k: loop(feats[k & 1], dets(k), next_features=feats[(k + 1) & 1])
     else:
-        step = lambda k: loop(feats[k & 1], dets(k))
+        step0 = lambda k: loop(feats[k & 1], dets(k))
+
+    def step(k):
+        o = last[0] = step0(k)
+        return o
     for k in range(1, 30):
         out = step(k)
     torch.cuda.synchronize()

@@ -289,8 +289,26 @@ class TrackingLoop(torch.nn.Module):
         ob, ab, osc, asc = fbuf.split((4 * M, 4 * M, M, M))
         act_boxes = ab.view(M, 4)
         pre = emm.extract_cache_rows(features, act_boxes, state[4:5])              # runs while the host wakes up
+        ahead = None
+        if pre is not None and len(pre) == 2:
+            ahead = self._carry_ahead(mem, fbuf, ibuf, pre[0], pre[1], M, state, dev, ops._stream(dev))
         ring.wait(rec_host)                                                        # the frame's one synchronisation
-        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre)
+        return self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, pre, carried_ahead=ahead)
+
+    def _carry_ahead(self, mem, fbuf, ibuf, templates, sr_rows, M, state, dev, stream, lib=None):
+        """Before the frame's record is read: the dormant rows of the memory this frame's head ran on, copied behind the
+        rows the solver is leaving active — the first destination row read from the solver's count on the device — on the
+        guess that the dormant tracks stay the ones they were (the usual frame).  ``_carry_dormant`` checks the guess
+        against the record and copies again when it did not hold; the copy launch is off the frame's serial chain
+        (record -> next head) either way.  Returns (source rows, guessed first destination row) or None."""
+        if not (type(mem) is _LazyMemory and mem.A > mem.n_act and self.__dict__.get("device_carry", True)):
+            return None
+        rows = list(range(mem.n_act, mem.A))
+        fp, ip = fbuf.data_ptr(), ibuf.data_ptr()
+        ops.memory_carry(mem.carry_pointers(), mem.A, (templates.data_ptr(), fp + 16 * M, sr_rows.data_ptr(), ip + 16 * M,
+                                                       ip + 24 * M, fp + 36 * M), M, rows, mem.n_act, templates[0].numel(),
+                         dev, stream, dst_row0_dev=state.data_ptr() + 16, lib=lib)
+        return rows, mem.n_act
 
     def _carry_dormant(self, prev, pool, fbuf, ibuf, templates, sr_rows, M, A, ahead=None):
         """The dormant tracks' rows of the next memory, copied on the device from the memory this frame's head ran on
@@ -666,7 +684,8 @@ class TrackingLoop(torch.nn.Module):
                 if hook is not None:
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
-        spec_tf = carried_ahead = None
+        spec_tf = None
+        carried_ahead = self._carry_ahead(mem, fbuf, ibuf, templates, sr_next, M, state, dev, stream, P.lib)
         # (a wrong guess costs the GPU a whole head: the guess is made only while the count has been holding — this frame
         # had as many tracks as the frame before)
         steady = self.__dict__.get("_prev_n_trk") == n_trk
@@ -677,14 +696,7 @@ class TrackingLoop(torch.nn.Module):
             # memory of this frame was the previous frame's active rows, untouched): rows 0 .. n_trk-1 of act_boxes / ids /
             # labels, of the extraction's search regions and templates, and its order hint
             need = P.ws_need[n_trk]
-            if mem.A > mem.n_act:
-                # ... and that the dormant tracks stay the ones they were: their rows of this frame's memory go behind the
-                # active rows now, the first destination row read from the solver's count on the device
-                rows = list(range(mem.n_act, mem.A))
-                ops.memory_carry(mem.carry_pointers(), mem.A, (templates.data_ptr(), fp + 16 * M, sr_next.data_ptr(), ip + 16 * M,
-                                                               ip + 24 * M, fp + 36 * M), M, rows, mem.n_act,
-                                 templates[0].numel(), dev, stream, dst_row0_dev=state.data_ptr() + 16, lib=P.lib)
-                carried_ahead = (rows, mem.n_act)
+            # (... and that the dormant tracks stay the ones they were: their rows went behind the active rows just above)
             spec_tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = spec_tf.data_ptr()
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
