@@ -486,6 +486,32 @@ int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_
                          int* record, smot_stream_t stream);
 
 /*
+ * The same launch carrying the dormant tracks' rows of the track memory (track_head/track_head.py:77-97; the stand-alone
+ * form is smot_memory_carry_fwd, below): rows carry_src_row0 .. carry_src_row0 + carry_rows - 1 of the memory the frame's
+ * head ran on (carry_* arrays: templates [*, row_floats], boxes / sr [*,4], ids / labels int64, scores) go behind the rows
+ * this launch leaves active.  Boxes, ids, labels and scores are appended to act_* behind the count the launch determines
+ * (always the right place).  Templates and search regions are copied by extra workgroups beside the solver's one — they
+ * add nothing to the launch's duration but cannot know that count: they write to rows carry_dst_row0 .. of next_templates /
+ * next_sr (capacity n_det + n_trk rows; the masked template extraction fills rows 0 .. count-1 of the same buffers
+ * afterwards), the CALLER'S GUESS of the count; a caller whose guess turns out wrong (record word 1 != carry_dst_row0)
+ * copies again with smot_memory_carry_fwd.  row_floats % 4 == 0, 16-byte aligned arrays.  carry_rows == 0: plain
+ * smot_track_solve_fwd.
+ */
+int smot_track_solve_carry_fwd(const float* det_boxes, float* det_scores, const int64_t* det_ids,
+                               const int64_t* det_labels, int n_det,
+                               const float* trk_boxes, float* trk_scores, const int64_t* trk_ids,
+                               const int64_t* trk_labels, int n_trk, float trk_score_bias,
+                               float track_thresh, float start_thresh, float resume_thresh, float nms_thresh,
+                               int max_dormant_frames, int* pool_state, int pool_capacity,
+                               float* out_boxes, float* out_scores, int64_t* out_ids, int64_t* out_labels,
+                               float* act_boxes, int64_t* act_ids, int64_t* act_labels, float* act_scores,
+                               int* record,
+                               const float* carry_templates, const float* carry_boxes, const float* carry_sr,
+                               const int64_t* carry_ids, const int64_t* carry_labels, const float* carry_scores,
+                               int carry_src_row0, int carry_rows, int carry_dst_row0,
+                               float* next_templates, float* next_sr, int row_floats, smot_stream_t stream);
+
+/*
  * One tracking frame behind ONE call (or two): the launches of smot_emm_track_fwd (3) [+ smot_box_refine_fwd (8)] +
  * smot_track_solve_fwd (1) + smot_emm_extract_cache_masked_fwd (1) enqueued back to back on `stream`.
  *
@@ -509,6 +535,7 @@ int smot_track_solve_fwd(const float* det_boxes, float* det_scores, const int64_
 #define SMOT_STAGE_REFINE 2
 #define SMOT_STAGE_SOLVE 4
 #define SMOT_STAGE_EXTRACT 8
+#define SMOT_STAGE_CARRY 16     /* with SMOT_STAGE_SOLVE: smot_track_solve_carry_fwd on the carry_* fields */
 typedef struct smot_frame_args {
     /* ---- fixed while the video's geometry and the model stand ---- */
     /* FPN levels (HOST arrays of num_levels entries, as in smot_roi_align_levels_fwd; the entries of `feats` are
@@ -547,12 +574,16 @@ typedef struct smot_frame_args {
     float* next_templates;
     float* next_sr;
     float* next_order_hint;      /* smot_emm_order_hint_floats(n_det + n_trk, rz, sampling_ratio) floats or NULL */
+    /* dormant rows carried by the solver's launch (SMOT_STAGE_CARRY; smot_track_solve_carry_fwd) */
+    const float* carry_templates; const float* carry_boxes; const float* carry_sr;
+    const int64_t* carry_ids; const int64_t* carry_labels; const float* carry_scores;
     /* ---- sizes and scalars: per frame first ---- */
     int n_trk, stages, n_det;
     int num_levels, C;
     int rx, rz, sampling_ratio, gn_groups, up, use_centerness;
     int refine, box_pooled, box_sampling_ratio, dim6, dim7, num_classes, reg_classes, tracktor;
     int max_dormant_frames, pool_capacity;
+    int carry_src_row0, carry_rows, carry_dst_row0;
     float track_thresh, start_thresh, resume_thresh;
     float gn_eps, pad_pixels, one_minus_sigma, sigma, clip_w, clip_h;
     float box_wx, box_wy, box_ww, box_wh, box_xform_clip;

@@ -197,11 +197,15 @@ extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stre
         }
     }
     if (stages & SMOT_STAGE_SOLVE) {
-        rc = smot_track_solve_fwd(a->det_boxes, a->det_scores, a->det_ids, a->det_labels, a->n_det, trk_boxes, trk_scores,
-                                  trk_ids, trk_labels, a->n_trk, bias, a->track_thresh, a->start_thresh, a->resume_thresh,
-                                  a->nms_thresh, a->max_dormant_frames, a->pool_state, a->pool_capacity, a->out_boxes,
-                                  a->out_scores, a->out_ids, a->out_labels, a->act_boxes, a->act_ids, a->act_labels,
-                                  a->act_scores, a->record, stream);
+        const int carry = (stages & SMOT_STAGE_CARRY) ? a->carry_rows : 0;
+        rc = smot_track_solve_carry_fwd(a->det_boxes, a->det_scores, a->det_ids, a->det_labels, a->n_det, trk_boxes, trk_scores,
+                                        trk_ids, trk_labels, a->n_trk, bias, a->track_thresh, a->start_thresh,
+                                        a->resume_thresh, a->nms_thresh, a->max_dormant_frames, a->pool_state,
+                                        a->pool_capacity, a->out_boxes, a->out_scores, a->out_ids, a->out_labels,
+                                        a->act_boxes, a->act_ids, a->act_labels, a->act_scores, a->record,
+                                        a->carry_templates, a->carry_boxes, a->carry_sr, a->carry_ids, a->carry_labels,
+                                        a->carry_scores, a->carry_src_row0, carry, a->carry_dst_row0, a->next_templates,
+                                        a->next_sr, a->C * a->rz * a->rz, stream);
         if (rc) return rc;
     }
     if (!(stages & SMOT_STAGE_EXTRACT)) return SMOT_OK;

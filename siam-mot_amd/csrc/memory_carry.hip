@@ -14,6 +14,7 @@
 //
 // Pure copies: bit-exact by construction.  HBM-bound: 2 x D x (C rz rz + 11) x 4 bytes; one workgroup per 16 KB piece.
 #include "smot_common.h"
+#include <cstddef>
 
 namespace smot {
 
@@ -44,7 +45,12 @@ struct MemoryCarryArgs {
 template <bool VEC>
 __global__ void __launch_bounds__(MC_THREADS) memory_carry_kernel(MemoryCarryArgs A) {
     const int j = blockIdx.y;
-    const int s = A.src_rows[j];
+    // (read straight from the kernel-argument segment: a by-value array indexed by a run-time value would be copied to
+    // scratch or LDS first — 16 KB of LDS per workgroup in the first build)
+    typedef const char __attribute__((address_space(4))) ka_char;
+    typedef const short __attribute__((address_space(4))) ka_short;
+    ka_char* ka = (ka_char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int s = *(ka_short*)(ka + offsetof(MemoryCarryArgs, src_rows) + 2 * j);
     const int d0 = A.dst_row0_dev ? *A.dst_row0_dev : A.dst_row0;
     const int d = d0 + j;
     if (d0 < 0 || d >= A.capacity) return;
@@ -53,17 +59,19 @@ __global__ void __launch_bounds__(MC_THREADS) memory_carry_kernel(MemoryCarryArg
     if constexpr (VEC) {
         const int nv = A.row_floats >> 2;
         const int base = blockIdx.x * (MC_THREADS * MC_VEC_PER_THREAD) + threadIdx.x;
-        float4 v[MC_VEC_PER_THREAD];
-#pragma unroll
-        for (int u = 0; u < MC_VEC_PER_THREAD; ++u) {                    // the loads first: independent, in flight together
-            const int e = base + u * MC_THREADS;
-            if (e < nv) v[u] = reinterpret_cast<const float4*>(src)[e];
-        }
-#pragma unroll
-        for (int u = 0; u < MC_VEC_PER_THREAD; ++u) {
-            const int e = base + u * MC_THREADS;
-            if (e < nv) reinterpret_cast<float4*>(dst)[e] = v[u];
-        }
+        // (named registers: an array filled under a condition was promoted to LDS, 16 KB per workgroup, in the first build)
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src);
+        float4* __restrict__ d4 = reinterpret_cast<float4*>(dst);
+        const int e0 = base, e1 = base + MC_THREADS, e2 = base + 2 * MC_THREADS, e3 = base + 3 * MC_THREADS;
+        static_assert(MC_VEC_PER_THREAD == 4, "four pieces per thread");
+        const float4 v0 = s4[min(e0, nv - 1)];                           // the loads first (clamped, unconditional): in flight together
+        const float4 v1 = s4[min(e1, nv - 1)];
+        const float4 v2 = s4[min(e2, nv - 1)];
+        const float4 v3 = s4[min(e3, nv - 1)];
+        if (e0 < nv) d4[e0] = v0;
+        if (e1 < nv) d4[e1] = v1;
+        if (e2 < nv) d4[e2] = v2;
+        if (e3 < nv) d4[e3] = v3;
     } else {
         const int base = blockIdx.x * (MC_THREADS * MC_VEC_PER_THREAD * 4);
         for (int e = base + threadIdx.x; e < min(A.row_floats, base + MC_THREADS * MC_VEC_PER_THREAD * 4); e += MC_THREADS)

@@ -87,6 +87,9 @@ _SIGNATURES = {
                                              _vp, _i, _vp]),
     "smot_track_solve_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
                                             _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "smot_track_solve_carry_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _f, _i,
+                                                  _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                  _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES.keys())
 _DEBUG_SIGNATURES = {
@@ -914,7 +917,7 @@ class HostRecordRing(object):
 
 
 def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_frames, pool_state, pool_capacity,
-                host_record=False):
+                host_record=False, carry=None):
     """``smot_track_solve_fwd``: one launch for TrackSolver.forward + the pool transitions + the active-row filter.
 
     det / trk: ``(boxes [n,4] xyxy, scores [n], ids [n] int64, labels [n] int64 or None)`` device tensors or ``None``
@@ -924,7 +927,10 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     (``rec[0]`` = K, ``rec[1]`` = A, ...: include/smot_emm.h); ``track_solve_record(rec)`` brings it to the host.
     ``host_record=ring`` (a ``HostRecordRing``): the kernel writes the record straight into the ring's next pinned
     host buffer (``rec`` is then that host tensor; ``ring.record_event()`` behind this launch, ``ring.wait(rec)`` to
-    read it — no copy command; the count of active rows for device-side consumers is ``pool_state[4:5]``)."""
+    read it — no copy command; the count of active rows for device-side consumers is ``pool_state[4:5]``).
+    ``carry`` = (source addresses (templates, boxes, search regions, ids, labels, scores), first source row, rows, guessed
+    first destination row, next_templates address, next_sr address, row_floats): ``smot_track_solve_carry_fwd`` — the
+    dormant rows of the track memory go behind the active rows in this launch."""
     lib = _lib or load_library()
     segs = []
     dev = pool_state.device
@@ -945,12 +951,22 @@ def track_solve(det, trk, trk_score_bias, thresholds, nms_thresh, max_dormant_fr
     if cur != dev.index:
         torch.cuda.set_device(dev.index)
     try:
-        rc = lib.smot_track_solve_fwd(segs[0][0], segs[0][1], segs[0][2], segs[0][3], segs[0][4],
-                                      segs[1][0], segs[1][1], segs[1][2], segs[1][3], segs[1][4], trk_score_bias,
-                                      thresholds[0], thresholds[1], thresholds[2], nms_thresh, max_dormant_frames,
-                                      pool_state.data_ptr(), pool_capacity,
-                                      fp, fp + 32 * M, ip, ip + 8 * M, fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,
-                                      rec.data_ptr(), _stream(dev))
+        if carry is None:
+            rc = lib.smot_track_solve_fwd(segs[0][0], segs[0][1], segs[0][2], segs[0][3], segs[0][4],
+                                          segs[1][0], segs[1][1], segs[1][2], segs[1][3], segs[1][4], trk_score_bias,
+                                          thresholds[0], thresholds[1], thresholds[2], nms_thresh, max_dormant_frames,
+                                          pool_state.data_ptr(), pool_capacity,
+                                          fp, fp + 32 * M, ip, ip + 8 * M, fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,
+                                          rec.data_ptr(), _stream(dev))
+        else:
+            src, row0, rows, dst0, nz, nsr, row_floats = carry
+            rc = lib.smot_track_solve_carry_fwd(segs[0][0], segs[0][1], segs[0][2], segs[0][3], segs[0][4],
+                                                segs[1][0], segs[1][1], segs[1][2], segs[1][3], segs[1][4], trk_score_bias,
+                                                thresholds[0], thresholds[1], thresholds[2], nms_thresh, max_dormant_frames,
+                                                pool_state.data_ptr(), pool_capacity,
+                                                fp, fp + 32 * M, ip, ip + 8 * M, fp + 16 * M, ip + 16 * M, ip + 24 * M,
+                                                fp + 36 * M, rec.data_ptr(), src[0], src[1], src[2], src[3], src[4], src[5],
+                                                int(row0), int(rows), int(dst0), nz, nsr, int(row_floats), _stream(dev))
     finally:
         if cur != dev.index:
             torch.cuda.set_device(cur)
@@ -1131,18 +1147,20 @@ _FRAME_PTRS = ("feats", "heights", "widths", "pad_cells", "scales", "predictor_p
                "refine_ws", "ref_boxes", "ref_scores", "ref_ids", "ref_labels",
                "det_boxes", "det_scores", "det_ids", "det_labels",
                "out_boxes", "out_scores", "out_ids", "out_labels", "act_boxes", "act_ids", "act_labels", "act_scores",
-               "record", "next_templates", "next_sr", "next_order_hint")
+               "record", "next_templates", "next_sr", "next_order_hint",
+               # dormant rows carried by the solver's launch (STAGE_CARRY)
+               "carry_templates", "carry_boxes", "carry_sr", "carry_ids", "carry_labels", "carry_scores")
 _FRAME_INTS = ("n_trk", "stages", "n_det", "num_levels", "C", "rx", "rz", "sampling_ratio", "gn_groups", "up",
                "use_centerness", "refine", "box_pooled", "box_sampling_ratio", "dim6", "dim7", "num_classes", "reg_classes",
-               "tracktor", "max_dormant_frames", "pool_capacity")
+               "tracktor", "max_dormant_frames", "pool_capacity", "carry_src_row0", "carry_rows", "carry_dst_row0")
 _FRAME_FLOATS = ("track_thresh", "start_thresh", "resume_thresh", "gn_eps", "pad_pixels", "one_minus_sigma", "sigma",
                  "clip_w", "clip_h", "box_wx", "box_wy", "box_ww", "box_wh", "box_xform_clip",
                  "nms_thresh", "search_expansion", "min_search_wh")
-STAGE_HEAD, STAGE_REFINE, STAGE_SOLVE, STAGE_EXTRACT = 1, 2, 4, 8
+STAGE_HEAD, STAGE_REFINE, STAGE_SOLVE, STAGE_EXTRACT, STAGE_CARRY = 1, 2, 4, 8, 16
 
 
 class FrameArgs(object):
-    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 46 pointers, 21 ints, 17 floats, in the header's
+    """``smot_frame_args`` of include/smot_emm.h as one byte buffer: 52 pointers, 24 ints, 17 floats, in the header's
     order.  Fields are plain Python attributes (``__slots__``); ``pack()`` writes all of them with one ``struct.pack_into``
     (a ctypes.Structure costs ~0.4 us per field assignment).  The fields that change from frame to frame are contiguous
     inside each group: ``poke_head`` / ``poke_rest`` rewrite only those ranges of a block that was packed once."""
@@ -1155,7 +1173,9 @@ class FrameArgs(object):
     _HEAD_FMT = struct.Struct("<%dQ" % (_HEAD1 - _HEAD0))
     _REST_FMT = struct.Struct("<%dQ" % (_REST1 - _HEAD1))
     _II = struct.Struct("<ii")
+    _III = struct.Struct("<iii")
     _FFF = struct.Struct("<fff")
+    _CARRY_INT0 = _INT0 + 4 * _FRAME_INTS.index("carry_src_row0")
 
     def __init__(self):
         for n in _FRAME_PTRS + _FRAME_INTS:
@@ -1178,11 +1198,12 @@ class FrameArgs(object):
         self._II.pack_into(self._buf, self._INT0, n_trk, stages)
         return self._addr
 
-    def poke_rest(self, ptrs, stages, n_det, thresholds):
-        """Rewrite the per-frame pointers behind the head's (``refine_ws`` .. ``next_order_hint``), ``stages``,
-        ``n_det`` and the three solver thresholds."""
+    def poke_rest(self, ptrs, stages, n_det, thresholds, carry=(0, 0, 0)):
+        """Rewrite the per-frame pointers behind the head's (``refine_ws`` .. ``carry_scores``), ``stages``,
+        ``n_det``, the three solver thresholds and ``carry`` = (carry_src_row0, carry_rows, carry_dst_row0)."""
         self._REST_FMT.pack_into(self._buf, 8 * self._HEAD1, *ptrs)
         self._II.pack_into(self._buf, self._INT0 + 4, stages, n_det)
+        self._III.pack_into(self._buf, self._CARRY_INT0, *carry)
         self._FFF.pack_into(self._buf, self._FLT0, *thresholds)
         return self._addr
 

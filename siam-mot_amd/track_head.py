@@ -669,11 +669,26 @@ class TrackingLoop(torch.nn.Module):
                 rw = ops._workspace(dev, need[1], ("refine", stream.value)).data_ptr()
                 r0, r1, r2, r3 = p + 20 * n_trk, p + 36 * n_trk, ti.data_ptr(), ti.data_ptr() + 8 * n_trk
                 stages |= ops.STAGE_REFINE
+        # the dormant rows of the memory this frame's head ran on go behind the rows the solver leaves active, in the solver's
+        # own launch (extra workgroups beside its one: no launch, no time on the chain) — on the guess that the dormant
+        # tracks stay the ones they were and the active count what it was (the usual frame); _carry_dormant checks both
+        # against the record and copies again, with the stand-alone kernel, when the guess did not hold
+        carried_ahead = None
+        cz = cb = cs = ci = cl = cc = 0
+        carry = (0, 0, 0)
+        if (type(mem) is _LazyMemory and mem.A > mem.n_act and self.__dict__.get("device_carry", True)
+                and (P.C * P.rz * P.rz) % 4 == 0 and self.__dict__.get("carry_in_solver", True)):
+            cz, cb, cs, ci, cl, cc = mem.carry_pointers()
+            carry = (mem.n_act, mem.A - mem.n_act, mem.n_act)
+            carried_ahead = (list(range(mem.n_act, mem.A)), mem.n_act)
+            stages |= ops.STAGE_CARRY
+            ops.MEMORY_CARRY["in_the_solver_launch"] += 1
         addr = a.poke_rest((rw, r0, r1, r2, r3, d0, d1, d2, d3,
                             fp, fp + 32 * M, ip, ip + 8 * M,                       # out_boxes, out_scores, out_ids, out_labels
                             fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,    # act_boxes, act_ids, act_labels, act_scores
-                            rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), (fp + 4 * hint_off) if hint_off else 0),
-                           stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh))
+                            rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), (fp + 4 * hint_off) if hint_off else 0,
+                            cz, cb, cs, ci, cl, cc),
+                           stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh), carry)
         ops.track_frame_addr(P.lib, addr, dev, stream)
         if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
             hook = emm.__dict__.get("raw_output_hook")
@@ -685,7 +700,8 @@ class TrackingLoop(torch.nn.Module):
                     hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
         spec_tf = None
-        carried_ahead = self._carry_ahead(mem, fbuf, ibuf, templates, sr_next, M, state, dev, stream, P.lib)
+        if carried_ahead is None:
+            carried_ahead = self._carry_ahead(mem, fbuf, ibuf, templates, sr_next, M, state, dev, stream, P.lib)
         # (a wrong guess costs the GPU a whole head: the guess is made only while the count has been holding — this frame
         # had as many tracks as the frame before)
         steady = self.__dict__.get("_prev_n_trk") == n_trk

@@ -353,9 +353,10 @@ def test_frame_args_buffer_matches_the_header_struct():
     head = P[P.index("head_ws"):P.index("trk_conf") + 1]
     rest = P[P.index("trk_conf") + 1:]
     assert head == ("head_ws", "tpl_boxes", "sr", "templates", "order_hint", "trk_ids", "trk_labels", "trk_boxes", "trk_conf")
-    assert rest[0] == "refine_ws" and rest[-1] == "next_order_hint" and len(rest) == 21
+    assert rest[0] == "refine_ws" and rest[20] == "next_order_hint" and rest[-1] == "carry_scores" and len(rest) == 27
     a.poke_head(tuple(1000 + i for i in range(len(head))), 11, ops.STAGE_HEAD)
-    a.poke_rest(tuple(2000 + i for i in range(len(rest))), ops.STAGE_SOLVE | ops.STAGE_EXTRACT, 5, (0.25, 0.5, 0.75))
+    a.poke_rest(tuple(2000 + i for i in range(len(rest))), ops.STAGE_SOLVE | ops.STAGE_EXTRACT, 5, (0.25, 0.5, 0.75),
+                carry=(24, 6, 24))
     v2 = ops.FrameArgs._FMT.unpack_from(a._buf, 0)
     want = list(vals)
     for i, n in enumerate(head):
@@ -363,10 +364,13 @@ def test_frame_args_buffer_matches_the_header_struct():
     for i, n in enumerate(rest):
         want[P.index(n)] = 2000 + i
     want[len(P) + I.index("n_trk")], want[len(P) + I.index("stages")], want[len(P) + I.index("n_det")] = 11, 12, 5
+    for n, x in zip(("carry_src_row0", "carry_rows", "carry_dst_row0"), (24, 6, 24)):
+        want[len(P) + I.index(n)] = x
     for n, x in zip(("track_thresh", "start_thresh", "resume_thresh"), (0.25, 0.5, 0.75)):
         want[len(P) + len(I) + F.index(n)] = x
     assert list(v2) == want
     src_c = open(os.path.join(ROOT, "include", "smot_emm.h")).read()
     for name, val in (("SMOT_STAGE_HEAD", ops.STAGE_HEAD), ("SMOT_STAGE_REFINE", ops.STAGE_REFINE),
-                      ("SMOT_STAGE_SOLVE", ops.STAGE_SOLVE), ("SMOT_STAGE_EXTRACT", ops.STAGE_EXTRACT)):
+                      ("SMOT_STAGE_SOLVE", ops.STAGE_SOLVE), ("SMOT_STAGE_EXTRACT", ops.STAGE_EXTRACT),
+                      ("SMOT_STAGE_CARRY", ops.STAGE_CARRY)):
         assert re.search(r"#define\s+%s\s+%d\b" % (name, val), src_c), name

@@ -710,6 +710,102 @@ def test_memory_carry_copies_the_named_rows(row_shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("guess", [5, 2, 9])
+def test_solver_launch_carries_the_dormant_rows(guess):
+    """``smot_track_solve_carry_fwd``: the solver's own results are those of the plain launch bit for bit; the dormant rows'
+    boxes / ids / labels / scores stand behind the active rows it determined (whatever the caller guessed); their templates
+    and search regions stand at the GUESSED rows (right when the guess equals the count; a wrong guess is the caller's to
+    repair, smot_memory_carry_fwd) and nothing else of the next memory's buffers is written."""
+    import siammot_amd.ops as ops
+    from siammot_amd.solver import TrackPool
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    n_det, n_src, D, row0 = 5, 7, 3, 2
+    row_shape = (32, 15, 15)
+    rf = int(np.prod(row_shape))
+    det_boxes = torch.tensor([[10 + 200 * i, 20, 90 + 200 * i, 180] for i in range(n_det)], dtype=torch.float32, device=dev)
+    src = [torch.randn((n_src,) + row_shape, generator=g), torch.randn(n_src, 4, generator=g), torch.randn(n_src, 4, generator=g),
+           torch.randint(0, 1 << 40, (n_src,), generator=g), torch.randint(0, 9, (n_src,), generator=g), torch.rand(n_src, generator=g)]
+    src = [t.to(dev) for t in src]
+    cap = TrackPool.DEVICE_CAPACITY
+
+    def solve(carry):
+        state = torch.zeros(8 + 3 * cap, dtype=torch.int32, device=dev)
+        state[0] = -1
+        det = (det_boxes, torch.full((n_det,), 0.9, device=dev), torch.full((n_det,), -1, dtype=torch.int64, device=dev),
+               torch.ones(n_det, dtype=torch.int64, device=dev))
+        nz = torch.full((n_det,) + row_shape, -7.0, device=dev)
+        nsr = torch.full((n_det, 4), -7.0, device=dev)
+        c = None
+        if carry:
+            c = ([t.data_ptr() for t in src], row0, D, guess, nz.data_ptr(), nsr.data_ptr(), rf)
+        fbuf, ibuf, rec, M = ops.track_solve(det, None, 1.0, (0.4, 0.6, 0.4), 0.5, 3, state, cap, carry=c)
+        torch.cuda.synchronize()
+        return fbuf.clone(), ibuf.clone(), rec.cpu().numpy().copy(), M, nz, nsr, state.cpu()
+    f0, i0, r0, M, nz0, nsr0, st0 = solve(False)
+    f1, i1, r1, _, nz1, nsr1, st1 = solve(True)
+    K, A = int(r0[0]), int(r0[1])
+    assert K == n_det and A == n_det and M == n_det          # five far-apart detections start five tracks
+    assert np.array_equal(r0, r1) and torch.equal(st0, st1)
+    # the plain launch's outputs, untouched: kept rows, active rows (the buffers' other words are uninitialised)
+    for off, n in ((0, 4 * K), (4 * M, 4 * A), (8 * M, K), (9 * M, A)):
+        assert torch.equal(f0[off:off + n], f1[off:off + n])
+    for off, n in ((0, K), (M, K), (2 * M, A), (3 * M, A)):
+        assert torch.equal(i0[off:off + n], i1[off:off + n])
+    # (capacity M = 5 rows: behind five active rows there is no room — nothing may be written beyond the buffers; the rows
+    # that fit are checked with a guess below the count, where the templates land on rows the extraction overwrites later)
+    want_z, want_sr = torch.full_like(nz1, -7.0), torch.full_like(nsr1, -7.0)
+    for j in range(D):
+        if guess + j < M:
+            want_z[guess + j] = src[0][row0 + j]
+            want_sr[guess + j] = src[2][row0 + j]
+    assert torch.equal(nz1, want_z) and torch.equal(nsr1, want_sr)
+    assert torch.equal(nz0, torch.full_like(nz0, -7.0))
+
+
+@pytest.mark.gpu
+def test_solver_launch_appends_the_dormant_rows_behind_the_active_count():
+    """The same with room behind the active rows: eight detections of which the NMS keeps five (three sit on top of
+    others), none below the start threshold -> five active rows, capacity eight: the three carried rows' boxes / ids /
+    labels / scores stand at rows 5 .. 7 of the act_* arrays, their templates / search regions at the guessed rows."""
+    import siammot_amd.ops as ops
+    from siammot_amd.solver import TrackPool
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    n_src, D, row0 = 9, 3, 4
+    row_shape = (128, 7, 7)
+    rf = int(np.prod(row_shape))
+    b = [[10 + 200 * i, 20, 90 + 200 * i, 180] for i in range(5)] + [[12 + 200 * i, 22, 92 + 200 * i, 182] for i in range(3)]
+    det_boxes = torch.tensor(b, dtype=torch.float32, device=dev)
+    scores = torch.tensor([0.9] * 5 + [0.8] * 3, device=dev)
+    src = [torch.randn((n_src,) + row_shape, generator=g), torch.randn(n_src, 4, generator=g), torch.randn(n_src, 4, generator=g),
+           torch.randint(0, 1 << 40, (n_src,), generator=g), torch.randint(0, 9, (n_src,), generator=g), torch.rand(n_src, generator=g)]
+    src = [t.to(dev) for t in src]
+    cap = TrackPool.DEVICE_CAPACITY
+    for guess in (5, 4):
+        state = torch.zeros(8 + 3 * cap, dtype=torch.int32, device=dev)
+        state[0] = -1
+        det = (det_boxes, scores.clone(), torch.full((8,), -1, dtype=torch.int64, device=dev), torch.ones(8, dtype=torch.int64, device=dev))
+        nz = torch.full((8,) + row_shape, -7.0, device=dev)
+        nsr = torch.full((8, 4), -7.0, device=dev)
+        fbuf, ibuf, rec, M = ops.track_solve(det, None, 1.0, (0.4, 0.6, 0.4), 0.5, 3, state, cap,
+                                             carry=([t.data_ptr() for t in src], row0, D, guess, nz.data_ptr(), nsr.data_ptr(), rf))
+        torch.cuda.synchronize()
+        r = rec.cpu().numpy()
+        K, A = int(r[0]), int(r[1])
+        assert (K, A, M) == (5, 5, 8) and int(state[4]) == 5
+        act_boxes, act_scores = fbuf[4 * M:8 * M].view(M, 4), fbuf[9 * M:10 * M]
+        act_ids, act_labels = ibuf[2 * M:3 * M], ibuf[3 * M:4 * M]
+        sel = slice(row0, row0 + D)
+        assert torch.equal(act_boxes[A:A + D], src[1][sel]) and torch.equal(act_scores[A:A + D], src[5][sel])
+        assert torch.equal(act_ids[A:A + D], src[3][sel]) and torch.equal(act_labels[A:A + D], src[4][sel])
+        assert act_ids[:A].tolist() == [0, 1, 2, 3, 4]
+        want_z, want_sr = torch.full_like(nz, -7.0), torch.full_like(nsr, -7.0)
+        want_z[guess:guess + D], want_sr[guess:guess + D] = src[0][sel], src[2][sel]
+        assert torch.equal(nz, want_z) and torch.equal(nsr, want_sr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("native", [True, False])
 def test_lean_step_equals_general_path(native):
     """TrackingLoop's lean per-frame step (raw tensors, masked template extraction before the synchronisation, lazy
