@@ -746,7 +746,12 @@ def test_solver_launch_carries_the_dormant_rows(guess):
     f1, i1, r1, _, nz1, nsr1, st1 = solve(True)
     K, A = int(r0[0]), int(r0[1])
     assert K == n_det and A == n_det and M == n_det          # five far-apart detections start five tracks
-    assert np.array_equal(r0, r1) and torch.equal(st0, st1)
+    # (record and state are compared where the launch defines them: header, kept rows, final ids, active ids, the id table)
+    na = int(r0[4])
+    assert na == n_det and int(r0[5]) == 0
+    for lo, n in ((0, 8), (8, K), (8 + M, K), (8 + 2 * M, A), (8 + 3 * M, na)):
+        assert np.array_equal(r0[lo:lo + n], r1[lo:lo + n]), lo
+    assert torch.equal(st0[:5], st1[:5]) and torch.equal(st0[8:8 + na], st1[8:8 + na])
     # the plain launch's outputs, untouched: kept rows, active rows (the buffers' other words are uninitialised)
     for off, n in ((0, 4 * K), (4 * M, 4 * A), (8 * M, K), (9 * M, A)):
         assert torch.equal(f0[off:off + n], f1[off:off + n])
