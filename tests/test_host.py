@@ -37,6 +37,7 @@ def test_library_exports_every_declared_symbol():
     ops.load_library()
     assert lib.smot_abi_version() == ops.ABI_VERSION
     assert lib.smot_build_info() == 0                     # the product library is not a measurement build
+    assert lib.smot_memory_carry_max_rows() == ops.MEMORY_CARRY_MAX_ROWS     # (the binding's row array has that many entries)
     assert not hasattr(lib, "smot_debug_set_knob")
 
 
