@@ -768,11 +768,16 @@ def main():
         keep = ("value", "unit", "ms_per_frame", "tracked_in_last_frame", "track_count_held", "active_tracks", "dormant_tracks",
                 "memory_rows", "dormant_rows", "frame_entry_point_frames", "frames", "speculative_heads")
         nd = max(1, n // 5)
+        import siammot_amd.ops as _ops
+        fb_before = dict(_ops.FALLBACKS)          # (a carried memory has no order hint: its heads count as `unhinted_head`
         wd = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd).items() if k in keep}
         wd["host_form"] = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd, device_carry=False).items()
                            if k in keep}
         wd["next_frame_shown"] = {k: v for k, v in tracking_loop_throughput(n, dev, feats, dormant=nd, ahead=True).items()
                                   if k in keep}
+        wd["fallbacks"] = {k: v - fb_before.get(k, 0) for k, v in _ops.FALLBACKS.items() if v != fb_before.get(k, 0)}
+        _ops.FALLBACKS.clear()                    #  — reported here, not among the headline's fallbacks)
+        _ops.FALLBACKS.update(fb_before)
         loop_stats["with_dormant_tracks"] = wd
     # host cost of a step: the time to ENQUEUE frame pairs (no synchronisation), measured outside the timed region on
     # a burst short enough for the stream's queue; next to the GPU time per step it says how much host headroom a
