@@ -56,8 +56,12 @@ template <int HO>
 __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], const int (&boff)[ConvGeom<HO>::NTW],
                                                int my_tiles, const float (&hwv)[9], const TowerParams& P, int tower,
                                                int oc0, int cpg, float eps, float* sm, float* chs,
-                                               float* __restrict__ dst, int tid, int lane, int wave, int kq, int xl) {
+                                               float* __restrict__ dst, int tid, int lane, int wave, int kq, int xl,
+                                               long long* tr = nullptr) {
     using G = ConvGeom<HO>;
+    // phase trace (smot_debug_trace): s_memtime stamps 1 .. 5 of this workgroup, or nothing
+#define CT_TRACE(SLOT) \
+    if (tr && tid == 0) tr[SLOT] = (long long)__builtin_amdgcn_s_memtime();
     // ---- GroupNorm (two-pass, fp32) + affine + ReLU -------------------------------------------------------------
     // acc[t][r] = conv output of channel oc0 + 4*kq + r at position 16*(wave + 4t) + xl
     bool valid[G::NTW];
@@ -78,6 +82,7 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
             if (xl == 0) chs[wave * 16 + 4 * kq + r] = s[r];
         }
         __syncthreads();
+        CT_TRACE(1)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g0 = ((4 * kq + r) / cpg) * cpg;
@@ -101,6 +106,7 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
             if (xl == 0) chs[64 + wave * 16 + 4 * kq + r] = q[r];
         }
         __syncthreads();
+        CT_TRACE(2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g0 = ((4 * kq + r) / cpg) * cpg;
@@ -133,6 +139,7 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
             }
     }
     __syncthreads();
+    CT_TRACE(3)
 
     // ---- fused partial heads: 16 channels x 9 taps -> 4 head outputs per position, 64 positions per group ---------
     // A wave's groups (g = wave, wave + 4, ...: up to NGW of them) run SIDE BY SIDE: one accumulator chain per group — a
@@ -161,6 +168,7 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
     C_HEAD16(0) C_HEAD16(1) C_HEAD16(2) C_HEAD16(3) C_HEAD16(4) C_HEAD16(5) C_HEAD16(6) C_HEAD16(7) C_HEAD16(8)
 #undef C_HEAD16
 #undef C_HEAD
+    CT_TRACE(4)
 #pragma unroll
     for (int q = 0; q < NGW; ++q) {
         const int p = 64 * (wave + 4 * q) + lane;
@@ -171,6 +179,8 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
             dst[3 * G::HW + p] = hacc[q][3];
         }
     }
+    CT_TRACE(5)
+#undef CT_TRACE
 }
 
 template <int HO>
@@ -312,7 +322,7 @@ tower_conv_mfma_kernel(const float* __restrict__ resp, TowerParams P, int C, int
 // them; this workgroup has them in registers): part[(n*tiles + tile) * 16 * HW + o * HW + p], tile stride 16 * HW.
 template <int HO>
 __global__ void __launch_bounds__(256, 2)
-tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int cpg, float eps) {
+tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int cpg, float eps, long long* trace) {
     using G = ConvGeom<HO>;
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [16][PLANE] + [128]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -324,6 +334,10 @@ tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int n = (slot / (2 * tiles_per_tower)) * 8 + xcd;
     if (n >= N) return;
+    // [grid][8] behind 65,536 workgroups' worth of slots (the other kernels of a head launch stamp the buffer's front):
+    // start, sums, squares, planes, heads, end
+    long long* tr = trace ? trace + ((size_t)65536 + blockIdx.x) * 8 : nullptr;
+    if (tr && tid == 0) tr[0] = (long long)__builtin_amdgcn_s_memtime();
     const int rem = slot % (2 * tiles_per_tower);
     const int tower = rem / tiles_per_tower;
     const int oc0 = (rem - tower * tiles_per_tower) * 16;
@@ -352,7 +366,7 @@ tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int
     }
     __builtin_amdgcn_sched_barrier(0);
     conv_tile_tail<HO>(acc, boff, my_tiles, hwv, P, tower, oc0, cpg, eps, sm, sm + 16 * G::PLANE, base, tid, lane, wave, kq,
-                       xl);
+                       xl, tr);
 }
 
 // logits[n][ch][pos] = bias[ch] + sum over the tower's tiles of the partial head sums (fixed tile order), ReLU on the
@@ -421,7 +435,7 @@ int launch_tower_conv_wino(const float* resp, const float* packed, const TowerPa
                                      "predictor GroupNorm + heads (Ho=29)");
     if (rco) return rco;
     hipLaunchKernelGGL(tower_gn_heads_kernel<29>, dim3(((N + 7) / 8) * 8 * 2 * (C / 16)), dim3(256), smem, st, tower_ws, P, N, C,
-                       cpg, eps);
+                       cpg, eps, g_trace);
     rc = check_launch("predictor GroupNorm + heads (Ho=29)");
     if (rc) return rc;
     hipLaunchKernelGGL(heads_combine_hw_kernel, dim3(N, 7, (G::HW + 255) / 256), dim3(256), 0, st,
