@@ -52,7 +52,23 @@ struct ConvGeom {
 // tower_conv_mfma_kernel (accumulators straight from its main loop) and tower_gn_heads_kernel (convolution output of
 // the blocked Winograd kernel, re-loaded).  sm: 16 zero-haloed planes + 128 floats of channel sums; every wave is past its
 // last use of sm when it gets here.  part_tile: where this tile's four partial head planes go.
+// Zero the one-cell halo of the 16 LDS planes (every interior cell is written by the tail): 4 * (HO + 1) cells per plane
+// instead of (HO + 2)^2.
 template <int HO>
+__device__ __forceinline__ void conv_zero_halo(float* hp, int tid) {
+    using G = ConvGeom<HO>;
+    for (int e = tid; e < 16 * 4 * (HO + 1); e += 256) {
+        const int pl = e / (4 * (HO + 1)), c = e - pl * 4 * (HO + 1);
+        const int side = c / (HO + 1), k = c - side * (HO + 1);          // four runs of HO + 1 cells around the plane
+        const int y = side == 0 ? 0 : (side == 1 ? HO + 1 : (side == 2 ? 1 + k : k));
+        const int x = side == 0 ? k : (side == 1 ? 1 + k : (side == 2 ? 0 : HO + 1));
+        hp[pl * G::PLANE + y * G::PW + x] = 0.0f;
+    }
+}
+
+// HALO_DONE: the caller zeroed the halo already (conv_zero_halo, on planes no wave still uses otherwise) — the loop and
+// its barrier are skipped (tower_gn_heads_kernel does it in the shadow of its loads).
+template <int HO, bool HALO_DONE = false>
 __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], const int (&boff)[ConvGeom<HO>::NTW],
                                                int my_tiles, const float (&hwv)[9], const TowerParams& P, int tower,
                                                int oc0, int cpg, float eps, float* sm, float* chs,
@@ -118,15 +134,10 @@ __device__ __forceinline__ void conv_tile_tail(f32x4 (&acc)[ConvGeom<HO>::NTW], 
     }
     // ---- normalised tile -> zero-haloed LDS planes (over the stage buffers: every wave is past its last MFMA) -----
     float* hp = sm;
-    // only the halo needs zeros (every interior cell is written below): 4 * (HO + 1) cells per plane instead of (HO + 2)^2
-    for (int e = tid; e < 16 * 4 * (HO + 1); e += 256) {
-        const int pl = e / (4 * (HO + 1)), c = e - pl * 4 * (HO + 1);
-        const int side = c / (HO + 1), k = c - side * (HO + 1);          // four runs of HO + 1 cells around the plane
-        const int y = side == 0 ? 0 : (side == 1 ? HO + 1 : (side == 2 ? 1 + k : k));
-        const int x = side == 0 ? k : (side == 1 ? 1 + k : (side == 2 ? 0 : HO + 1));
-        hp[pl * G::PLANE + y * G::PW + x] = 0.0f;
+    if constexpr (!HALO_DONE) {
+        conv_zero_halo<HO>(hp, tid);
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int oc = 4 * kq + r;
@@ -327,6 +338,7 @@ tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int
     extern __shared__ __attribute__((aligned(16))) float sm[];       // [16][PLANE] + [128]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __builtin_assume(wave >= 0 && wave < 4);                         // (lets the tail's position masks fold for all but the last tile)
     const int kq = lane >> 4, xl = lane & 15;
     const int tiles_per_tower = C >> 4;
     // consecutive workgroup ids go round-robin over the 8 XCDs: a track's workgroups run on the XCD whose L2 the blocked
@@ -365,8 +377,12 @@ tower_gn_heads_kernel(float* __restrict__ conv, TowerParams P, int N, int C, int
         for (int r = 0; r < 4; ++r) acc[t][r] = base[(size_t)(4 * kq + r) * G::HW + p];
     }
     __builtin_amdgcn_sched_barrier(0);
-    conv_tile_tail<HO>(acc, boff, my_tiles, hwv, P, tower, oc0, cpg, eps, sm, sm + 16 * G::PLANE, base, tid, lane, wave, kq,
-                       xl, tr);
+    // the planes' halo while the loads are in flight (round 4's phase trace: the planes phase was 11.4 k of a workgroup's
+    // 37.9 k cycles, the halo loop ~2.5 k of them on the critical path); the tail's barriers order it before the heads read
+    conv_zero_halo<HO>(sm, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    conv_tile_tail<HO, true>(acc, boff, my_tiles, hwv, P, tower, oc0, cpg, eps, sm, sm + 16 * G::PLANE, base, tid, lane, wave,
+                             kq, xl, tr);
 }
 
 // logits[n][ch][pos] = bias[ch] + sum over the tower's tiles of the partial head sums (fixed tile order), ReLU on the
