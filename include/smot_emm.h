@@ -523,6 +523,9 @@ int smot_track_solve_carry_fwd(const float* det_boxes, float* det_scores, const 
  * stage are the inputs of the next (the propagated boxes / scores feed the refinement or the solver, the solver's
  * act_boxes and pool_state[4] feed the masked template extraction).  n_trk == 0 skips the head and the refinement
  * (first frame, or an empty memory); refine == 0 skips the refinement (the solver then applies trk_score_bias = 1).
+ * SMOT_STAGE_CARRY (with SMOT_STAGE_SOLVE; never part of stages == 0) makes the solver's launch carry the dormant rows
+ * of the track memory the head ran on (the carry_* fields: smot_track_solve_carry_fwd; next_templates / next_sr are the
+ * destination buffers, row_floats = C * rz * rz).
  * `stages` selects what this call enqueues (0 = everything): a frame is a serial chain — host work before the first
  * launch, the kernels, the record, host bookkeeping — so a caller whose argument preparation is not free calls once
  * with SMOT_STAGE_HEAD as soon as the head's arguments stand (fields of later stages are not read) and a second time
