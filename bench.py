@@ -29,7 +29,10 @@ The JSON line also carries:
                  `xcorr_op` = the stand-alone operator (figure A of §8(d)) timed the same way.
   roofline_tower / roofline_path — the towers against the fp32 matrix pipe (executed multiply-adds), the whole frame
                  pair against HBM (compulsory bytes / ms_per_step).
-  tracking_loop — head + solver + memory per frame, with and without box-head refinement, track count asserted.
+  tracking_loop — head + solver + memory per frame, with and without box-head refinement, track count asserted;
+                 `next_frame_shown`: the same with every call shown the next frame's features (speculative next-frame
+                 head); `with_dormant_tracks`: a fifth of the tracks dormant — their rows of the memory copied on the
+                 device, in the reference's host form, and with the next frame shown.
   cpu_baseline — the CPU oracle (oracle/emm_oracle.py, the reference's torch-CPU ops) timed on this
                  host's cores on the same workload (rank 0, N=1 only), bounded to ~10-20 s.
   parity       — the LAST result of the timed loop compared, outside the timed region, with the CPU oracle on the
