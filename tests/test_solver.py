@@ -371,6 +371,183 @@ def test_lean_frame_bookkeeping_with_carried_dormant_rows_equals_the_general_pat
     assert ops_.FALLBACKS["dormant_rows_on_the_host"] == fb0 and lazy_frames >= 170, (lazy_frames,)
 
 
+class _FrameEntryEmulation(object):
+    """``smot_track_frame_fwd`` on CPU memory — test infrastructure: the argument block is read as the library reads it
+    (include/smot_emm.h, ``ops.FrameArgs``) and the stages it selects run on the arrays its pointers name — the head as the
+    fake tracker (boxes + 2, a score hashed from the id), the solver as ``_HostEmulation.track_solve`` (twin host solver),
+    SMOT_STAGE_CARRY as csrc/track_solver.hip does it (small fields behind the count the solver determined, templates and
+    search regions at the caller's guess), the masked extraction as the fake tracker's.  Calls execute in the order they
+    are made: the stream order of the real thing."""
+
+    def __init__(self, host_emu, pad, row_floats):
+        import siammot_amd.ops as ops_
+        self.ops, self.host, self.pad, self.rf = ops_, host_emu, pad, row_floats
+        self.names = ops_._FRAME_PTRS + ops_._FRAME_INTS + ops_._FRAME_FLOATS
+        self.heads = self.carried = 0
+
+    @staticmethod
+    def _arr(ptr, n, ctype, dtype):
+        import ctypes
+        return np.frombuffer((ctype * n).from_address(ptr), dtype=dtype) if n > 0 else np.zeros(0, dtype)
+
+    def f32(self, ptr, n):
+        import ctypes
+        return self._arr(ptr, n, ctypes.c_float, np.float32)
+
+    def i64(self, ptr, n):
+        import ctypes
+        return self._arr(ptr, n, ctypes.c_int64, np.int64)
+
+    def __call__(self, lib, addr, dev, stream):
+        import ctypes
+        ops_ = self.ops
+        fmt = ops_.FrameArgs._FMT
+        a = dict(zip(self.names, fmt.unpack_from((ctypes.c_char * fmt.size).from_address(addr))))
+        stages, n_trk, n_det, rf = a["stages"], a["n_trk"], a["n_det"], self.rf
+        assert a["C"] * a["rz"] * a["rz"] == rf
+        if stages & ops_.STAGE_HEAD and n_trk > 0:
+            tb, ids = self.f32(a["tpl_boxes"], 4 * n_trk), torch.from_numpy(self.i64(a["trk_ids"], n_trk).copy())
+            self.f32(a["trk_boxes"], 4 * n_trk)[:] = tb + np.float32(2.0)
+            self.f32(a["trk_conf"], n_trk)[:] = ((((ids * 37) % 100).to(torch.float32) / 100.0) * 0.9 + 0.05).numpy()
+            self.heads += 1
+        if not stages & ops_.STAGE_SOLVE:
+            return
+        M = n_det + n_trk
+        det = trk = None
+        if n_det:
+            det = (torch.from_numpy(self.f32(a["det_boxes"], 4 * n_det).reshape(n_det, 4).copy()),
+                   torch.from_numpy(self.f32(a["det_scores"], n_det).copy()),
+                   torch.from_numpy(self.i64(a["det_ids"], n_det).copy()), torch.from_numpy(self.i64(a["det_labels"], n_det).copy()))
+        if n_trk:
+            trk = (torch.from_numpy(self.f32(a["trk_boxes"], 4 * n_trk).reshape(n_trk, 4).copy()),
+                   torch.from_numpy(self.f32(a["trk_conf"], n_trk).copy()),
+                   torch.from_numpy(self.i64(a["trk_ids"], n_trk).copy()), torch.from_numpy(self.i64(a["trk_labels"], n_trk).copy()))
+        state = torch.zeros(8, dtype=torch.int32)
+        fbuf, ibuf, rec, M2 = self.host.track_solve(det, trk, 1.0, (a["track_thresh"], a["start_thresh"], a["resume_thresh"]),
+                                                    a["nms_thresh"], a["max_dormant_frames"], state, a["pool_capacity"])
+        assert M2 == M
+        fb, ib = fbuf.numpy(), ibuf.numpy()
+        K, A = int(rec[0]), int(rec[1])
+        self.f32(a["out_boxes"], 4 * M)[:4 * K] = fb[:4 * K]
+        self.f32(a["act_boxes"], 4 * M)[:4 * A] = fb[4 * M:4 * M + 4 * A]
+        self.f32(a["out_scores"], M)[:K] = fb[8 * M:8 * M + K]
+        self.f32(a["act_scores"], M)[:A] = fb[9 * M:9 * M + A]
+        self.i64(a["out_ids"], M)[:K] = ib[:K]
+        self.i64(a["out_labels"], M)[:K] = ib[M:M + K]
+        self.i64(a["act_ids"], M)[:A] = ib[2 * M:2 * M + A]
+        self.i64(a["act_labels"], M)[:A] = ib[3 * M:3 * M + A]
+        r = rec.numpy()
+        np.frombuffer((ctypes.c_int32 * len(r)).from_address(a["record"]), dtype=np.int32)[:] = r
+        np.frombuffer((ctypes.c_int32 * 8).from_address(a["pool_state"]), dtype=np.int32)[4] = A
+        nz, nsr = self.f32(a["next_templates"], M * rf).reshape(M, rf), self.f32(a["next_sr"], 4 * M).reshape(M, 4)
+        if stages & ops_.STAGE_CARRY and a["carry_rows"] > 0:
+            r0, D, guess = a["carry_src_row0"], a["carry_rows"], a["carry_dst_row0"]
+            n_src = r0 + D
+            src_z = self.f32(a["carry_templates"], n_src * rf).reshape(n_src, rf)
+            src_b, src_sr = self.f32(a["carry_boxes"], 4 * n_src).reshape(n_src, 4), self.f32(a["carry_sr"], 4 * n_src).reshape(n_src, 4)
+            src_i, src_l, src_s = self.i64(a["carry_ids"], n_src), self.i64(a["carry_labels"], n_src), self.f32(a["carry_scores"], n_src)
+            ab, ai = self.f32(a["act_boxes"], 4 * M).reshape(M, 4), self.i64(a["act_ids"], M)
+            al, asc = self.i64(a["act_labels"], M), self.f32(a["act_scores"], M)
+            for j in range(D):
+                if guess + j < M:                                   # the carrying workgroups: to the caller's guess
+                    nz[guess + j], nsr[guess + j] = src_z[r0 + j], src_sr[r0 + j]
+                if A + j < M:                                       # workgroup 0: behind the count it determined
+                    ab[A + j], ai[A + j], al[A + j], asc[A + j] = src_b[r0 + j], src_i[r0 + j], src_l[r0 + j], src_s[r0 + j]
+            self.carried += 1
+        if stages & ops_.STAGE_EXTRACT:
+            act = self.f32(a["act_boxes"], 4 * M).reshape(M, 4)[:A]
+            nz[:A] = np.repeat(act + np.float32(1000.0), rf // 4, axis=1) if rf != 4 else act + np.float32(1000.0)
+            nsr[:A] = act + np.float32(self.pad)
+
+
+def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(monkeypatch):
+    """``TrackingLoop._step_native`` — the default path: two calls of the frame entry point per frame on a block that stays
+    packed, the next frame's head launched before the record is read when the caller shows the next features, the dormant
+    rows carried inside the solver's launch on a guess — with the library call emulated on CPU memory
+    (``_FrameEntryEmulation`` reads the argument block as the library does), against the general path on 200 frames of
+    churning and calm traffic: outputs identical in every frame, memory and pool identical whenever they are compared
+    (every third frame: looking at a memory builds it, and a built memory takes no speculative head — on purpose), both
+    outcomes of both guesses occur."""
+    import ctypes
+    import types
+    import siammot_amd.ops as ops_
+    from fake_tracker import FakeTracker, detections
+    from siammot_amd.solver import TrackPool, TrackSolver
+    from siammot_amd.track_head import TrackHead, TrackingLoop, _LazyMemory
+    pad, thresholds, max_dormant = 512, (0.4, 0.6, 0.4), 4
+    cap = TrackPool.DEVICE_CAPACITY
+
+    class NativeFake(FakeTracker):
+        rz, rx, pad_pixels, sigma, amodal, use_centerness = 1, 2, pad, 0.4, False, True
+
+        def __init__(self):
+            super(NativeFake, self).__init__(pad)
+            self.track_utils = types.SimpleNamespace(pad_pixels=pad, search_expansion=1.0, min_search_wh=0.0)
+            self.feature_extractor = types.SimpleNamespace(pooler_x=types.SimpleNamespace(scales=(0.25,), sampling_ratio=2))
+            self.predictor = types.SimpleNamespace(param_dict=lambda: {}, gn_groups=1, gn_eps=1e-5)
+
+    loops = []
+    for lean in (True, False):
+        pool = TrackPool(max_dormant_frames=max_dormant)
+        head = TrackHead(NativeFake(), types.SimpleNamespace(pad_pixels=pad), pool).eval()
+        loops.append(TrackingLoop(head, TrackSolver(pool, *thresholds, nms_mask_fn=_numpy_mask)).eval())
+    loops[1]._lean_ok = lambda d: False                     # general path
+    host = _HostEmulation(loops[0], thresholds, max_dormant)
+    emu = _FrameEntryEmulation(host, pad, 4)
+    geom = types.SimpleNamespace(a_fp=0, a_hs=0, a_ws=0, a_pc=0, a_sc=0, L=1, C=4)
+    monkeypatch.setattr(ops_, "_geometry", lambda features, scales, pad_pixels, dev: geom)
+    monkeypatch.setattr(ops_, "_geometry_refresh", lambda g, features, dev: True)
+    monkeypatch.setattr(ops_, "_param_block", lambda params: types.SimpleNamespace(a_pp=4711))
+    monkeypatch.setattr(ops_, "_check_segment", lambda *a: None)
+    monkeypatch.setattr(ops_, "_stream", lambda dev=None: ctypes.c_void_p(0))
+    monkeypatch.setattr(ops_, "load_library", lambda: types.SimpleNamespace(
+        smot_emm_track_ws_floats=lambda *a: 64, smot_box_refine_ws_floats=lambda *a: 0))
+    monkeypatch.setattr(ops_, "track_frame_addr", emu)
+    monkeypatch.setattr(ops_, "memory_carry", host.memory_carry)
+    pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+    state = torch.zeros(8 + 3 * cap, dtype=torch.int32)
+    monkeypatch.setattr(pa, "device_state", lambda dev: state, raising=False)
+
+    class Ring(_HostEmulation.Ring):
+        def next(self):
+            return torch.zeros(8 + 4 * 512 + 3 * cap, dtype=torch.int32)
+    monkeypatch.setattr(pa, "host_record_ring", lambda dev: Ring(), raising=False)
+    for key in ("launched", "used", "discarded"):
+        ops_.SPECULATION[key] += 0
+    sp0, mc0 = dict(ops_.SPECULATION), dict(ops_.MEMORY_CARRY)
+    fb0 = ops_.FALLBACKS["dormant_rows_on_the_host"]
+    rs = [np.random.RandomState(33), np.random.RandomState(33)]
+    feats = (torch.zeros(1, 4, 8, 8),)
+    compared = 0
+    for f in range(200):
+        if f == 110:
+            for sv in (loops[0].solver, loops[1].solver, host.solver):      # the calm stretch (see the test above)
+                sv.track_thresh, sv.start_thresh, sv.resume_track_thresh = 0.0, 2.0, 2.0
+                sv.track_pool._max_dormant_frames = 1000
+        a = loops[0]._step_native(feats, detections(rs[0], f), next_features=feats)
+        b = loops[1](feats, detections(rs[1], f))
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores")) and torch.equal(a.get_field("labels"), b.get_field("labels"))
+        assert pa.get_active_ids() == pb.get_active_ids() and list(pa._dormant_ids.items()) == list(pb._dormant_ids.items())
+        assert pa._kill_ids == pb._kill_ids and pa._max_id == pb._max_id
+        if f % 3 == 2 or f > 190:
+            ma, mb = loops[0].track_memory, loops[1].track_memory
+            assert type(ma) is _LazyMemory
+            assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
+            assert torch.equal(ma[2][0].bbox, mb[2][0].bbox)
+            for fld in ("ids", "labels", "scores"):
+                assert torch.equal(ma[2][0].get_field(fld), mb[2][0].get_field(fld)), "memory %s, frame %d" % (fld, f)
+            assert [int(t) for t in ma[2][0].host_ids] == mb[2][0].get_field("ids").tolist()
+            compared += 1
+    sp = {k: ops_.SPECULATION[k] - sp0.get(k, 0) for k in ("launched", "used", "discarded")}
+    mc = {k: ops_.MEMORY_CARRY[k] - mc0.get(k, 0) for k in ("in_the_solver_launch", "ahead_kept", "ahead_redone", "launched")}
+    # (the last frame's speculative head may still be waiting for a call that never comes)
+    assert sp["launched"] - sp["used"] - sp["discarded"] in (0, 1) and sp["used"] >= 20 and sp["discarded"] >= 10, sp
+    assert mc["in_the_solver_launch"] >= 60 and mc["ahead_kept"] >= 20 and mc["ahead_redone"] >= 20, mc
+    assert emu.carried == mc["in_the_solver_launch"] and compared >= 60
+    assert ops_.FALLBACKS["dormant_rows_on_the_host"] == fb0 and pa._kill_ids and pa._max_id > 25
+
+
 @pytest.mark.gpu
 def test_solver_on_the_device_with_the_hip_nms():
     _run("cuda:0", None)
