@@ -731,7 +731,7 @@ class TrackingLoop(torch.nn.Module):
                     and (m2.A == m2.n_act or self.__dict__.get("_carry_ahead_kept"))):
                 self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf)
             else:
-                ops.SPECULATION["discarded"] += 1        # the row count changed, or dormant rows joined the memory
+                ops.SPECULATION["discarded"] += 1        # the row count changed, or the dormant rows are not the ones copied ahead
         return out
 
     @torch.no_grad()
