@@ -33,9 +33,16 @@ typedef void* smot_stream_t; /* hipStream_t */
 #define SMOT_ERR_UNSUPPORTED (-2)  /* legal in the reference but not implemented here (documented per call) */
 
 #define SMOT_MAX_LEVELS 8
-/* 10: the image of smot_emm_tower_pack grew (fp32 image + three-part bf16 image: ask smot_emm_tower_pack_floats), an image
- *     packed by a version-9 library is too short for this one; smot_emm_tower_form added.  (9: order-hint entries of 528 floats) */
-#define SMOT_ABI_VERSION 11
+/* ABI history.
+ * 10: the image of smot_emm_tower_pack grew (fp32 image + three-part bf16 image: ask smot_emm_tower_pack_floats), an image
+ *     packed by a version-9 library is too short for this one; smot_emm_tower_form added.  (9: order-hint entries of 528 floats)
+ * 11: smot_frame_args grew by the six carry_* pointers and carry_src_row0 / carry_rows / carry_dst_row0 (SMOT_STAGE_CARRY);
+ *     smot_track_solve_carry_fwd and smot_memory_carry_fwd added.
+ * 12: order-hint entries of 536 floats — behind the tables every entry carries the by-roi record the consumer VERIFIES against
+ *     its own boxes / search regions, and entry 0 the list's status word; the geometry stamp includes the level's scale;
+ *     smot_emm_track_fwd writes NaN rows when the verification fails; record word 6 of the solver became a bit field;
+ *     smot_emm_order_hint_status added. */
+#define SMOT_ABI_VERSION 12
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -326,18 +333,30 @@ int smot_dispatch_floor_fwd(int workgroups, int threads, smot_stream_t stream);
  *   can rank them once: given a buffer of smot_emm_order_hint_floats(N, rz, sampling_ratio) floats (32-byte
  *   aligned; 0 = this shape / count writes no hint: pass NULL), smot_emm_extract_cache[_masked]_fwd writes
  *   SMOT_HINT_FLOATS dwords per roi — {search region x1,y1,x2,y2, FPN level (int32 bits), roi index (int32 bits),
- *   0, 0 | ymin, ymax, xmin, xmax of the touched window, pad cells / H / W of the level the tables stand for, 0 |
+ *   0, 0 | ymin, ymax, xmin, xmax of the touched window, pad cells / H / W / scale of the level the tables stand for |
  *   y sample table 64 x {row byte offset lo, hi, weight lo, hi} | x sample table 64 x {window column lo, hi, weight lo,
- *   hi}}, entry k = the roi of rank k; the tables (ABI 9) are the FINISHED sample tables of the roi's 30x30 search-region
+ *   hi} | by-roi record (8 dwords, see below)}, entry k = the roi of rank k; the tables (ABI 9) are the FINISHED sample tables of the roi's 30x30 search-region
  *   pooling in the next frame (zero-pad int(pad_pixels * scale) cells, same map sizes), so that a consumer workgroup
  *   copies them instead of building them (a geometry stamp that does not match the consumer's level makes it rebuild
  *   them) — and smot_emm_track_fwd given that buffer TOGETHER WITH exactly the `boxes`
  *   and `sr` of the same extraction (same N, same row order, same maps geometry) reads one entry per workgroup
- *   instead of ranking.  A hint from any other boxes gives wrong results (the entries' search regions are used as
- *   they stand; indices are clamped, so nothing is read out of range): callers that re-order, merge or edit the
- *   track memory pass NULL.  For the masked form the hint covers the first *n_valid rows.
+ *   instead of ranking.  For the masked form the hint covers the first *n_valid rows.
+ *   VERIFIED, not trusted (ABI 12): behind the tables, entry x carries the by-roi record of roi x — {its search region,
+ *   its FPN level, the number of rois the list ranks, a status word, 0} — and the consuming kernel compares every record with
+ *   ITS sr[x] (bit for bit), the level it derives from ITS boxes[x] and ITS N (one workgroup per roi, loads that travel
+ *   beside the entry's own: no cost on the kernel's chain).  The list is a permutation of the rois it was made from by
+ *   construction, so a list that passes describes exactly these rois.  One that does not (other boxes, another row
+ *   order, another count or level geometry) raises the status word of entry 0 (SMOT_HINT_STATUS_WORD; the buffer is
+ *   therefore IN/OUT for smot_emm_track_fwd), and the same call's decode kernel then writes NaN into every row of `bb`
+ *   and `conf`: a stale hint is reported (NaN rows; smot_emm_order_hint_status; bit 1 of the solver's record word 6),
+ *   never silently used.  Indices are clamped, so nothing is read out of range either way.
  */
-#define SMOT_HINT_FLOATS 528
+#define SMOT_HINT_FLOATS 536
+#define SMOT_HINT_STATUS_WORD 534   /* dword index (in the buffer, i.e. of entry 0) of the list's status word */
+/* Copies the status word of an order hint to *status_host (pinned or pageable host memory) on `stream`: 0 = every head that
+ * was given this hint found it describing its rois; non-zero = one did not (and wrote NaN rows).  Asynchronous: valid once
+ * the stream has been synchronised. */
+int smot_emm_order_hint_status(const float* order_hint, int* status_host, smot_stream_t stream);
 long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio);
 
 long long smot_emm_track_ws_floats(int N, int C, int rx, int rz);
@@ -468,7 +487,10 @@ int smot_linear_rows_fwd(const float* x, int M, int K, const float* W, const flo
  *   record         int32 [8 + 4*M + 3*pool_capacity], DEVICE memory or device-accessible pinned HOST memory (the
  *                  kernel's stores then land in host memory directly and the caller needs no copy, only an event
  *                  behind this launch): K (kept), A (active rows), max_id, frame_idx,
- *                  n_active, n_dormant, table overflow flag, M; kept original row [M]; kept id [M]; active-row id
+ *                  n_active, n_dormant, flags (bit 0: id table overflow; bit 1, ABI 12: a propagated track came in with a NaN
+ *                  score — what a head writes whose order hint failed its verification, see order_hint; bit 2, ABI 12: no id
+ *                  started, resumed, was suspended or expired in this frame — the three tables stand), M; kept
+ *                  original row [M]; kept id [M]; active-row id
  *                  [M]; snapshot of the three pool tables.  The only thing the host has to read back.  frame_idx
  *                  (word 3, always >= 1) is stored last, behind a system-scope fence: a host polling a pinned
  *                  record it zeroed before the launch finds the record complete once word 3 is non-zero.
@@ -525,7 +547,12 @@ int smot_track_solve_carry_fwd(const float* det_boxes, float* det_scores, const 
  * (first frame, or an empty memory); refine == 0 skips the refinement (the solver then applies trk_score_bias = 1).
  * SMOT_STAGE_CARRY (with SMOT_STAGE_SOLVE; never part of stages == 0) makes the solver's launch carry the dormant rows
  * of the track memory the head ran on (the carry_* fields: smot_track_solve_carry_fwd; next_templates / next_sr are the
- * destination buffers, row_floats = C * rz * rz).
+ * destination buffers, row_floats = C * rz * rz).  ORDERING CONTRACT of the carried templates / search regions: they are
+ * written to rows [carry_dst_row0, carry_dst_row0 + carry_rows) of next_templates / next_sr BEFORE the active count A is
+ * known; when carry_dst_row0 < A the masked extraction of the same frame (SMOT_STAGE_EXTRACT, enqueued behind the solver
+ * on the same stream) overwrites rows 0 .. A-1 afterwards and never writes rows >= A — so a wrong guess leaves garbage
+ * only in rows the caller re-copies (record word 1 != carry_dst_row0 -> smot_memory_carry_fwd).  A caller that runs the
+ * two launches on different streams, or the extraction first, must not use SMOT_STAGE_CARRY.
  * `stages` selects what this call enqueues (0 = everything): a frame is a serial chain — host work before the first
  * launch, the kernels, the record, host bookkeeping — so a caller whose argument preparation is not free calls once
  * with SMOT_STAGE_HEAD as soon as the head's arguments stand (fields of later stages are not read) and a second time

@@ -27,7 +27,8 @@ for n in counts:
     emm = emm.to(dev)
     ref = None
     for rep in range(2):
-        for var in ({}, {"SMOT_NO_HINT": "1"}, {"SMOT_NO_HINT": "2"}):
+        # ({"SMOT_FUSED_ABL": "6"}: round 5 — the hinted kernel WITHOUT its verification of the hint, i.e. the round-4 kernel)
+        for var in ({}, {"SMOT_FUSED_ABL": "6"}, {"SMOT_NO_HINT": "1"}, {"SMOT_NO_HINT": "2"}):
             with ops.debug_library(**var), torch.no_grad():
                 state = emm.extract_cache(feats[3], det)
 

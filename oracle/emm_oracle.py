@@ -140,9 +140,52 @@ def roi_align(feat, rois, spatial_scale, out_h, out_w, sampling_ratio):
     return out
 
 
-def sr_pool(features, boxes, sr_boxes, out_size, scales, sampling_ratio):
+# The same operator as compiled C (oracle/csrc/roi_align_cpu.c: upstream's published CPU algorithm, OpenMP over rois):
+# bit-identical to ``roi_align`` above (tests/test_oracle_golden.py) and ~20x faster — bench.py's cpu_baseline leg times
+# the reference's algorithm at the speed its C++ operator would have, not at a Python restatement's.
+_ROI_C = {}
+
+
+def roi_align_c_library():
+    """ctypes handle of oracle/_build/libroi_align_cpu.so (built by ``__graft_entry__.build()`` /
+    ``oracle/build_c.py``), or None when it has not been built."""
+    if "lib" not in _ROI_C:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build", "libroi_align_cpu.so")
+        lib = None
+        if os.path.exists(path):
+            lib = ctypes.CDLL(path)
+            lib.roi_align_forward_cpu.restype = ctypes.c_int
+            lib.roi_align_forward_cpu.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int,
+                                                  ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _ROI_C["lib"] = lib
+    return _ROI_C["lib"]
+
+
+def roi_align_c(feat, rois, spatial_scale, out_h, out_w, sampling_ratio):
+    """``roi_align`` through the compiled C restatement (fp32 CPU tensors)."""
+    lib = roi_align_c_library()
+    if lib is None:
+        raise RuntimeError("oracle/_build/libroi_align_cpu.so is not built (python oracle/build_c.py)")
+    feat = feat.contiguous().float()
+    rois = rois.contiguous().float()
+    B, C, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.empty((R, C, out_h, out_w), dtype=torch.float32)
+    if R:
+        rc = lib.roi_align_forward_cpu(feat.data_ptr(), B, C, H, W, rois.data_ptr(), R, float(spatial_scale), out_h, out_w,
+                                       int(sampling_ratio), out.data_ptr())
+        if rc:
+            raise RuntimeError("roi_align_forward_cpu: roi with a batch index outside the input")
+    return out
+
+
+def sr_pool(features, boxes, sr_boxes, out_size, scales, sampling_ratio, roi_align=None):
     """``SRPooler.forward`` (sr_pool.py:53-91): level from the TEMPLATE box, rois from ``sr_boxes``
-    (or the template boxes when ``sr_boxes is None``); one image per call (batch idx 0)."""
+    (or the template boxes when ``sr_boxes is None``); one image per call (batch idx 0).
+    ``roi_align``: the per-level operator (default: the torch restatement above; ``roi_align_c``: compiled)."""
+    roi_align = globals()["roi_align"] if roi_align is None else roi_align
     rois_xyxy = boxes if sr_boxes is None else sr_boxes
     N = rois_xyxy.shape[0]
     rois = torch.cat((rois_xyxy.new_zeros((N, 1)), rois_xyxy), dim=1)
@@ -368,16 +411,16 @@ class EMMConfig(object):
         self.gn_eps = gn_eps
 
 
-def extract_cache(cfg, features, det_boxes):
+def extract_cache(cfg, features, det_boxes, roi_align=None):
     """``EMM.extract_cache`` (track_core.py:81-98): template ROIAlign on UNPADDED features +
     search regions.  Returns (z [N,C,rz,rz], sr [N,4])."""
-    z = sr_pool(features, det_boxes, None, cfg.rz, cfg.scales, cfg.sampling_ratio)
+    z = sr_pool(features, det_boxes, None, cfg.rz, cfg.scales, cfg.sampling_ratio, roi_align)
     sr = search_region(det_boxes, cfg.pad_pixels, cfg.search_expansion, cfg.min_search_wh)
     return z, sr
 
 
 def emm_forward(cfg, params, features, boxes, sr_boxes, template_features, image_wh,
-                return_intermediates=False, reference_ops=False):
+                return_intermediates=False, reference_ops=False, roi_align=None):
     """Inference branch of ``EMM.forward`` (track_core.py:28-79).
 
     Returns (bb [N,4], conf [N], nonempty [N] bool) after ``wrap_results_to_boxlist`` clipping
@@ -389,7 +432,7 @@ def emm_forward(cfg, params, features, boxes, sr_boxes, template_features, image
     xcorr = xcorr_depthwise_conv if reference_ops else xcorr_depthwise
     upsample = bicubic_upsample_torch if reference_ops else bicubic_upsample
     padded = pad_features(features, cfg.pad_pixels)                                   # :49
-    x = sr_pool(padded, boxes, sr_boxes, cfg.rx, cfg.scales, cfg.sampling_ratio)      # :51
+    x = sr_pool(padded, boxes, sr_boxes, cfg.rx, cfg.scales, cfg.sampling_ratio, roi_align)      # :51
     resp = xcorr(x, template_features)                                                # :53
     cls, center, reg = predictor(resp, params, cfg.gn_groups, cfg.gn_eps)             # :54
     cls_up = upsample(cls)                                                            # :69

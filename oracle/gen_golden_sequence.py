@@ -120,10 +120,10 @@ def install_stubs(case):
             make_roi_box_predictor=lambda cfg, dim: BO.FPNPredictor(dim, b["num_classes"]))
 
 
-def det_boxlist(boxes, scores, image_wh):
+def det_boxlist(boxes, scores, image_wh, labels=None):
     bl = BoxList(torch.from_numpy(boxes.copy()), image_wh, mode="xyxy")
     bl.add_field("ids", torch.full((len(boxes),), -1, dtype=torch.int64))
-    bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64))
+    bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64) if labels is None else torch.from_numpy(labels.copy()))
     bl.add_field("scores", torch.from_numpy(scores.copy()))
     bl.detector_output = True
     return bl
@@ -190,8 +190,8 @@ def run_case(name, save=True):
     t0 = time.time()
     for f in range(case["frames"]):
         feats = [torch.from_numpy(a) for a in inp.features(f)]
-        db, ds = inp.detections(f)
-        dets = [det_boxlist(db, ds, case["image_wh"])]
+        db, ds, dl = inp.detections(f, labels=True)
+        dets = [det_boxlist(db, ds, case["image_wh"], dl)]
         captured.clear()
         box.refined = None
         prev_active = set(track_pool._active_ids)
@@ -233,6 +233,9 @@ def run_case(name, save=True):
         if box.refined is not None:
             out[p + "ref_boxes"] = box.refined.bbox.numpy().copy()
             out[p + "ref_scores"] = box.refined.get_field("scores").numpy().copy()
+            if case.get("n_foreground", 1) > 1:      # the box head regroups its rows by class (box_head/inference.py:164-191)
+                out[p + "ref_ids"] = box.refined.get_field("ids").numpy().copy()
+                out[p + "ref_labels"] = box.refined.get_field("labels").numpy().copy()
         n_trk = len(captured.get("trk_ids", ()))
         print("%s f%02d: dets %2d, tracked %2d (min margin %s, scores %s), out %2d, active %2d, dormant %2d, "
               "max id %d, %.0f s" % (

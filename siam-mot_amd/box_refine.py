@@ -260,8 +260,12 @@ class TrackBoxHead(nn.Module):
             out = torch.addmm(b, h, w)
         K = self.predictor.cls_score.out_features
         KR = self.predictor.bbox_pred.out_features // 4
-        return ops.box_refine_post(out, K, KR, boxes, labels, ids, conf, bc.weights, bc.bbox_xform_clip,
-                                   None if pp.amodal_inference else image_wh, tracktor)
+        res = ops.box_refine_post(out, K, KR, boxes, labels, ids, conf, bc.weights, bc.bbox_xform_clip,
+                                  None if pp.amodal_inference else image_wh, tracktor)
+        hook = self.__dict__.get("raw_output_hook")          # (as in the one-call form above)
+        if hook is not None:
+            hook(*res)
+        return res
 
 
 class RefineTracks(object):

@@ -192,6 +192,9 @@ struct FinalizeArgs {
     long long* trace;       // phase trace (smot_debug_trace) or nullptr: 8 stamps per workgroup
     int rx, rz;
     float pad, clip_w, clip_h;
+    const int* poison;      // status word of the order hint this head's pooling + correlation kernel verified (sr_xcorr.hip,
+                            // fx_verify_hint) or nullptr: non-zero = the hint did not describe the rois, the responses are
+                            // not the rois' -> every row's box and score are written as NaN (reported, never silently used)
 };
 
 // SPLIT: workgroups of 256*SPLIT threads; the band's output rows are divided among the SPLIT thread groups
@@ -471,6 +474,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     const int full = F.rx * D.up;
     const int st = (F.rz / 2) * D.up;
     const float sx1 = F.sr[n * 4 + 0], sy1 = F.sr[n * 4 + 1], sx2 = F.sr[n * 4 + 2], sy2 = F.sr[n * 4 + 3];
+    const int poisoned = (F.poison != nullptr) ? *F.poison : 0;          // (beside the search region's loads: same round trip)
     const float stride_w = div_rn(sub_rn(sx2, sx1), (float)(full - 1));
     const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
     const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), F.pad);
@@ -484,13 +488,15 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         bx2 = clamp_nan(bx2, 0.0f, F.clip_w - 1.0f);
         by2 = clamp_nan(by2, 0.0f, F.clip_h - 1.0f);
     }
+    const float qnan = __uint_as_float(0x7FC00000u);
+    if (poisoned != 0) bx1 = by1 = bx2 = by2 = qnan;
     F.bb[n * 4 + 0] = bx1;
     F.bb[n * 4 + 1] = by1;
     F.bb[n * 4 + 2] = bx2;
     F.bb[n * 4 + 3] = by2;
     const float m = fmaxf(v[0], v[1]);
     const float e0 = expf(sub_rn(v[0], m)), e1 = expf(sub_rn(v[1], m));
-    F.conf[n] = div_rn(e1, add_rn(e0, e1));
+    F.conf[n] = (poisoned != 0) ? qnan : div_rn(e1, add_rn(e0, e1));
     if (F.idx_out != nullptr) F.idx_out[n] = (long long)idx;
     if (F.trace) F.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 7] = (long long)__builtin_amdgcn_s_memtime();
 #undef DC_TRACE
@@ -519,7 +525,7 @@ unsigned* decode_tickets(float* cand_ws, int N, int Ho) {
 int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
                 int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
                 float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, bool tickets_zeroed,
-                hipStream_t st) {
+                hipStream_t st, const int* poison) {
     SMOT_REQUIRE(N >= 0 && Ho > 0 && up > 0, "decode: bad sizes N=%d Ho=%d up=%d", N, Ho, up);
     SMOT_REQUIRE(rx - rz + 1 == Ho && (rz & 1) == 1, "decode: need Ho == rx-rz+1 and odd rz (Ho=%d rx=%d rz=%d)", Ho,
                  rx, rz);
@@ -582,6 +588,7 @@ int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* ha
     F.clip_w = clip_w;
     F.clip_h = clip_h;
     F.trace = g_trace;
+    F.poison = poison;
     if (!tickets_zeroed) {
         hipError_t e = hipMemsetAsync(F.ticket, 0, (size_t)N * sizeof(unsigned), st);
         if (e != hipSuccess) {
@@ -611,5 +618,5 @@ extern "C" int smot_emm_decode_fwd(const float* logits, const float* sr, const f
     L.cls_b = L.center_b = L.reg_b = nullptr;
     L.logits_out = nullptr;
     return smot::decode_impl(L, sr, boxes, hann, N, Ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma,
-                             use_centerness, clip_w, clip_h, cand_ws, bb, conf, idx, false, (hipStream_t)stream);
+                             use_centerness, clip_w, clip_h, cand_ws, bb, conf, idx, false, (hipStream_t)stream, nullptr);
 }

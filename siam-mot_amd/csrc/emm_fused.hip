@@ -18,7 +18,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
 int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
                 int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
                 float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, bool tickets_zeroed,
-                hipStream_t st);
+                hipStream_t st, const int* poison);
 unsigned* decode_tickets(float* cand_ws, int N, int Ho);
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
@@ -27,7 +27,7 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
-                        hipStream_t st);
+                        hipStream_t st, const int** hint_status);
 int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                          const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                          const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st);
@@ -62,11 +62,13 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     float* logits = tower + (size_t)N * 2 * C * ho * ho;
     float* cand = logits + (size_t)N * 8 * ho * ho;       // 7 planes used; 8 keeps the 8-byte alignment
     int rc;
+    const int* poison = nullptr;
     const bool no_fuse = knobs().no_fuse;             // A/B: measurement library only (constant false otherwise)
     if (rx == 30 && rz == 15 && sampling_ratio == 2 && !no_fuse) {
         // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
+        // (a hint the kernel honours is VERIFIED against `boxes` / `sr` by it; `poison` = the list's status word)
         rc = sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
-                                 nullptr, order_hint, (hipStream_t)stream);
+                                 nullptr, order_hint, (hipStream_t)stream, &poison);
         if (rc) return rc;
     } else if (rx == 35 && rz == 7 && sampling_ratio == 2 && !no_fuse) {
         // the second yaml family's shape: gathers + correlation in one kernel (sr_xcorr_small.hip), same arithmetic
@@ -98,7 +100,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     L.reg_b = p[11];
     L.logits_out = logits;
     return decode_impl(L, sr, boxes, hann, N, ho, up, rx, rz, pad_pixels, one_minus_sigma, sigma, use_centerness,
-                       clip_w, clip_h, cand, bb, conf, idx, tickets_zeroed, (hipStream_t)stream);
+                       clip_w, clip_h, cand, bb, conf, idx, tickets_zeroed, (hipStream_t)stream, poison);
 }
 
 extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* heights, const int* widths,

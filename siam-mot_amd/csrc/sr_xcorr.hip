@@ -59,7 +59,14 @@ struct SrOut {
 // instead of ranking, dividing and building them.
 constexpr int HINT_FLOATS = SMOT_HINT_FLOATS;
 constexpr int HINT_BOUNDS = 8, HINT_GEOM = 12, HINT_YTAB = 16, HINT_XTAB = 16 + 256;
-static_assert(HINT_XTAB + 256 == HINT_FLOATS, "hint entry layout");
+// ABI 12: behind the tables, entry x also carries the BY-ROI record of roi x (entries are sorted by rank, this record is
+// not): {search region x1,y1,x2,y2 of roi x, its FPN level, the number of rois the list ranks, status word (entry 0's is
+// THE status word of the list, zeroed by the writer), 0}.  The consumer verifies it against ITS `sr[x]` / `boxes[x]` / roi
+// count (fx_verify_hint) — the list is a permutation of the rois it was made from by construction, so "every by-roi
+// record equals the consumer's roi" is "the list describes exactly these rois".
+constexpr int HINT_BYROI = HINT_XTAB + 256, HINT_STATUS = HINT_BYROI + 6;
+static_assert(HINT_BYROI + 8 == HINT_FLOATS && (HINT_FLOATS * 4) % 32 == 0 && HINT_STATUS == SMOT_HINT_STATUS_WORD,
+              "hint entry layout");
 
 // base (wave-uniform, SGPR pair) + 32-bit unsigned BYTE offset: selects the `global_load v, v_off, s[base]`
 // addressing form (one address VGPR per load instead of a 64-bit pair — 120 loads are in flight).
@@ -218,9 +225,46 @@ __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float*
             ent[HINT_GEOM + 0] = pad;
             ent[HINT_GEOM + 1] = H;
             ent[HINT_GEOM + 2] = W;
-            ent[HINT_GEOM + 3] = 0;
+            ent[HINT_GEOM + 3] = __float_as_int(scale);           // (the tables were built with this scale: part of the stamp)
+            // the by-roi record of roi x, in entry x (not entry `rank`): what the consumer verifies against its own tensors
+            int* rec = reinterpret_cast<int*>(S.hint_out) + (size_t)x * HINT_FLOATS + HINT_BYROI;
+            float4* r4 = reinterpret_cast<float4*>(rec);
+            r4[0] = roi;
+            rec[4] = lvl;
+            rec[5] = nv;
+            rec[6] = 0;                                            // status word (entry 0's is the list's)
+            rec[7] = 0;
         }
     }
+}
+
+// The consumer's check of an order hint (VERDICT r4 "next" #2: detect, not trust).  A workgroup of grid row 0 verifies the
+// by-roi record of ITS grid column x against the launch's own tensors: sr[x] bit for bit, the FPN level recomputed from
+// boxes[x], and the number of rois.  Every address is known at kernel start, so the loads travel beside the entry's own
+// (no dependent round trip), one dword per lane, and the comparison runs in a wave that would otherwise wait at the table
+// barrier: no cost on the workgroup's chain.  A mismatch raises the list's status word (entry 0): the decode kernel of the
+// same head then writes NaN boxes and scores for every row (smot_emm_track_fwd), the solver's record counts them, and the
+// tracking loop raises — a stale hint is reported, never silently used.
+__device__ __forceinline__ void fx_verify_hint(const LevelParams& P, const float* __restrict__ sr,
+                                               const float* __restrict__ boxes, const float* hint, int x, int NT, int lane) {
+    const int* rec = reinterpret_cast<const int*>(hint) + (size_t)x * HINT_FLOATS + HINT_BYROI;
+    int v = 0;
+    if (lane < 4) {
+        v = __float_as_int(sr[(size_t)x * 4 + lane]);
+    } else if (lane < 8) {
+        v = __float_as_int(boxes[(size_t)x * 4 + lane - 4]);
+    } else if (lane < 14) {
+        v = rec[lane - 8];
+    }
+    const int up = __shfl_up(v, 8);                              // lanes 8..11: the consumer's sr[x] beside the record's
+    float b4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b4[i] = __int_as_float(__builtin_amdgcn_readlane(v, 4 + i));
+    int lvl = 0;
+    if (P.num_levels > 1) lvl = map_level(b4, P.k_min, P.k_max);
+    const bool bad = (lane >= 8 && lane < 12 && up != v) || (lane == 12 && v != lvl) || (lane == 13 && v != NT);
+    if (__ballot(bad) != 0ull && lane == 0)
+        atomicOr(reinterpret_cast<int*>(const_cast<float*>(hint)) + HINT_STATUS, 1);
 }
 
 // Which (roi, channel group) a workgroup takes.  The grid is (rois, channel groups) and the hardware dispatches
@@ -443,6 +487,15 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
             if (wave < 2) tab_early = *reinterpret_cast<const int4*>(ent + (wave == 0 ? HINT_YTAB : HINT_XTAB) + 4 * lane);
         }
     }
+    if constexpr (XCORR && RX == 30) {
+        if (S.hint_in != nullptr && S.order == 1 && S.n_valid == nullptr && gridDim.x >= 2 && gridDim.x <= 256 &&
+            blockIdx.y == 0 && wave == 2
+#ifdef SMOT_DEBUG
+            && S.abl != 6                 // A/B (measurement library, SMOT_FUSED_ABL=6): the round-4 kernel that trusted the hint
+#endif
+        )
+            fx_verify_hint(P, sr, boxes, S.hint_in, blockIdx.x, gridDim.x, lane);
+    }
     int k_assigned = -1;
     const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, grid_row, grid_rows,
                                     XCORR ? S.hint_in : nullptr, lane, &n_assigned, &cg_assigned, &roi_assigned,
@@ -509,7 +562,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // With a hint entry the tables arrive FINISHED (fx_write_hint built them when the roi was made, one frame earlier):
     // waves 0 / 1 copy 1 KB each instead of ~150 vector instructions and two IEEE divisions; the entry's geometry stamp
     // must match this launch's level (another pad / map size: the tables are rebuilt here, the assignment stands).
-    const bool hent = XCORR && RX == 30 && k_assigned >= 0 && g8[4] == pad && g8[5] == H && g8[6] == W;
+    const bool hent = XCORR && RX == 30 && k_assigned >= 0 && g8[4] == pad && g8[5] == H && g8[6] == W &&
+                      g8[7] == __float_as_int(scale);
     const int hb[4] = {g8[0], g8[1], g8[2], g8[3]};
     if (wave < 2 && hent) {
         tab[wave][lane] = tab_early;
@@ -901,11 +955,14 @@ int fused10_plan_floats();
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
-                        hipStream_t st) {
+                        hipStream_t st, const int** hint_status) {
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
     if (rc) return rc;
     if (!order_hint_rois(N, true)) order_hint = nullptr;
+    // the status word of a hint this launch honours (and verifies: fx_verify_hint) — for the head's decode kernel
+    if (hint_status != nullptr)
+        *hint_status = order_hint != nullptr ? reinterpret_cast<const int*>(order_hint) + HINT_STATUS : nullptr;
     SMOT_REQUIRE(order_hint == nullptr || (((uintptr_t)order_hint) & 31) == 0,
                  "sr_xcorr_fused: the order hint must be 32-byte aligned");
     dim3 grid(N, (C + FX_CH - 1) / FX_CH);
@@ -961,9 +1018,21 @@ extern "C" int smot_debug_sr_xcorr_fused_hint_fwd(const float* const* feats, con
                                                   const float* boxes, const float* sr, const float* templates, int N,
                                                   float* resp, const float* order_hint, smot_stream_t stream) {
     return smot::sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
-                                     resp, nullptr, order_hint, (hipStream_t)stream);
+                                     resp, nullptr, order_hint, (hipStream_t)stream, nullptr);
 }
 #endif
+
+extern "C" int smot_emm_order_hint_status(const float* order_hint, int* status_host, smot_stream_t stream) {
+    using namespace smot;
+    SMOT_REQUIRE(order_hint != nullptr && status_host != nullptr, "order_hint_status: null pointer");
+    const hipError_t e = hipMemcpyAsync(status_host, reinterpret_cast<const int*>(order_hint) + HINT_STATUS, sizeof(int),
+                                        hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        set_error("order_hint_status: hipMemcpyAsync: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return SMOT_OK;
+}
 
 extern "C" long long smot_emm_order_hint_floats(int N, int rz, int sampling_ratio) {
     using namespace smot;
@@ -986,5 +1055,5 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_fused: null pointer");
     return sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
-                               x_debug, nullptr, (hipStream_t)stream);
+                               x_debug, nullptr, (hipStream_t)stream, nullptr);
 }

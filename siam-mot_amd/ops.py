@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -82,6 +82,7 @@ _SIGNATURES = {
     "smot_linear_rows_fwd": (ctypes.c_int, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp]),
     "smot_track_frame_fwd": (ctypes.c_int, [_vp, _vp]),
     "smot_track_solve_max_boxes": (ctypes.c_int, []),
+    "smot_emm_order_hint_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "smot_memory_carry_max_rows": (ctypes.c_int, []),
     "smot_memory_carry_fwd": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i,
                                              _vp, _i, _vp]),
@@ -517,11 +518,14 @@ def _geometry_refresh(g, features, device):
     the pointer array is refilled and True is returned; anything else returns False (the caller takes the full path,
     which raises or rebuilds)."""
     fp, shapes = g.fp, g.shapes
-    for l in range(g.L):
+    if len(features) < g.L:
+        return False
+    for l in range(g.L):                 # validate every level first: a mismatch must leave the pointer array as it was
         f = features[l]
         if f.shape != shapes[l] or not (f.is_cuda and f.dtype is _F32 and f.is_contiguous()) or f.device != device:
             return False
-        fp[l] = f.data_ptr()
+    for l in range(g.L):
+        fp[l] = features[l].data_ptr()
     return True
 
 
@@ -597,8 +601,9 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     """The inference branch of ``EMM.forward`` in ONE library call.  Returns (bb ``[N,4]``, conf ``[N]``).
 
     ``order_hint``: the ``[N, HINT_FLOATS]`` tensor ``emm_extract_cache(..., hint=True)`` returned TOGETHER WITH exactly
-    these ``boxes`` / ``sr`` (include/smot_emm.h: a scheduling side channel; a hint of other boxes gives wrong results —
-    ``siammot_amd.emm.EMM`` checks tensor identity and versions before it passes one), or None."""
+    these ``boxes`` / ``sr`` (include/smot_emm.h: a scheduling side channel, VERIFIED by the kernel against these very
+    tensors: a hint of other boxes raises its status word — ``order_hint_status`` — and every returned row is NaN;
+    ``siammot_amd.emm.EMM`` also checks tensor identity and versions before it passes one), or None."""
     lib = _lib or load_library()
     if not (isinstance(boxes, torch.Tensor) and boxes.is_cuda):
         _dev_f32(boxes, "boxes")                 # raises: no CPU path
@@ -649,8 +654,16 @@ def emm_track(features, boxes, sr, templates, params, rx, rz, scales, sampling_r
     return (bb, conf, idx) if return_index else (bb, conf)
 
 
-HINT_FLOATS = 528                    # SMOT_HINT_FLOATS (include/smot_emm.h): entry header + both finished sample tables
+HINT_FLOATS = 536                    # SMOT_HINT_FLOATS (include/smot_emm.h): entry header + both finished sample tables + by-roi record
+HINT_STATUS_WORD = 534               # SMOT_HINT_STATUS_WORD: the list's status word (entry 0), raised by a head that found the
+                                     # hint NOT describing its rois (that head's rows are NaN)
 _hint_floats = {}
+
+
+def order_hint_status(order_hint):
+    """Status word of an order hint (``[N, HINT_FLOATS]`` tensor): 0 = every head given this hint found it describing its
+    rois.  Synchronises (one 4-byte copy): for error paths and tests, not for the frame loop."""
+    return int(order_hint.view(-1)[HINT_STATUS_WORD:HINT_STATUS_WORD + 1].view(torch.int32).item())
 
 
 def order_hint_floats(N, rz, sampling_ratio):
@@ -1197,6 +1210,14 @@ class FrameArgs(object):
         self._HEAD_FMT.pack_into(self._buf, 8 * self._HEAD0, *ptrs)
         self._II.pack_into(self._buf, self._INT0, n_trk, stages)
         return self._addr
+
+    _HINT_OFF = 8 * _FRAME_PTRS.index("order_hint")
+    _Q = struct.Struct("<Q")
+
+    def fix_head(self, n_trk, hint_ptr):
+        """Correct the row count and the order-hint pointer of a head range poked on a guess (stage HEAD stands)."""
+        self._II.pack_into(self._buf, self._INT0, n_trk, STAGE_HEAD)
+        self._Q.pack_into(self._buf, self._HINT_OFF, hint_ptr)
 
     def poke_rest(self, ptrs, stages, n_det, thresholds, carry=(0, 0, 0)):
         """Rewrite the per-frame pointers behind the head's (``refine_ws`` .. ``carry_scores``), ``stages``,

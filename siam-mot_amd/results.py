@@ -187,6 +187,20 @@ def postprocess_tracks(tracks, track_len=5, track_conf=0.7):
     return out
 
 
+def _storage_overlap(feats_a, dets_a, feats_b, dets_b):
+    """True when any tensor of frame b lives in the storage of a tensor of frame a (a detector re-using its outputs)."""
+    def ptrs(feats, dets):
+        out = set()
+        for f in feats:
+            if isinstance(f, torch.Tensor) and f.numel():
+                out.add(f.untyped_storage().data_ptr())
+        box = getattr(dets, "bbox", None)
+        if isinstance(box, torch.Tensor) and box.numel():
+            out.add(box.untyped_storage().data_ptr())
+        return out
+    return bool(ptrs(feats_a, dets_a) & ptrs(feats_b, dets_b))
+
+
 class FrameSequenceRunner(object):
     """The per-video loop of the reference's entry points (demos/demo_inference.py:94-122 ``process`` /
     ``process_frame_sequence``; engine/inferencer.py:24-75 ``do_inference``) around this repository's pieces:
@@ -217,7 +231,10 @@ class FrameSequenceRunner(object):
         ``lookahead``: the detector runs one frame ahead of the tracker and every tracker call is shown the next frame's
         feature maps (``TrackingLoop.forward(..., next_features=)``: the next frame's head is enqueued behind this frame's
         extraction while the host still waits for this frame's record).  Same results frame for frame; each frame's
-        result arrives one detector pass later."""
+        result arrives one detector pass later.  The detector must return FRESH tensors per call: one that writes into
+        persistent output buffers (graph-captured, pre-allocated FPN outputs) would overwrite the pending frame's maps
+        and detections before the tracker consumes them — detected through the storage addresses and refused
+        (RuntimeError): run such a detector with ``lookahead=False``."""
         self.loop.reset()
         if not lookahead:
             for frame_id, frame in frame_iterator:
@@ -229,6 +246,12 @@ class FrameSequenceRunner(object):
             features, detections = self.detector(self.preprocess(frame))
             if pending is not None:
                 pid, psize, pf, pd = pending
+                if _storage_overlap(pf, pd, features, detections):
+                    # the pending frame's maps / detections have just been overwritten: nothing correct can be produced
+                    raise RuntimeError(
+                        "FrameSequenceRunner(lookahead=True): the detector returned frame %r in the storage of frame %r, "
+                        "which the tracker had not consumed yet — it re-uses its output buffers; call it with "
+                        "lookahead=False or make it return fresh tensors" % (frame_id, pid))
                 yield pid, to_original_xywh(self.loop(pf, pd, next_features=features), psize)
             pending = (frame_id, size, features, detections)
         if pending is not None:

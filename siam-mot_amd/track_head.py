@@ -122,24 +122,44 @@ class _LazyMemory(object):
     solver's output buffers and the extraction's outputs (``pointers``) — building the views costs ~8 us of host time on the
     frame's serial chain and, frame after frame, nobody looks at them.  Indexing / iterating / ``len`` behave like the
     tuple."""
-    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls", "hint_ptr",
+    __slots__ = ("_val", "fbuf", "ibuf", "templates", "sr_rows", "M", "A", "size", "sr_size", "host_ids", "cls", "hint_off",
                  "n_act", "dormant")
 
-    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls, hint_ptr=0, n_act=None, dormant=()):
+    def __init__(self, fbuf, ibuf, templates, sr_rows, M, A, size, sr_size, host_ids, cls, hint_off=0, n_act=None, dormant=()):
         self._val = None
         self.fbuf, self.ibuf, self.templates, self.sr_rows = fbuf, ibuf, templates, sr_rows
         self.M, self.A, self.size, self.sr_size, self.host_ids, self.cls = M, A, size, sr_size, host_ids, cls
         self.n_act = A if n_act is None else n_act          # rows 0 .. n_act-1 are active tracks, the rest dormant ones
         self.dormant = dormant                              # ids of rows n_act .. A-1, in row order
-        # device address of the order hint the masked extraction wrote for exactly rows 0 .. A-1 (it lives behind the
-        # frame's float outputs in `fbuf`), or 0.  It needs no host object: the memory IS the extraction's output, untouched
-        # — the condition under which this class is used at all — so the hint is valid by construction.
-        self.hint_ptr = hint_ptr
+        # where in `fbuf` (in floats, behind the frame's float outputs) the order hint lives that the masked extraction wrote
+        # for exactly rows 0 .. A-1, or 0: none.  An OFFSET, not an address (ADVICE r4): a deep copy / pickle of the loop
+        # mid-video copies `fbuf` and the hint with it.  It needs no host object — and the head VERIFIES the list against the
+        # rows it is given with (csrc/sr_xcorr.hip, fx_verify_hint), so a stale one is reported, not used.
+        self.hint_off = hint_off
+
+    @property
+    def hint_ptr(self):
+        return self.fbuf.data_ptr() + 4 * self.hint_off if self.hint_off else 0
+
+    def hint_status(self):
+        """Status word of this memory's order hint (0 = fine / no hint).  Synchronises: error paths and tests only."""
+        if not self.hint_off:
+            return 0
+        w = self.hint_off + ops.HINT_STATUS_WORD
+        return int(self.fbuf[w:w + 1].view(torch.int32).item())
+
+    def clear_hint_status(self):
+        """Zero the hint's status word on the current stream (after a speculative head that was launched on a guessed row
+        count and discarded: its verification failed by construction)."""
+        if self.hint_off:
+            w = self.hint_off + ops.HINT_STATUS_WORD
+            self.fbuf[w:w + 1].zero_()
 
     def pointers(self):
         """(template boxes, search regions, templates, ids, labels, order hint or 0) of rows 0 .. A-1 as device addresses."""
         fp, ip, M = self.fbuf.data_ptr(), self.ibuf.data_ptr(), self.M
-        return fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M, self.hint_ptr
+        return (fp + 16 * M, self.sr_rows.data_ptr(), self.templates.data_ptr(), ip + 16 * M, ip + 24 * M,
+                fp + 4 * self.hint_off if self.hint_off else 0)
 
     def carry_pointers(self):
         """(templates, boxes, search regions, ids, labels, scores) as device addresses: ``ops.memory_carry``'s order."""
@@ -202,7 +222,7 @@ class TrackingLoop(torch.nn.Module):
         # per-frame caches (ctypes blocks, library handles, the trusted-memory marker) are rebuilt on demand: a copy or a
         # pickle of the loop carries none of them
         d = self.__dict__.copy()
-        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head", "_prev_n_trk"):
+        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head", "_prev_n_trk", "_early_head", "_prev_K"):
             d.pop(k, None)
         return d
 
@@ -379,7 +399,8 @@ class TrackingLoop(torch.nn.Module):
                                        fp + 36 * M), M, rows, A, templates[0].numel(), dev, ops._stream(dev))
         return ids, rows, False
 
-    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None, hint_ptr=0, carried_ahead=None):
+    def _finish_frame(self, features, detections, rec_host, fbuf, ibuf, M, pre, P=None, hint_off=0, carried_ahead=None,
+                      pre_out=None):
         """After the record arrived: mirror the pool, slice the outputs, build the next track memory.  This is host work on
         the frame's serial chain: ten strided views straight off the two output buffers (no intermediate splits), the
         record through the ring's numpy view, BoxLists of this package's own class without re-validation."""
@@ -391,13 +412,21 @@ class TrackingLoop(torch.nn.Module):
         view = ring.view(rec_host) if ring is not None and (rec_host is ring.bufs[0] or rec_host is ring.bufs[1]) else rec_host.numpy()
         rec = view[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
+        if rec[6] & 2:
+            # a propagated track came in with a NaN score: what a head writes whose order hint failed the kernel's
+            # verification (include/smot_emm.h, order_hint) — ask the hint; NaN features give NaN scores too and pass
+            self._raise_on_bad_hint(self.__dict__.get("track_memory"))
         pool._mirror(rec, M)
         cls, size = detections.__class__, detections.size
         st = torch.as_strided
         # fbuf = out_boxes [4M] | act_boxes [4M] | out_scores [M] | act_scores [M]; ibuf = out_ids | out_labels | act_ids | act_labels
-        ob, oi, osc, ol = st(fbuf, (K, 4), (4, 1), 0), st(ibuf, (K,), (1,), 0), st(fbuf, (K,), (1,), 8 * M), st(ibuf, (K,), (1,), M)
         own = cls is BoxList
-        if own:
+        if not (pre_out is not None and pre_out[0] == K):
+            ob, oi, osc, ol = (st(fbuf, (K, 4), (4, 1), 0), st(ibuf, (K,), (1,), 0), st(fbuf, (K,), (1,), 8 * M),
+                               st(ibuf, (K,), (1,), M))
+        if pre_out is not None and pre_out[0] == K:
+            out = pre_out[1]              # the output's views were built before the record arrived, on the right row count
+        elif own:
             out = BoxList._wrap(ob, size, "xyxy", {"ids": oi, "scores": osc, "labels": ol})
         else:
             out = cls(ob, size, mode="xyxy")
@@ -423,7 +452,7 @@ class TrackingLoop(torch.nn.Module):
                     self.__dict__["_carry_ahead_kept"] = carried[2]
                 pad2 = emm.track_utils.pad_pixels * 2
                 memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A + D, size, [int(size[0] + pad2), int(size[1] + pad2)],
-                                     host_ids, cls, hint_ptr if (A >= 2 and D == 0) else 0, A, list(dormant))
+                                     host_ids, cls, hint_off if (A >= 2 and D == 0) else 0, A, list(dormant))
                 pool.note_memory(memory, memory.host_ids)
                 self.__dict__["track_memory"] = memory
                 self.__dict__["_own_memory"] = memory
@@ -459,6 +488,22 @@ class TrackingLoop(torch.nn.Module):
         self.__dict__["track_memory"] = memory
         self.__dict__["_own_memory"] = memory          # built here from this package's own kernels' outputs: the next
         return out                                     # frame's head takes its tensors without re-checking them
+
+    @staticmethod
+    def _raise_on_bad_hint(mem):
+        """``mem``: the track memory the frame's head ran on.  Raises when the order hint that went with it failed the head's
+        verification (the head's rows are NaN then)."""
+        status = 0
+        if type(mem) is _LazyMemory:
+            status = mem.hint_status()
+        elif mem is not None:
+            h = getattr(mem[1][0], "order_hint", None)
+            if h is not None:
+                status = ops.order_hint_status(h.data)
+        if status:
+            raise RuntimeError("siammot_amd.TrackingLoop: the order hint handed to this frame's head does not describe the "
+                               "track memory's rows (status %d): the head's output is NaN.  The memory was edited, re-ordered "
+                               "or replaced without dropping its hint" % status)
 
     # ---- the same frame through the frame entry point: two calls on a block that stays packed -------------------------
     def _native_ok(self, detections):
@@ -618,12 +663,20 @@ class TrackingLoop(torch.nn.Module):
         if spec is not None and not (head_ptrs is not None and not repack and spec[0] is mem and spec[1] == n_trk
                                      and type(mem) is _LazyMemory and mem._val is None
                                      and spec[2] is features and spec[3] == blk.a_pp):
+            if spec[5] and spec[0] is mem:
+                mem.clear_hint_status()                   # (see the other discard below)
+            ops.SPECULATION["early_discarded" if spec[7] else "discarded"] += 1
             spec = None                                   # the guess did not hold: the head runs again, below
-            ops.SPECULATION["discarded"] += 1
+        tf_cap = n_trk                    # rows the head's output buffer `tf` is laid out for: boxes | scores | refined boxes | refined scores
         if spec is not None:
-            tf = spec[4]                                  # the head of this frame has been running since the last call
-            need = P.ws_need[n_trk]
-            ops.SPECULATION["used"] += 1
+            tf, tf_cap = spec[4], spec[6]                 # the head of this frame has been running since the last call /
+            need = P.ws_need.get(n_trk)                   # since this call's first line (early head: TrackingLoop.forward)
+            if need is None:
+                need = P.ws_need[n_trk] = (
+                    int(P.lib.smot_emm_track_ws_floats(n_trk, P.C, P.rx, P.rz)),
+                    int(P.lib.smot_box_refine_ws_floats(n_trk, P.C, a.box_pooled, a.dim6, a.dim7, a.num_classes, a.reg_classes))
+                    if a.refine else 0)
+            ops.SPECULATION["early_used" if spec[7] else "used"] += 1
         elif head_ptrs is not None:
             p_tbb, p_sr, p_z, p_ids, p_lab, p_hint = head_ptrs
             need = P.ws_need.get(n_trk)
@@ -667,7 +720,7 @@ class TrackingLoop(torch.nn.Module):
                 ti = torch.empty((2 * n_trk,), dtype=torch.int64, device=dev)
                 p = tf.data_ptr()
                 rw = ops._workspace(dev, need[1], ("refine", stream.value)).data_ptr()
-                r0, r1, r2, r3 = p + 20 * n_trk, p + 36 * n_trk, ti.data_ptr(), ti.data_ptr() + 8 * n_trk
+                r0, r1, r2, r3 = p + 20 * tf_cap, p + 36 * tf_cap, ti.data_ptr(), ti.data_ptr() + 8 * n_trk
                 stages |= ops.STAGE_REFINE
         # the dormant rows of the memory this frame's head ran on go behind the rows the solver leaves active, in the solver's
         # own launch (extra workgroups beside its one: no launch, no time on the chain) — on the guess that the dormant
@@ -693,11 +746,12 @@ class TrackingLoop(torch.nn.Module):
         if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
             hook = emm.__dict__.get("raw_output_hook")
             if hook is not None:
-                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * n_trk:5 * n_trk])
+                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * tf_cap:4 * tf_cap + n_trk])
             if a.refine:
                 hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
                 if hook is not None:
-                    hook(tf[5 * n_trk:9 * n_trk].view(n_trk, 4), tf[9 * n_trk:10 * n_trk], ti[:n_trk], ti[n_trk:])
+                    hook(tf[5 * tf_cap:5 * tf_cap + 4 * n_trk].view(n_trk, 4), tf[9 * tf_cap:9 * tf_cap + n_trk], ti[:n_trk],
+                         ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
         spec_tf = None
         if carried_ahead is None:
@@ -715,27 +769,87 @@ class TrackingLoop(torch.nn.Module):
             # (... and that the dormant tracks stay the ones they were: their rows went behind the active rows just above)
             spec_tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = spec_tf.data_ptr()
+            spec_hint = hint_ptr if (n_trk >= 2 and carried_ahead is None) else 0
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
-                                templates.data_ptr(), hint_ptr if (n_trk >= 2 and carried_ahead is None) else 0, ip + 16 * M,
+                                templates.data_ptr(), spec_hint, ip + 16 * M,
                                 ip + 24 * M, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)
             ops.SPECULATION["launched"] += 1
+            ops._geometry_refresh(P.g, features, dev)     # the plan's pointer array names THIS frame's maps again
+        early = None
+        if (spec_tf is None and M >= 1 and detections.__class__ is BoxList and self.__dict__.get("early_head", True)
+                and self.__dict__.get("lazy_memory", True)):
+            # No speculative head: the NEXT call's head launch is prepared NOW, while the GPU works on this frame — its
+            # output buffer, workspace and the nine pointers of the head's argument range (all of them addresses inside THIS
+            # frame's output buffers: the next memory, if it stays the unbuilt lazy one) — so that the next call can enqueue
+            # its head on its FIRST line (TrackingLoop.forward) and validate afterwards: what used to be ~12 us of host work
+            # between the record and the first launch of the next frame — the GPU idle — runs beside the GPU here.  The row
+            # count is this frame's, corrected after the record.
+            nm = P.ws_need.get(M)
+            if nm is None:
+                nm = P.ws_need[M] = (
+                    int(P.lib.smot_emm_track_ws_floats(M, P.C, P.rx, P.rz)),
+                    int(P.lib.smot_box_refine_ws_floats(M, P.C, a.box_pooled, a.dim6, a.dim7, a.num_classes, a.reg_classes))
+                    if a.refine else 0)
+            e_tf = torch.empty((10 * M,), dtype=torch.float32, device=dev)
+            p = e_tf.data_ptr()
+            a.poke_head((ops._workspace(dev, nm[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
+                         templates.data_ptr(), hint_ptr, ip + 16 * M, ip + 24 * M, p, p + 16 * M), max(n_trk, 1), ops.STAGE_HEAD)
+            early = (e_tf, stream.value, blk.a_pp)
+        # the frame's output BoxList, built NOW on the guess that it has as many rows as the last frame's (four strided views:
+        # ~6 us that would otherwise sit between the record and the return)
+        pre_out = None
+        Kg = self.__dict__.get("_prev_K")
+        if Kg is not None and Kg <= M and detections.__class__ is BoxList:
+            st = torch.as_strided
+            pre_out = (Kg, BoxList._wrap(st(fbuf, (Kg, 4), (4, 1), 0), detections.size, "xyxy",
+                                         {"ids": st(ibuf, (Kg,), (1,), 0), "scores": st(fbuf, (Kg,), (1,), 8 * M),
+                                          "labels": st(ibuf, (Kg,), (1,), M)}))
         ring.wait(rec_host, event=False)                                           # the frame's one synchronisation
-        out = self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P, hint_ptr=hint_ptr,
-                                 carried_ahead=carried_ahead)
+        out = self._finish_frame(features, detections, rec_host, fbuf, ibuf, M, (templates, sr_next), P, hint_off=hint_off,
+                                 carried_ahead=carried_ahead, pre_out=pre_out)
+        self.__dict__["_prev_K"] = len(out.bbox)
         if spec_tf is not None:
             # valid for exactly the memory _finish_frame just built, if it is the lazy one over these buffers with n_trk rows
             # — and its dormant rows, if any, are the ones that were copied before that head was enqueued
             m2 = self.__dict__.get("track_memory")
             if (type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk
                     and (m2.A == m2.n_act or self.__dict__.get("_carry_ahead_kept"))):
-                self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf)
+                self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf, spec_hint, n_trk, False)
             else:
                 ops.SPECULATION["discarded"] += 1        # the row count changed, or the dormant rows are not the ones copied ahead
+                # the discarded head VERIFIED the extraction's hint against a row count that was not the frame's and raised
+                # its status word: the head that runs again on the true rows must find it clear
+                if spec_hint and type(m2) is _LazyMemory and m2.fbuf is fbuf:
+                    m2.clear_hint_status()
+        self.__dict__["_early_head"] = None
+        if early is not None:
+            m2 = self.__dict__.get("track_memory")
+            if type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A >= 1:
+                # the head's argument range stands as poked above; the record brought the row count (and whether the
+                # extraction's hint describes all rows: not when dormant rows were carried behind them)
+                use_hint = hint_ptr if m2.hint_off else 0
+                if m2.A != max(n_trk, 1) or use_hint != hint_ptr:
+                    a.fix_head(m2.A, use_hint)
+                self.__dict__["_early_head"] = (m2, m2.A, early[0], early[1], early[2], use_hint, M, P)
         return out
 
     @torch.no_grad()
     def forward(self, features, detections, next_features=None):
+        eh = self.__dict__.get("_early_head")
+        if eh is not None:
+            # the head of THIS frame, prepared by the last call while the GPU was busy (see _step_native): enqueued before
+            # anything else — the checks that it is the right launch follow while it runs (the memory object untouched, the
+            # same stream and device, the maps' geometry here; parameters and packing in _step_native, which launches the
+            # head again when any of them moved: the early launch wrote its own output buffer only)
+            self.__dict__["_early_head"] = None
+            mem = self.__dict__.get("track_memory")
+            P = eh[7]
+            if (eh[0] is mem and mem._val is None and P is self.__dict__.get("_plan")
+                    and ops._stream(P.dev).value == eh[3] and ops._geometry_refresh(P.g, features, P.dev)):
+                ops.track_frame_addr(P.lib, P.args._addr, P.dev, ops._stream(P.dev))
+                ops.SPECULATION["early_launched"] += 1
+                self.__dict__["_spec_head"] = (mem, eh[1], features, eh[4], eh[2], eh[5], eh[6], True)
         if self._lean_ok(detections):
             if self._native_ok(detections):
                 if next_features is None:

@@ -78,6 +78,72 @@ class OracleEMM(torch.nn.Module):
         return z, [sr], [detection]
 
 
+class RecordedEMM(torch.nn.Module):
+    """The reference's OWN head outputs, replayed: ``forward`` returns the tracked boxes / scores the golden stores for
+    the current frame (``trk_boxes`` / ``trk_scores``, after checking that it is asked about the same ids and template
+    boxes), ``extract_cache`` the search regions (oracle arithmetic) and placeholder templates.  With it the host glue of
+    a whole sequence — TrackHead, solver, pool, dormant-row order, expiry — is pinned against the reference on CPU in
+    seconds, whatever the sequence's length and row count (``replay(..., features=False)``; set ``.t`` to the frame)."""
+
+    def __init__(self, golden, track_utils, case):
+        super(RecordedEMM, self).__init__()
+        self.golden, self.track_utils, self.case, self.t = golden, track_utils, case, 0
+        fam = gi.BENCH_FAMILIES[case.get("family", "default")]
+        self.e, self.min_wh = fam["search_region"] - 1.0, fam["min_search_wh"]
+        self.calls = 0
+
+    def forward(self, features, boxes, sr, targets=None, template_features=None):
+        p = "f%02d_" % self.t
+        b = boxes[0]
+        g = self.golden
+        assert b.get_field("ids").tolist() == g[p + "trk_ids"].tolist(), "frame %d: rows handed to the head" % self.t
+        assert np.abs(b.bbox.numpy() - g[p + "trk_tpl_boxes"]).max() < 1e-3, "frame %d: template boxes" % self.t
+        assert np.abs(sr[0].bbox.numpy() - g[p + "trk_sr_boxes"]).max() < 1e-2, "frame %d: search regions" % self.t
+        assert template_features.shape[0] == len(b)
+        self.calls += 1
+        out = b.__class__(torch.from_numpy(g[p + "trk_boxes"].copy()), b.size, mode="xyxy")
+        out.add_field("ids", b.get_field("ids"))
+        out.add_field("labels", b.get_field("labels"))
+        out.add_field("scores", torch.from_numpy(g[p + "trk_scores"].copy()))
+        return {}, [out], {}
+
+    def extract_cache(self, features, detection):
+        pad = self.track_utils.pad_pixels
+        sr_bbox = torch.from_numpy(gi.np_search_region(detection.bbox.numpy(), pad, self.e, self.min_wh))
+        w, h = detection.size
+        sr = detection.__class__(sr_bbox, [int(w + 2 * pad), int(h + 2 * pad)], mode="xyxy")
+        for f in detection.fields():
+            sr.add_field(f, detection.get_field(f))
+        # one float per row, tagged with the row's id: a dormant row's entry must come back as it went in
+        z = detection.get_field("ids").to(torch.float32).view(-1, 1, 1, 1).clone()
+        return z, [sr], [detection]
+
+
+class RecordedRefine(object):
+    """The reference's own box-head outputs for the propagated tracks, replayed (``ref_boxes`` / ``ref_scores`` of the
+    golden — the latter are the box head's scores, in its output order; ids / labels follow the class regrouping of
+    box_head/inference.py:164-191, which the golden's solver inputs reflect)."""
+
+    def __init__(self, golden, emm, num_classes):
+        self.golden, self.emm, self.num_classes = golden, emm, num_classes
+
+    def __call__(self, features, tracks):
+        t = tracks[0]
+        if len(t) == 0:
+            return tracks
+        p = "f%02d_" % self.emm.t
+        g = self.golden
+        track_scores = t.get_field("scores") + 1.0                                  # roi_heads.py:67
+        labels, ids = t.get_field("labels"), t.get_field("ids")
+        order = torch.cat([torch.nonzero(labels == j).squeeze(1) for j in range(1, self.num_classes)])   # filter_results
+        out = t.__class__(torch.from_numpy(g[p + "ref_boxes"].copy()), t.size, mode="xyxy")
+        det_scores = torch.from_numpy(g[p + "ref_scores"].copy())
+        out.add_field("scores", (det_scores + track_scores) / 2.0)                  # :73-76: input order + output order
+        out.add_field("ids", ids[order])
+        out.add_field("labels", labels[order])
+        return [out]
+
+
 def iou_rows(a, b):
     """IoU of matching rows (continuous boxes, no +1)."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
@@ -93,10 +159,10 @@ def load_golden(name):
 
 
 def detections_boxlist(inp, t, device, boxlist_cls=BoxList):
-    boxes, scores = inp.detections(t)
+    boxes, scores, labels = inp.detections(t, labels=True)
     bl = boxlist_cls(torch.from_numpy(boxes).to(device), inp.case["image_wh"], mode="xyxy")
     bl.add_field("ids", torch.full((len(boxes),), -1, dtype=torch.int64, device=device))
-    bl.add_field("labels", torch.ones(len(boxes), dtype=torch.int64, device=device))
+    bl.add_field("labels", torch.from_numpy(labels).to(device))
     bl.add_field("scores", torch.from_numpy(scores).to(device))
     return bl
 
@@ -151,7 +217,8 @@ SCORE_TOL = 1e-3       # scores in the closed loop.  Single frame pairs agree to
                        # frames (oracle with the reference's library calls vs the explicit restatements)
 
 
-def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, box_probe=None, prefetch=False):
+def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, box_probe=None, prefetch=False,
+           features=True, before_frame=None):
     """Run the loop over the sequence and compare every frame with the golden: ids, labels, pool state and memory
     ids must be IDENTICAL in every frame; boxes >= 1 - 1e-3 IoU, scores within 1e-4.  With ``probe``
     (``probe_tracker``) the raw head output is compared too, and a tracked row that lands one arg-max cell away from
@@ -172,11 +239,18 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
     ahead = None                  # (frame index, device tensors) of the frame prepared one call early (prefetch)
     for t in range(n_frames):
         p = "f%02d_" % t
-        feats_np = inp.features(t)
-        chk = np.array([float(f.astype(np.float64).sum()) for f in feats_np] +
-                       [float(np.abs(f.astype(np.float64)).sum()) for f in feats_np])
-        np.testing.assert_allclose(chk, golden[p + "feat_checksum"], rtol=1e-9, err_msg="inputs drifted, frame %d" % t)
-        if ahead is not None and ahead[0] == t:
+        if before_frame is not None:
+            before_frame(t)
+        if not features:                 # (a recorded head: nothing reads the maps, only their device)
+            feats = (torch.zeros(1),)
+        else:
+            feats_np = inp.features(t)
+            chk = np.array([float(f.astype(np.float64).sum()) for f in feats_np] +
+                           [float(np.abs(f.astype(np.float64)).sum()) for f in feats_np])
+            np.testing.assert_allclose(chk, golden[p + "feat_checksum"], rtol=1e-9, err_msg="inputs drifted, frame %d" % t)
+        if not features:
+            pass
+        elif ahead is not None and ahead[0] == t:
             feats = ahead[1]                                                      # the SAME tensors the last call was shown
         else:
             feats = tuple(torch.from_numpy(f).to(device) for f in feats_np)
@@ -221,8 +295,10 @@ def replay(loop, inp, golden, device, frames=None, on_frame=None, probe=None, bo
             bb, bs, bi = [x.cpu().numpy() if x is not None else None for x in box_probe["last"]]
             if bs is None:
                 bs = golden[p + "ref_scores"]
-            assert bi.tolist() == golden[p + "trk_ids"].tolist(), "box-head rows: %s\n got %s\n ref %s" % (
-                ctx, bi.tolist(), golden[p + "trk_ids"].tolist())
+            # (rows come back in input order for one foreground class, regrouped by class otherwise: stored as `ref_ids`)
+            want_rows = golden[p + "ref_ids"] if (p + "ref_ids") in golden.files else golden[p + "trk_ids"]
+            assert bi.tolist() == want_rows.tolist(), "box-head rows: %s\n got %s\n ref %s" % (
+                ctx, bi.tolist(), want_rows.tolist())
             cl = np.array([int(i) not in tainted for i in bi])
             be, se = np.abs(bb - golden[p + "ref_boxes"]).max(axis=1), np.abs(bs - golden[p + "ref_scores"])
             stats["box_head_max_box_err"] = max(stats.get("box_head_max_box_err", 0.0), float(be[cl].max(initial=0.0)))

@@ -1143,6 +1143,72 @@ def test_order_hint_lists_the_rois_in_cost_order_and_changes_nothing(ops, n):
         head(hint[:n - 1])
 
 
+@pytest.mark.parametrize("n", [2, 30, 100, 256])
+def test_order_hint_is_verified_by_the_head_not_trusted(ops, n):
+    """``fx_assign`` used to take the roi, its FPN level and its index from the hint entry without
+    looking at ``sr[n]`` / ``boxes[n]``.  Now every roi's by-roi record is compared with the launch's own tensors
+    (fx_verify_hint): a hint made for OTHER boxes, for the same boxes in another order, for one roi more, or for a roi
+    whose search region was edited raises the list's status word and the head returns NaN in every row — reported, never
+    silently wrong; the right hint leaves the word at 0 and changes no result (sr_pool.py:53-91: results depend on
+    ``boxes`` / ``sr`` only)."""
+    rs = np.random.RandomState(2300 + n)
+    g = torch.Generator().manual_seed(n)
+    C = 32
+    feats = tuple(torch.randn((1, C, 352 // s, 640 // s), generator=g).to(DEV) for s in (4, 8, 16, 32))
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+
+    def some_boxes(m):
+        wh = np.exp(rs.uniform(np.log(16), np.log(300), (m, 1))) * np.array([[1.0, 1.6]])
+        xy = rs.uniform(0, 1, (m, 2)) * np.maximum(np.array([640.0, 352.0]) - wh, 1.0)
+        return np.concatenate((xy, xy + wh), 1).astype(np.float32)
+    b1_np = some_boxes(n)
+    b1, b2 = _d(b1_np), _d(some_boxes(n))
+    params = {k: _d(v) for k, v in gi.predictor_params(rs, C, b1_np).items()}
+
+    def extract(b):
+        return ops.emm_extract_cache(feats, b, 15, scales, 2, 512, 1.0, 0, hint=True)
+
+    def head(b, sr, z, hh):
+        return ops.emm_track(feats, b, sr, z, params, 30, 15, scales, 2, 512, clip_wh=(640, 352), order_hint=hh)
+    z1, sr1, h1 = extract(b1)
+    z2, sr2, h2 = extract(b2)
+    want = head(b1, sr1, z1, None)
+    # the right hint: same rows, status clear
+    got = head(b1, sr1, z1, h1)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and ops.order_hint_status(h1) == 0
+    # a hint of other boxes
+    bad = head(b1, sr1, z1, h2)
+    assert bool(torch.isnan(bad[0]).all()) and bool(torch.isnan(bad[1]).all()) and ops.order_hint_status(h2) != 0
+    # the same rois in another order (a re-ordered memory that kept its hint)
+    perm = torch.from_numpy(np.roll(np.arange(n), 1)).to(DEV)
+    z3, sr3, h3 = extract(b1)
+    bad = head(b1[perm].contiguous(), sr3[perm].contiguous(), z3[perm].contiguous(), h3)
+    assert bool(torch.isnan(bad[0]).all()) and ops.order_hint_status(h3) != 0
+    # one search region edited in place behind the hint's back (one ulp is enough: the comparison is bit for bit)
+    z4, sr4, h4 = extract(b1)
+    sr4[n // 2, 1] = torch.nextafter(sr4[n // 2, 1], sr4[n // 2, 1] + 1)
+    bad = head(b1, sr4, z4, h4)
+    assert bool(torch.isnan(bad[1]).all()) and ops.order_hint_status(h4) != 0
+    # a template box that moved to another FPN level (the hint carries the level the extraction derived)
+    z5, sr5, h5 = extract(b1)
+    b5 = b1.clone()
+    b5[0] = torch.tensor([0.0, 0.0, 600.0, 340.0], device=DEV) if float((b1[0, 2] - b1[0, 0])) < 150 else \
+        torch.tensor([10.0, 10.0, 30.0, 40.0], device=DEV)
+    lv = ops.roi_align_levels(feats, b5, b5, 15, scales, 2, return_levels=True)[1]
+    lv1 = ops.roi_align_levels(feats, b1, b1, 15, scales, 2, return_levels=True)[1]
+    assert int(lv[0]) != int(lv1[0])
+    bad = head(b5, sr5, z5, h5)
+    assert bool(torch.isnan(bad[0]).all()) and ops.order_hint_status(h5) != 0
+    # a list that ranks one roi more than the head is given (n - 1 rows with the first n - 1 entries of the n-roi list)
+    if n > 2:
+        z6, sr6, h6 = extract(b1)
+        bad = head(b1[:n - 1], sr6[:n - 1], z6[:n - 1], h6[:n - 1])
+        assert bool(torch.isnan(bad[0]).all()) and ops.order_hint_status(h6) != 0
+    # and nothing of this leaks: the untouched list still gives the un-hinted result
+    got = head(b1, sr1, z1, h1)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]) and ops.order_hint_status(h1) == 0
+
+
 @pytest.mark.parametrize("n", [1, 9, 30, 70])
 def test_template_extraction_of_the_second_yaml_family_in_one_launch(ops, n):
     """``extract_cache`` at the 7x7 template of DLA_34_FPN_EMM_AOT.yaml (pad 256, search regions x5): one launch of the

@@ -50,7 +50,15 @@ def _cpu_loop(name):
     return inp, emm, TrackingLoop(TrackHead(emm, tu, pool).eval(), solver, refine).eval()
 
 
-@pytest.mark.parametrize("name", ["plain", "refine", "aot", "amodal"])
+# frames of each case the oracle head replays on CPU (None: all).  The round-5 cases cost seconds per frame at their row
+# counts (crowd: 60-190 rows with a box head; multiclass: 256-channel 1080p maps): their first frames pin the oracle +
+# box-head arithmetic in the loop, test_host_glue_replays_... below pins the host logic over EVERY frame, the device tests
+# run every frame with the real head.
+CPU_FRAMES = {"amodal": 10, "crowd": 3, "longdormant": 6, "multiclass": 4}
+CPU_FLOOR = {"plain": 300, "refine": 300, "aot": 60, "amodal": 100, "crowd": 60, "longdormant": 35, "multiclass": 25}
+
+
+@pytest.mark.parametrize("name", ["plain", "refine", "aot", "amodal", "crowd", "longdormant", "multiclass"])
 def test_closed_loop_on_cpu_equals_the_reference(name):
     """Oracle head + this repository's TrackHead / solver / pool (+ RefineTracks / TrackBoxHead over the oracle
     pooler) reproduce the reference's closed loop: same ids, same pool, boxes to fp32 rounding — every event type
@@ -58,10 +66,11 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
     golden = SR.load_golden(name)
     for ev in ("start", "suspend", "resume", "expire"):
         assert int(golden["events_" + ev]) > 0, ev
+    # (crowd512 — 110-350 rows per frame — is replayed by the recorded-head test below and on the device only)
     inp, emm, loop = _cpu_loop(name)
     # (the amodal + given-detections case replays its first ten frames here: the oracle head and box head on CPU cost
     # seconds per frame at 30-40 rows; the device test runs every frame)
-    frames = 10 if name == "amodal" else None
+    frames = CPU_FRAMES.get(name)
     with torch.no_grad():
         # ("plain" is replayed with every call shown the next frame's features: on the general path — no device, no
         # one-launch frame — the argument is accepted and changes nothing)
@@ -69,8 +78,54 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
                           box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None,
                           prefetch=(name == "plain"))
     assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-5 and stats["raw_max_box_err"] < 1e-2, stats
-    floor = {"plain": 300, "refine": 300, "aot": 60, "amodal": 100}[name]
+    floor = CPU_FLOOR[name]
     assert stats["tracked_rows"] > floor and stats["raw_rows"] > floor, stats
+
+
+@pytest.mark.parametrize("name", ["plain", "refine", "amodal", "crowd", "crowd512", "longdormant", "multiclass"])
+def test_host_glue_replays_every_frame_of_the_reference_sequences_on_recorded_head_outputs(name):
+    """VERDICT r4 next #1, host half: the reference's own head (and box-head) outputs of every frame, replayed through this
+    repository's TrackHead / TrackSolver / TrackPool / TrackingLoop (general path, CPU): ids, labels, scores, pool state,
+    memory row order and the dormant rows' entries equal the reference's in EVERY frame of every sequence — including the
+    regimes the round-4 goldens never reached: > 128 / > 256 / > 512 rows, 30-frame dormancy with expiry and resumption
+    after tens of frames, two foreground classes regrouped by the box head (track_solver.py:36-108,
+    track_utils.py:152-178, box_head/inference.py:164-191 vs roi_heads.py:67-76)."""
+    golden = SR.load_golden(name)
+    inp = gi.SequenceInputs(name)
+    case = inp.case
+    cfg = SR.sequence_cfg(case)
+    tu = build_track_utils(cfg)
+    pool = TrackPool(max_dormant_frames=case["max_dormant_frames"])
+    emm = SR.RecordedEMM(golden, tu, case)
+    refine = SR.RecordedRefine(golden, emm, case["box_head"]["num_classes"]) if case["refine"] else None
+    solver = TrackSolver(pool, *case["thresholds"], nms_mask_fn=_numpy_mask)
+    loop = TrackingLoop(TrackHead(emm, tu, pool).eval(), solver, refine).eval()
+    seen = dict(rows=0, max_rows=0, max_boxes=0, dormant=0, tags=0)
+
+    def before(t):
+        emm.t = t
+
+    def after(t, out):
+        mem = loop.track_memory
+        ids = mem[2][0].get_field("ids")
+        if len(ids):
+            # every row's template is the one extracted when its track was last active (tagged with the id)
+            assert mem[0].view(-1).tolist() == ids.to(torch.float32).tolist(), "frame %d: memory templates" % t
+            seen["tags"] += len(ids)
+        n_trk = len(golden["f%02d_trk_ids" % t]) if ("f%02d_trk_ids" % t) in golden.files else 0
+        seen["rows"] += n_trk
+        seen["max_rows"] = max(seen["max_rows"], n_trk)
+        seen["max_boxes"] = max(seen["max_boxes"], n_trk + len(golden["f%02d_det_boxes" % t]))
+        seen["dormant"] = max(seen["dormant"], len(pool._dormant_ids))
+    with torch.no_grad():
+        stats = SR.replay(loop, inp, golden, "cpu", features=False, before_frame=before, on_frame=after)
+    assert stats["flips"] == [] and stats["min_iou"] > 1 - 1e-6 and stats["max_score_err"] < 1e-6, stats
+    assert stats["frames"] == case["frames"] and emm.calls >= case["frames"] - 2
+    print("recorded replay %s: %s %s" % (name, stats, seen))
+    want = {"crowd": dict(max_rows=131), "crowd512": dict(max_rows=257, max_boxes=513),
+            "longdormant": dict(dormant=60)}.get(name, {})
+    for k, v in want.items():
+        assert seen[k] >= v, (k, seen)
 
 
 def _gpu_loop(name, lean):
@@ -95,11 +150,20 @@ def _gpu_loop(name, lean):
     return inp, emm, loop
 
 
+# the round-5 sequences and the capacity fallback each of them must actually take on the fast paths
+# (siammot_amd.ops.FALLBACKS): crowd -> more refinement rows than the weight-streaming kernels take; crowd512 -> more rois
+# than an order hint ranks and more boxes than the one-launch solver takes (general frame + host solver);
+# longdormant / multiclass -> none by design (the device paths must hold up in those regimes)
+ROUND5 = ("crowd", "crowd512", "longdormant", "multiclass")
+MUST_FALL_BACK = {"crowd": ("refine_library_gemm",), "crowd512": ("host_solver", "general_frame")}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,lean", [("plain", False), ("plain", True), ("plain", "python"), ("refine", False),
                                        ("refine", True), ("refine", "python"), ("aot", False), ("aot", True),
                                        ("aot", "python"), ("amodal", False), ("amodal", True), ("amodal", "python"),
-                                       ("plain", "ahead"), ("refine", "ahead"), ("aot", "ahead"), ("amodal", "ahead")])
+                                       ("plain", "ahead"), ("refine", "ahead"), ("aot", "ahead"), ("amodal", "ahead")] +
+                         [(n_, l_) for n_ in ROUND5 for l_ in (False, True, "python", "ahead")])
 def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     """The real head in the loop, on the device: (i) general path, (ii) one-launch path behind ONE library call
     (smot_track_frame_fwd), ("python") the same sequence composed in Python, (iii) refinement on (all three).  ids / labels / pool / memory ids identical in every frame; boxes >= 1 - 1e-3 IoU; a row
@@ -111,9 +175,10 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     ahead = lean == "ahead"
     lean = True if ahead else lean
     inp, emm, loop = _gpu_loop(name, lean)
-    taken = {"lean": 0}
+    taken = {"lean": 0, "other": 0}
+    import siammot_amd.ops as ops_a
+    fb0 = dict(ops_a.FALLBACKS)
     if ahead:
-        import siammot_amd.ops as ops_a
         ops_a.SPECULATION.clear()
     if lean:
         which = "_step_lean" if lean == "python" else "_step_native"
@@ -124,6 +189,14 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
             taken["lean"] += 1
             return step(*a, **k)
         setattr(loop, which, counted)
+        if lean != "python":
+            # (a frame beyond the one-call frame's capacities — crowd: > 128 refinement rows — takes the Python-composed form)
+            step2 = loop._step_lean
+
+            def counted2(*a, **k):
+                taken["other"] += 1
+                return step2(*a, **k)
+            loop._step_lean = counted2
     hinted = {"frames": 0}
     if lean is True:
         # the frame entry point hands the extraction's order hint to the next head as a bare address (no host object)
@@ -146,12 +219,26 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
         sp = dict(ops_a.SPECULATION)
         print("speculative heads:", sp)
         assert sp.get("used", 0) + sp.get("discarded", 0) == sp.get("launched", 0)
-    if lean:
+    fb = {k: v - fb0.get(k, 0) for k, v in ops_a.FALLBACKS.items() if v != fb0.get(k, 0)}
+    print("fallbacks taken:", fb, "frames by path:", taken)
+    if lean and name not in MUST_FALL_BACK:
         assert taken["lean"] == stats["frames"], "the lean path was not taken on every frame: %s" % taken
+    elif lean:
+        assert taken["lean"] + taken["other"] + fb.get("general_frame", 0) == stats["frames"] and taken["lean"] >= 2, (taken, fb)
+    if lean:
+        # the capacity cliffs this sequence was built to cross WERE crossed on the fast paths, and only those
+        for k in MUST_FALL_BACK.get(name, ()):
+            assert fb.get(k, 0) > 0, "fallback %r never taken: %s" % (k, fb)
+        for k in ("host_solver", "general_frame", "refine_library_gemm", "dormant_rows_on_the_host"):
+            if k not in MUST_FALL_BACK.get(name, ()) and name in ROUND5:
+                assert fb.get(k, 0) == 0, "unexpected fallback %r: %s" % (k, fb)
     # (frames whose memory was merged with dormant tracks' rows carry no hint — most frames of these sequences; the steady
     # state with the hint is pinned by test_frame_entry_point_hands_the_order_hint_to_the_next_head)
-    # none is observed; a row one cell away is tolerated only where the REFERENCE's own stored margin is below FLIP_MARGIN
-    assert len(stats["flips"]) <= 2 and all(m < SR.FLIP_MARGIN for (_, _, m, _) in stats["flips"]), stats
+    # none is observed in the round-3/4 sequences; a row one cell away is tolerated only where the REFERENCE's own stored
+    # margin is below FLIP_MARGIN (the round-5 sequences hold 1.8 k - 6 k arg-max decisions each, a handful of them with
+    # margins of 2e-7 .. 2e-6: at most one flip per thousand decisions)
+    assert len(stats["flips"]) <= max(2, stats["raw_rows"] // 1000) and all(
+        m < SR.FLIP_MARGIN for (_, _, m, _) in stats["flips"]), stats
     assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < 1e-4, stats
 
 
@@ -281,6 +368,101 @@ def test_frame_entry_point_hands_the_order_hint_to_the_next_head():
     for (b1, s1, i1), (b0, s0, i0) in zip(out_h, out_0):
         assert torch.equal(i1, i0) and torch.equal(b1, b0) and torch.equal(s1, s0)
     assert int((out_h[-1][2] >= 0).sum()) >= n - 1
+
+
+def _holding_loop(n=9):
+    """A loop whose head HOLDS its tracks (the construction of test_frame_entry_point_hands_the_order_hint_to_the_next_head):
+    returns (inp, loop, feats of two alternating frames, detections(t))."""
+    from siammot_amd.structures import BoxList
+    inp, emm, loop = _gpu_loop("plain", True)
+    loop.native_frame = True
+    dev = "cuda:0"
+    feats = [tuple(torch.from_numpy(f).to(dev) for f in inp.features(t)) for t in range(2)]
+    mw, mh = 64.0, 128.0
+    wh = np.tile(np.array([[mw, mh]], np.float32), (n, 1))
+    xy = np.stack([(np.arange(n) % 3) * 420.0 + 20.0, (np.arange(n) // 3) * 230.0 + 5.0], 1).astype(np.float32)
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], 1)).to(dev)
+    with torch.no_grad():
+        pr = emm.predictor
+        for name in ("cls", "center", "reg"):
+            getattr(pr, name).weight.zero_()
+            getattr(pr, name).bias.zero_()
+        dx, dy = (2.0 * mw + 1.0) / 958.0, (2.0 * mh + 1.0) / 958.0
+        pr.reg.bias.copy_(torch.tensor([0.5 * mw + dx, 0.5 * mh + dy, 0.5 * mw - dx, 0.5 * mh - dy]))
+    loop.solver.track_thresh = 0.0
+
+    def dets(t):
+        d = BoxList(boxes + 0.25 * (t & 1), inp.case["image_wh"], mode="xyxy")
+        d.add_field("ids", torch.full((n,), -1, dtype=torch.int64, device=dev))
+        d.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
+        d.add_field("scores", torch.full((n,), 0.97, device=dev))
+        return d
+    return inp, loop, feats, dets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("edit", ["search region", "row order", "row count"])
+def test_a_stale_order_hint_in_the_tracking_loop_is_reported_not_used(edit):
+    """the loop hands the extraction's order hint to the next head as a bare address.  The head
+    VERIFIES it against the rows it is given (csrc/sr_xcorr.hip fx_verify_hint); a memory edited behind the loop's back —
+    a search region moved, two rows swapped, a row dropped — without dropping the hint makes that head write NaN rows, the
+    solver's record carries the flag and the loop RAISES: never a silently wrong frame.  (The same edits through the
+    memory's public tuple interface drop the hint and just work: last assertion.)"""
+    from siammot_amd.track_head import _LazyMemory
+    inp, loop, feats, dets = _holding_loop()
+    loop.reset()
+    for t in range(4):
+        out = loop(feats[t & 1], dets(t))
+    mem = loop.track_memory
+    assert type(mem) is _LazyMemory and mem.hint_off and mem._val is None and mem.hint_status() == 0
+    if edit == "search region":
+        mem.sr_rows[2] += 16.0
+    elif edit == "row order":
+        tmp = mem.sr_rows[1].clone()
+        mem.sr_rows[1] = mem.sr_rows[5]
+        mem.sr_rows[5] = tmp
+    else:
+        mem.A -= 1                                 # the hint ranks one roi more than the head is given
+        mem.n_act -= 1
+        mem.host_ids = mem.host_ids[:-1]
+    with pytest.raises(RuntimeError, match="order hint"):
+        loop(feats[0], dets(4))
+    assert mem.hint_status() != 0
+    # the same kind of edit through the tuple interface: the memory is materialised, its hint is not passed, nothing is wrong
+    loop.reset()
+    for t in range(4):
+        loop(feats[t & 1], dets(t))
+    z, sr, tb = loop.track_memory
+    sr[0].bbox[2] += 16.0
+    out = loop(feats[0], dets(4))
+    assert bool(torch.isfinite(out.bbox).all()) and int((out.get_field("ids") >= 0).sum()) >= 8
+
+
+@pytest.mark.gpu
+def test_a_deep_copy_of_the_loop_mid_video_runs_on_its_own_buffers():
+    """the unbuilt memory used to keep the hint as a raw device ADDRESS into the original loop's buffer; a
+    deep copy then ran its first head on a hint in storage it did not own.  The hint is an offset into the memory's own
+    buffer now: the copy continues exactly like the original, also after the original's buffers were overwritten."""
+    import copy
+    inp, loop, feats, dets = _holding_loop()
+    loop.reset()
+    for t in range(4):
+        loop(feats[t & 1], dets(t))
+    twin = copy.deepcopy(loop)
+    m0, m1 = loop.track_memory, twin.track_memory
+    assert m1.fbuf.data_ptr() != m0.fbuf.data_ptr() and m1.hint_off == m0.hint_off != 0
+    assert m1.hint_ptr == m1.fbuf.data_ptr() + 4 * m1.hint_off
+    ref = []
+    for t in range(4, 8):
+        o = loop(feats[t & 1], dets(t))
+        ref.append((o.bbox.clone(), o.get_field("scores").clone(), o.get_field("ids").clone()))
+    m0.fbuf.fill_(float("nan"))                    # what the original left behind is gone
+    m0.templates.fill_(float("nan"))
+    for t in range(4, 8):
+        o = twin(feats[t & 1], dets(t))
+        b, s_, i = ref[t - 4]
+        assert torch.equal(o.get_field("ids"), i) and torch.equal(o.bbox, b) and torch.equal(o.get_field("scores"), s_)
+    assert int((ref[-1][2] >= 0).sum()) >= 8
 
 
 @pytest.mark.gpu

@@ -460,14 +460,19 @@ class _FrameEntryEmulation(object):
             nsr[:A] = act + np.float32(self.pad)
 
 
-def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(monkeypatch):
+@pytest.mark.parametrize("mode", ["ahead", "early"])
+def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(monkeypatch, mode):
     """``TrackingLoop._step_native`` — the default path: two calls of the frame entry point per frame on a block that stays
     packed, the next frame's head launched before the record is read when the caller shows the next features, the dormant
     rows carried inside the solver's launch on a guess — with the library call emulated on CPU memory
     (``_FrameEntryEmulation`` reads the argument block as the library does), against the general path on 200 frames of
     churning and calm traffic: outputs identical in every frame, memory and pool identical whenever they are compared
     (every third frame: looking at a memory builds it, and a built memory takes no speculative head — on purpose), both
-    outcomes of both guesses occur."""
+    outcomes of both guesses occur.
+    ``mode == "early"`` (round 5): the reference's one-frame contract — ``TrackingLoop.forward(features, detections)``, no
+    next frame shown —: every call prepares the NEXT call's head launch while the (emulated) GPU works and the next call
+    enqueues it on its first line, validating afterwards; the row count poked on a guess is corrected from the record.
+    Same comparison; the early head must be the one used on (nearly) every frame whose memory nobody looked at."""
     import ctypes
     import types
     import siammot_amd.ops as ops_
@@ -512,8 +517,11 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
         def next(self):
             return torch.zeros(8 + 4 * 512 + 3 * cap, dtype=torch.int32)
     monkeypatch.setattr(pa, "host_record_ring", lambda dev: Ring(), raising=False)
-    for key in ("launched", "used", "discarded"):
+    for key in ("launched", "used", "discarded", "early_launched", "early_used", "early_discarded"):
         ops_.SPECULATION[key] += 0
+    if mode == "early":
+        loops[0]._lean_ok = lambda d: True
+        loops[0]._native_ok = lambda d: True
     sp0, mc0 = dict(ops_.SPECULATION), dict(ops_.MEMORY_CARRY)
     fb0 = ops_.FALLBACKS["dormant_rows_on_the_host"]
     rs = [np.random.RandomState(33), np.random.RandomState(33)]
@@ -524,7 +532,12 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
             for sv in (loops[0].solver, loops[1].solver, host.solver):      # the calm stretch (see the test above)
                 sv.track_thresh, sv.start_thresh, sv.resume_track_thresh = 0.0, 2.0, 2.0
                 sv.track_pool._max_dormant_frames = 1000
-        a = loops[0]._step_native(feats, detections(rs[0], f), next_features=feats)
+        heads0 = emu.heads
+        if mode == "early":
+            a = loops[0](feats, detections(rs[0], f))
+        else:
+            a = loops[0]._step_native(feats, detections(rs[0], f), next_features=feats)
+        assert emu.heads - heads0 <= 2                       # (a head launched early / ahead and, at most, launched again)
         b = loops[1](feats, detections(rs[1], f))
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
         assert torch.equal(a.get_field("scores"), b.get_field("scores")) and torch.equal(a.get_field("labels"), b.get_field("labels"))
@@ -539,10 +552,17 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
                 assert torch.equal(ma[2][0].get_field(fld), mb[2][0].get_field(fld)), "memory %s, frame %d" % (fld, f)
             assert [int(t) for t in ma[2][0].host_ids] == mb[2][0].get_field("ids").tolist()
             compared += 1
-    sp = {k: ops_.SPECULATION[k] - sp0.get(k, 0) for k in ("launched", "used", "discarded")}
+    sp = {k: ops_.SPECULATION[k] - sp0.get(k, 0) for k in ("launched", "used", "discarded", "early_launched", "early_used",
+                                                           "early_discarded")}
     mc = {k: ops_.MEMORY_CARRY[k] - mc0.get(k, 0) for k in ("in_the_solver_launch", "ahead_kept", "ahead_redone", "launched")}
-    # (the last frame's speculative head may still be waiting for a call that never comes)
-    assert sp["launched"] - sp["used"] - sp["discarded"] in (0, 1) and sp["used"] >= 20 and sp["discarded"] >= 10, sp
+    if mode == "early":
+        # every frame whose memory was left unbuilt (two of three: the comparison builds the third) started with the head
+        # that the call before had prepared, whatever happened to the row count in between; none was launched twice
+        assert sp["launched"] == 0 and sp["early_launched"] >= 110 and sp["early_used"] == sp["early_launched"], sp
+        assert sp["early_discarded"] == 0 and emu.heads <= 200, (sp, emu.heads)
+    else:
+        # (the last frame's speculative head may still be waiting for a call that never comes)
+        assert sp["launched"] - sp["used"] - sp["discarded"] in (0, 1) and sp["used"] >= 20 and sp["discarded"] >= 10, sp
     assert mc["in_the_solver_launch"] >= 60 and mc["ahead_kept"] >= 20 and mc["ahead_redone"] >= 20, mc
     assert emu.carried == mc["in_the_solver_launch"] and compared >= 60
     assert ops_.FALLBACKS["dormant_rows_on_the_host"] == fb0 and pa._kill_ids and pa._max_id > 25

@@ -201,7 +201,8 @@ def test_frame_sequence_runner_over_an_image_folder(tmp_path):
         d.add_field("ids", torch.full((2,), -1, dtype=torch.int64, device=dev))
         d.add_field("labels", torch.ones(2, dtype=torch.int64, device=dev))
         d.add_field("scores", torch.tensor([0.9, 0.8], device=dev))
-        return feats, d
+        # (fresh tensors per call, as a detector's forward returns them: the look-ahead runner refuses re-used output buffers)
+        return tuple(f.clone() for f in feats), d
     runner = FrameSequenceRunner(detector, loop, pre)
     res = cached_video_result(str(tmp_path / "out"), "folder", lambda: runner.run_video(
         "folder", ImageFolderIterator(str(tmp_path)), fps=30.0))
@@ -220,6 +221,50 @@ def test_frame_sequence_runner_over_an_image_folder(tmp_path):
     assert len(ahead.entities) == len(res.entities)
     for e, w in zip(ahead.entities, res.entities):
         assert (e.id, e.frame_num, e.bbox, e.confidence, e.labels) == (w.id, w.frame_num, w.bbox, w.confidence, w.labels)
+
+
+def test_lookahead_refuses_a_detector_that_reuses_its_output_buffers():
+    """with ``lookahead=True`` the detector runs on frame t+1 before the tracker consumes frame t; a detector
+    that writes into persistent output buffers would make the tracker follow the wrong frame silently.  The runner
+    compares storage addresses and raises; without look-ahead the same detector is served."""
+    import numpy as np
+    from siammot_amd.results import FrameSequenceRunner
+    from siammot_amd.structures import BoxList
+
+    class Loop(object):
+        seen = []
+
+        def reset(self):
+            pass
+
+        def __call__(self, feats, dets, next_features=None):
+            self.seen.append(float(feats[0].flatten()[0]))
+            return dets
+    persistent = (torch.zeros(1, 4, 2, 2),)
+
+    def boxes():
+        d = BoxList(torch.tensor([[1.0, 2.0, 5.0, 7.0]]), (8, 8), mode="xyxy")
+        d.add_field("ids", torch.tensor([-1]))
+        d.add_field("labels", torch.tensor([1]))
+        d.add_field("scores", torch.tensor([0.9]))
+        return d
+
+    def reusing(image):
+        persistent[0].add_(1.0)
+        return persistent, boxes()
+
+    def fresh(image):
+        persistent[0].add_(1.0)
+        return (persistent[0].clone(),), boxes()
+    frames = [(i, np.zeros((8, 8, 3), np.uint8)) for i in range(3)]
+    loop = Loop()
+    with pytest.raises(RuntimeError, match="re-uses its output buffers"):
+        list(FrameSequenceRunner(reusing, loop, lambda f: torch.zeros(3, 8, 8)).process_frame_sequence(iter(frames), lookahead=True))
+    assert len(list(FrameSequenceRunner(reusing, loop, lambda f: torch.zeros(3, 8, 8)).process_frame_sequence(iter(frames)))) == 3
+    loop.seen.clear()
+    persistent[0].zero_()
+    out = list(FrameSequenceRunner(fresh, loop, lambda f: torch.zeros(3, 8, 8)).process_frame_sequence(iter(frames), lookahead=True))
+    assert [i for i, _ in out] == [0, 1, 2] and loop.seen == [1.0, 2.0, 3.0]        # every frame tracked on ITS maps
 
 
 # ---- the wire format against the reference's own code (tests/golden/results_wire.json, oracle/gen_golden_results.py) -------

@@ -35,77 +35,17 @@ def main():
     from siammot_amd import ops
     from siammot_amd.config import get_default_cfg
     from siammot_amd.emm import EMM
-    from siammot_amd.structures import BoxList
     from siammot_amd.track_utils import build_track_utils
     dev = torch.device("cuda:0")
     torch.set_num_threads(bench._cpu_threads())
     n = args.tracks
-    image_wh = (1280, 704)
     cfg = get_default_cfg(channels=128)
     emm = EMM(cfg, build_track_utils(cfg)).eval()
-    base_boxes = bench.synthetic_boxes(n, image_wh)
-    bench.init_predictor(emm.predictor, base_boxes)
+    bench.init_predictor(emm.predictor, bench.synthetic_boxes(n, (1280, 704)))
     emm = emm.to(dev)
-    params_cpu = {k: v.detach().cpu() for k, v in emm.predictor.named_parameters()}
-    ocfg = O.EMMConfig(channels=128)
-    fe, pr = emm.feature_extractor.pooler_x, emm.predictor
-    rows = []
     t0 = time.time()
-    with torch.no_grad():
-        for seed in range(args.pairs):
-            g = torch.Generator().manual_seed(10_000 + seed)
-            jitter = (torch.rand((n, 1), generator=g) * 6.0 - 3.0)
-            boxes = (base_boxes + jitter).clamp(min=0)
-            boxes[:, 2].clamp_(max=image_wh[0] - 1)
-            boxes[:, 3].clamp_(max=image_wh[1] - 1)
-            gd = torch.Generator(device=dev).manual_seed(20_000 + seed)
-            fa = tuple(torch.randn((1, 128, 704 // s, 1280 // s), generator=gd, device=dev) for s in (4, 8, 16, 32, 64))
-            fb = tuple(torch.randn((1, 128, 704 // s, 1280 // s), generator=gd, device=dev) for s in (4, 8, 16, 32, 64))
-            det = BoxList(boxes.to(dev), image_wh, mode="xyxy")
-            det.add_field("ids", torch.arange(n, device=dev))
-            det.add_field("labels", torch.ones(n, dtype=torch.int64, device=dev))
-            z, sr, d = emm.extract_cache(fa, det)
-            bb, conf, idx = ops.emm_track(fb, d[0].bbox, sr[0].bbox, z, pr.param_dict(), emm.rx, emm.rz, tuple(fe.scales),
-                                          fe.sampling_ratio, emm.pad_pixels, sigma=emm.sigma,
-                                          use_centerness=emm.use_centerness, clip_wh=image_wh, gn_groups=pr.gn_groups,
-                                          gn_eps=pr.gn_eps, return_index=True)
-            fa_c, fb_c = [t.cpu() for t in fa], [t.cpu() for t in fb]
-            z_o, sr_o = O.extract_cache(ocfg, fa_c, boxes)
-            bb_o, conf_o, _, inter = O.emm_forward(ocfg, params_cpu, fb_c, boxes, sr_o, z_o, image_wh,
-                                                   return_intermediates=True, reference_ops=True)
-            idx, idx_o = idx.cpu(), inter["idx"]
-            iou = bench.box_iou(bb.cpu().double(), bb_o.double())
-            diff = (idx != idx_o).nonzero().flatten().tolist()
-            gaps, kind = {}, {}
-            if diff:
-                # Attribution.  (1) the kernel's OWN logits (same operators, called one by one) decoded by the fp32
-                # oracle: if that elects the kernel's cell, the decode is exact and the difference was made upstream
-                # (pooling / correlation / Winograd-vs-direct summation order moved the logits by ~1e-5 of their
-                # scale and two cells swapped places).  (2) otherwise the two cells' fp64 scores on the kernel's
-                # logits: a gap <= 1e-6 is an exponential-rounding tie between torch-CPU and the device.
-                resp = ops.sr_xcorr_fused(fb, d[0].bbox, sr[0].bbox, z, emm.rx, emm.rz, tuple(fe.scales), fe.sampling_ratio,
-                                          emm.pad_pixels)
-                lg = ops.emm_predictor(resp, pr.param_dict(), pr.gn_groups, pr.gn_eps).cpu()[diff]
-                xs, ys = O.grid_axes(sr_o[diff], ocfg.rx, ocfg.rz, ocfg.pad_pixels)
-                up32 = [O.bicubic_upsample_torch(lg[:, a:b]) for a, b in ((0, 2), (2, 3), (3, 7))]
-                _, _, idx_mix = O.decode(up32[0], up32[1], up32[2], xs, ys, boxes[diff], True, 0.4)
-                up64 = [O.bicubic_upsample(lg[:, a:b].double()) for a, b in ((0, 2), (2, 3), (3, 7))]
-                score64, _ = O.score_map(up64[0], up64[1], up64[2], boxes[diff].double(), True, 0.4)
-                up_o = [O.bicubic_upsample(inter[k][diff].double()) for k in ("cls", "center", "reg")]
-                score_o, _ = O.score_map(up_o[0], up_o[1], up_o[2], boxes[diff].double(), True, 0.4)
-                for j, t in enumerate(diff):
-                    gaps[t] = float(score_o[j, idx_o[t]] - score_o[j, idx[t]])       # on the ORACLE's logits
-                    if int(idx_mix[j]) == int(idx[t]):
-                        kind[t] = 1                                                  # upstream fp32 rounding
-                    elif abs(float(score64[j, idx_mix[j]] - score64[j, idx[t]])) <= 1e-6:
-                        kind[t] = 2                                                  # decode-level rounding tie
-                    else:
-                        kind[t] = 3                                                  # unexplained
-            for t in range(n):
-                rows.append((seed, t, int(idx[t] == idx_o[t]), float(iou[t]), float((conf[t].cpu() - conf_o[t]).abs()),
-                             float((bb[t].cpu() - bb_o[t]).abs().max()), gaps.get(t, 0.0), kind.get(t, 0)))
-            if (seed + 1) % 50 == 0:
-                print("%d pairs, %.0f s" % (seed + 1, time.time() - t0), flush=True)
+    rows = bench.argmax_rows(emm, ops, dev, n, args.pairs, progress=True)      # (the loop lives in bench.py: its own line
+                                                                              #  carries the same statistic, measured in-run)
     a = np.array(rows, dtype=np.float64)
     same = a[:, 2] > 0.5
     one_minus_iou = 1.0 - a[:, 3]
