@@ -51,6 +51,7 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+CLOCK_GHZ = 2.4            # MI355X peak engine clock (MI355X_MICROARCH.md); sustained clocks under this load are ~2.1
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 METRIC = "frame-pairs/sec at 720p, 30 active tracks; EMM xcorr HBM GB/s vs peak"
 NET_HW = (704, 1280)       # 720p under MIN_SIZE_TEST 800 / MAX 1280 / divisibility 32
@@ -287,7 +288,13 @@ def multi_stream_throughput(emm, feats, det, n_streams, dev, steps=600):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     return {"streams": n_streams, "steps_per_stream": steps, "value": n_streams * steps / dt, "unit": "frame-pairs/s",
-            "ms_per_step_per_stream": dt / steps * 1e3}
+            "ms_per_step_per_stream": dt / steps * 1e3,
+            "note": "informational, and it does NOT use the rest of the chip: two streams reach ~1.06x of one (round 4 and "
+                    "5).  One Python thread enqueues both streams (host_enqueue ~44 us of a ~63 us step: two streams are "
+                    "host-bound at ~88 us per pair of steps), and each of the four kernels of a step fills the chip by "
+                    "itself (480 / 240 / 510 / 480 workgroups on 256 CUs, LDS- or register-limited to one or two per CU), "
+                    "so a second stream's kernels mostly queue behind the first's.  More cameras per GPU need more host "
+                    "threads or processes (one per stream, as `--gpus N` runs them), not more streams in one loop"}
 
 
 def hipgraph_loop_throughput(emm, feats, det, state, steps):
@@ -311,7 +318,12 @@ def hipgraph_loop_throughput(emm, feats, det, state, steps):
     res = ring.results[-1]
     return {"value": revs * len(feats) / dt, "unit": "frame-pairs/s", "ms_per_step": dt / (revs * len(feats)) * 1e3,
             "frame_pairs_per_graph": len(feats), "kernel_nodes_per_graph": 4 * len(feats),
-            "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all())}
+            "host_us_per_step": t_host / (revs * len(feats)) * 1e6, "boxes_finite": bool(torch.isfinite(res.bbox).all()),
+            "note": "informational: the replay is NOT faster than the eager loop (65 vs 63-64 us per step in rounds 4 and 5) — "
+                    "the eager loop is GPU-bound already (host_enqueue ~44 us < ~63 us of kernels per step), and a graph's "
+                    "kernel nodes pay the same dispatch gaps between dependent kernels (plus two small copy nodes per frame "
+                    "pair).  What the graph buys is host time: `host_us_per_step` against ~44 us of eager enqueue, i.e. "
+                    "headroom for a detector's launches on the same thread"}
 
 
 def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None, loop_hint=None, ahead=False, dormant=0,
@@ -419,6 +431,10 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
         d.add_field("scores", sc)
         return d
     last = [None]
+    # inference runs with autograd off in the reference's callers (demos/demo_inference.py:103, engine/inferencer.py:56);
+    # TrackingLoop.forward switches it off itself only when it finds it on (a context object per call: 2-7 us of host time)
+    grad_was = torch.is_grad_enabled()
+    torch.set_grad_enabled(False)
     out = loop(feats[0], dets(0))                     # frame 0: the n detections start n tracks
     # fixed track count: from here on the unchanged solver never starts or suspends a track — the n
     # tracks live on, every frame's n detections compete with them in NMS
@@ -467,6 +483,7 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     dt = time.perf_counter() - t0
     tracked = int((out.get_field("ids") >= 0).sum().item())
     pool = loop.solver.track_pool
+    torch.set_grad_enabled(grad_was)
     return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
             "active_tracks": len(pool.get_active_ids()), "dormant_tracks": len(pool._dormant_ids),
@@ -994,7 +1011,7 @@ def main():
             floor_us = ops.dispatch_floor_us(n * ((CHANNELS + 7) // 8), 512)
         except Exception:
             floor_us = None
-    traffic = traffic_source = None
+    traffic = traffic_source = valu_insts = None
     tpath = os.path.join(ROOT, "profiles", "xcorr_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -1003,6 +1020,7 @@ def main():
             stamp_ok = (tj.get("kernel") == ops.fused_kernel_name() and tj.get("source_sha1") == fused_source_sha1()
                         and (CHANNELS, tuple(NET_HW)) == (128, (704, 1280)))
             traffic = tj.get(str(n)) if stamp_ok else None
+            valu_insts = (tj.get("valu_insts") or {}).get(str(n)) if stamp_ok else None
             traffic_source = ("static:profiles/xcorr_traffic.json (%s)" % tj.get(
                 "source", "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured by this run")) if stamp_ok else (
                 "null: profiles/xcorr_traffic.json was taken on %s at source %s; this run launches %s at source %s" % (
@@ -1044,6 +1062,18 @@ def main():
             "bound": "hbm", "kernel": ops.fused_kernel_name() + " (search-region ROIAlign + depthwise xcorr)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
+            # the resource that actually binds this kernel: vector-instruction issue.  A wave64
+            # instruction occupies its SIMD's issue port for 4 cycles; SQ_INSTS_VALU (same counter passes and source stamp
+            # as `traffic`) x 4 cycles / (256 CUs x 4 SIMDs) / clock = the time the launch needs for vector issue alone,
+            # were it spread perfectly over the chip — `frac_of_duration` of the measured duration
+            "valu_issue": None if not valu_insts or xcorr_avg_s <= 0 else {
+                "wave_instructions_per_launch": valu_insts, "cycles_per_instruction": 4, "simds": 1024, "clock_ghz": CLOCK_GHZ,
+                "issue_bound_us": valu_insts * 4.0 / 1024.0 / (CLOCK_GHZ * 1e3),
+                "frac_of_duration": valu_insts * 4.0 / 1024.0 / (CLOCK_GHZ * 1e3) / (xcorr_avg_s * 1e6),
+                "note": "static counter (profiles/xcorr_traffic.json, SQ_INSTS_VALU of a separate --pmc pass at this source "
+                        "state), not measured by this run; un-packed fp32 FMAs with three distinct operands issue at 4 cycles "
+                        "(DESIGN.md §3): with the 8.8 us start-up / pooling chain that does not overlap them this is why the "
+                        "HBM fraction above cannot reach the north star's 0.6 on this operator"},
             "algorithmic_bytes_per_launch": fused_bytes,
             "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer": TIMER_NOTE,
             # an EMPTY kernel of the same launch shape bracketed by the same pair of events: an UPPER bound on the fixed cost

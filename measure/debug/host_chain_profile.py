@@ -19,6 +19,7 @@ from siammot_amd.solver import TrackPool, TrackSolver
 from siammot_amd.structures import BoxList
 from siammot_amd.track_head import TrackHead, TrackingLoop
 
+torch.set_grad_enabled(False)          # inference, as the reference's callers run it (demo_inference.py:103)
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 30
 frames = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 3000
 pad, thresholds = 512, (0.0, 2.0, 2.0)
@@ -42,6 +43,7 @@ host = TS._HostEmulation(loop, thresholds, 1000)
 emu = TS._FrameEntryEmulation(host, pad, 4)
 spans = {"in_emu": 0.0}
 marks = []
+waits = []
 
 
 def timed_emu(lib, addr, dev, stream):
@@ -74,6 +76,9 @@ class Ring(TS._HostEmulation.Ring):
         self.bufs[self.k][3] = 0
         return self.bufs[self.k]
 
+    def wait(self, rec, event=True):
+        waits.append(time.perf_counter())          # the frame's synchronisation: host work before it runs beside the GPU
+
 
 ring = Ring()
 pool.host_record_ring = lambda dev: ring
@@ -97,24 +102,26 @@ loop._native_ok = lambda d: True
 loop.solver.start_thresh = host.solver.start_thresh = 0.5
 loop._step_native(feats, dets())
 loop.solver.start_thresh = host.solver.start_thresh = 2.0
-pre, post, total = [], [], []
+pre, post, total, beside = [], [], [], []
 
 
 def run(k):
     for _ in range(k):
         d = dets()
         marks.clear()
+        waits.clear()
         t0 = time.perf_counter()
         out = loop(feats, d) if EARLY else loop._step_native(feats, d)
         t1 = time.perf_counter()
         pre.append(marks[0][0] - t0)
-        post.append(t1 - marks[-1][1])
+        post.append(t1 - waits[-1])
+        beside.append(waits[-1] - marks[-1][1])
         total.append((t1 - t0) - sum(b - a for a, b in marks))
     return out
 
 
 out = run(200)
-pre.clear(); post.clear(); total.clear()
+pre.clear(); post.clear(); total.clear(); beside.clear()
 if "--cprofile" in sys.argv:
     import cProfile, pstats
     pr = cProfile.Profile()
@@ -126,5 +133,5 @@ else:
     out = run(frames)
 med = lambda v: float(np.median(v)) * 1e6
 print("tracks held %d of %d; frames %d" % (int((out.get_field("ids") >= 0).sum()), n, frames))
-print("host us per frame (median): pre-launch %.1f, post-record %.1f, all host work outside the library %.1f" % (
-    med(pre), med(post), med(total)))
+print("host us per frame (median): pre-launch %.1f, post-record %.1f (on the serial chain); last launch -> wait %.1f (beside the "
+      "GPU); all host work outside the library %.1f" % (med(pre), med(post), med(beside), med(total)))

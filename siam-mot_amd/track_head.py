@@ -204,6 +204,12 @@ class _FramePlan(object):
                  "ws_need", "lib", "args", "box_params", "box_ptrs", "box_amodal", "image_wh", "a_pp", "state")
 
 
+def _GLOBAL_HOOKS():
+    m = torch.nn.modules.module
+    return (m._global_forward_hooks or m._global_forward_pre_hooks or m._global_backward_hooks
+            or m._global_backward_pre_hooks)
+
+
 class TrackingLoop(torch.nn.Module):
     """One tracking step per frame: ``forward(features, detections) -> BoxList`` with track ids."""
 
@@ -410,6 +416,27 @@ class TrackingLoop(torch.nn.Module):
             emm, pool = self.track.tracker, self.solver.track_pool
         ring = pool._ring
         view = ring.view(rec_host) if ring is not None and (rec_host is ring.bufs[0] or rec_host is ring.bufs[1]) else rec_host.numpy()
+        if (pre_out is not None and view[6] == 4 and view[0] == pre_out[0] and view[1] >= 1 and not pool._dormant_ids
+                and pool._last_tables is not None and self.__dict__.get("lazy_memory", True)
+                and pool.__dict__.get("mirror_skip", True)):
+            # The steady frame, in as few bytecodes as it takes (this is the serial chain: the GPU waits for the next head):
+            # the kernel says the id tables stand (record word 6 == 4: no overflow, no NaN score, nothing started /
+            # suspended / resumed / expired), there are no dormant tracks, the output has the row count its views were
+            # built for.  Same state as the general code below leaves: pool counters, output, the unbuilt next memory.
+            K, A = pre_out[0], int(view[1])
+            pool._max_id, pool._frame_idx = int(view[2]), int(view[3])
+            out = pre_out[1]
+            out.host_ids = view[8 + M:8 + M + K].copy()
+            host_ids = view[8 + 2 * M:8 + 2 * M + A].copy()
+            size = detections.size
+            pad2 = emm.track_utils.pad_pixels * 2
+            memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A, size, [int(size[0] + pad2), int(size[1] + pad2)], host_ids,
+                                 BoxList, hint_off if A >= 2 else 0, A, [])
+            pool._pending = (memory, host_ids)                      # = pool.note_memory
+            d = self.__dict__
+            d["_carry_ahead_kept"] = False
+            d["track_memory"] = d["_own_memory"] = memory
+            return out
         rec = view[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
         if rec[6] & 2:
@@ -692,6 +719,10 @@ class TrackingLoop(torch.nn.Module):
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), p_tbb, p_sr, p_z, p_hint, p_ids,
                                 p_lab, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)                         # the head is running from here on
+        if n_trk > 0:                               # probes (tests): the head's output of this frame, BEFORE anything consumes
+            hook = emm.__dict__.get("raw_output_hook")     # it (stream order: a probe may look at it or edit it in place)
+            if hook is not None:
+                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * tf_cap:4 * tf_cap + n_trk])
         # ---- while the head runs: detections, output buffers, the remaining stages --------------------------------------
         seg = solver._segment(detections)
         n_det = 0
@@ -743,10 +774,7 @@ class TrackingLoop(torch.nn.Module):
                             cz, cb, cs, ci, cl, cc),
                            stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh), carry)
         ops.track_frame_addr(P.lib, addr, dev, stream)
-        if n_trk > 0:                               # probes (tests): the head's / the box head's output of this frame
-            hook = emm.__dict__.get("raw_output_hook")
-            if hook is not None:
-                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * tf_cap:4 * tf_cap + n_trk])
+        if n_trk > 0:                               # probes (tests): the box head's output of this frame
             if a.refine:
                 hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
                 if hook is not None:
@@ -834,8 +862,24 @@ class TrackingLoop(torch.nn.Module):
                 self.__dict__["_early_head"] = (m2, m2.A, early[0], early[1], early[2], use_hint, M, P)
         return out
 
-    @torch.no_grad()
+    def __call__(self, features, detections, next_features=None):
+        # nn.Module.__call__ is three frames and a dozen hook-table reads deep (~3 us on the frame's serial chain): with no
+        # hook registered on this module the call goes straight to forward(); with one, through the usual machinery
+        d = self.__dict__
+        if d["_forward_hooks"] or d["_forward_pre_hooks"] or d["_backward_hooks"] or d["_backward_pre_hooks"] or _GLOBAL_HOOKS():
+            return super(TrackingLoop, self).__call__(features, detections, next_features=next_features)
+        return self.forward(features, detections, next_features)
+
     def forward(self, features, detections, next_features=None):
+        # inference only: nothing here may record an autograd graph.  (A ``@torch.no_grad()`` decorator costs 2-7 us per
+        # call — a context object, two switches of the grad mode — on the serial chain; callers run inference under
+        # ``torch.no_grad()`` anyway, as the reference does: demo_inference.py:103, inferencer.py:56.)
+        if torch.is_grad_enabled():
+            with torch.no_grad():
+                return self._forward(features, detections, next_features)
+        return self._forward(features, detections, next_features)
+
+    def _forward(self, features, detections, next_features=None):
         eh = self.__dict__.get("_early_head")
         if eh is not None:
             # the head of THIS frame, prepared by the last call while the GPU was busy (see _step_native): enqueued before

@@ -238,6 +238,7 @@ class _HostEmulation(object):
         bl.add_field("scores", scores)
         bl.add_field("labels", labels)
         in_ids = ids.numpy().copy()
+        tables_before = (set(self.pool._active_ids), dict(self.pool._dormant_ids))
         out = self.solver([bl])[0]
         K = len(out)
         assert K == len(rows) and np.array_equal(out.bbox.numpy(), boxes.numpy()[rows])
@@ -268,6 +269,9 @@ class _HostEmulation(object):
         rec[base + cap:base + cap + len(d)] = [k for k, _ in d]
         rec[base + 2 * cap:base + 2 * cap + len(d)] = [v for _, v in d]
         rec[8 + 3 * M + 3 * cap:] = in_ids
+        # record word 6, bit 2 (csrc/track_solver.hip): nothing started, resumed, was suspended or expired — the tables stand
+        if tables_before == (set(pool._active_ids), dict(pool._dormant_ids)):
+            rec[6] |= 4
         state[4] = A                                     # the count a launch enqueued behind the solver reads on the device
         return fbuf, ibuf, torch.from_numpy(rec), M
 

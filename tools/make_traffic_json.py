@@ -34,6 +34,8 @@ def main():
         if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
             raise SystemExit("%s: no FETCH_SIZE / WRITE_SIZE for %s" % (md, name))
         res[n] = int(round((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0))
+        if "SQ_INSTS_VALU" in c:             # wave-level vector instructions per launch: bench.py's roofline.valu_issue
+            res.setdefault("valu_insts", {})[n] = int(round(c["SQ_INSTS_VALU"]))
     res["kernel"] = name
     res["source_sha1"] = bench.fused_source_sha1()
     res["source"] = ("%s / %s: 2 x FETCH_SIZE + WRITE_SIZE (KiB) of %s, separate --pmc passes over bench.py --tracks N (8 rotating "
