@@ -23,7 +23,7 @@ unsigned* decode_tickets(float* cand_ws, int N, int Ho);
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
                          float two_e, float min_wh, float* templates, float* sr, const int* n_valid, float* order_hint,
-                         hipStream_t st);
+                         hipStream_t st, int hint_extra_rows);
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
@@ -116,7 +116,7 @@ extern "C" int smot_emm_extract_cache_fwd(const float* const* feats, const int* 
         const float half_e = (float)((double)search_expansion / 2.0);
         const float two_e = (float)((double)search_expansion * 2.0);
         return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, N, rz, pad_pixels, half_e,
-                                    two_e, min_search_wh, templates, sr, nullptr, order_hint, (hipStream_t)stream);
+                                    two_e, min_search_wh, templates, sr, nullptr, order_hint, (hipStream_t)stream, 0);
     }
     int zero_pad[SMOT_MAX_LEVELS] = {0};
     int rc = smot_roi_align_levels_fwd(feats, heights, widths, zero_pad, scales, num_levels, C, boxes, boxes, N, rz, rz,
@@ -147,7 +147,7 @@ extern "C" int smot_emm_extract_cache_masked_fwd(const float* const* feats, cons
     const float half_e = (float)((double)search_expansion / 2.0);
     const float two_e = (float)((double)search_expansion * 2.0);
     return launch_extract_cache(feats, heights, widths, scales, num_levels, C, boxes, capacity, rz, pad_pixels, half_e,
-                                two_e, min_search_wh, templates, sr, n_valid, order_hint, (hipStream_t)stream);
+                                two_e, min_search_wh, templates, sr, n_valid, order_hint, (hipStream_t)stream, 0);
 }
 
 
@@ -211,8 +211,18 @@ extern "C" int smot_track_frame_fwd(const smot_frame_args* a, smot_stream_t stre
         if (rc) return rc;
     }
     if (!(stages & SMOT_STAGE_EXTRACT)) return SMOT_OK;
-    return smot_emm_extract_cache_masked_fwd(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->act_boxes,
-                                             a->n_det + a->n_trk, a->pool_state + 4, a->rz, a->sampling_ratio,
-                                             a->pad_pixels, a->search_expansion, a->min_search_wh, a->next_templates,
-                                             a->next_sr, a->next_order_hint, stream);
+    // = smot_emm_extract_cache_masked_fwd, whose order hint also ranks the dormant rows the solver's launch has just put
+    // behind the active ones (SMOT_STAGE_CARRY: their boxes stand in act_boxes behind the count): a memory with dormant
+    // tracks — most frames of a MOT sequence — keeps its hint
+    SMOT_REQUIRE(a->n_det + a->n_trk >= 0 && a->num_levels >= 1 && a->num_levels <= SMOT_MAX_LEVELS, "track_frame: bad sizes");
+    if (a->n_det + a->n_trk == 0) return SMOT_OK;
+    if (!((a->rz == 15 || a->rz == 7) && a->sampling_ratio == 2)) {
+        set_error("track_frame: the masked extraction needs Rz=15 or 7, sampling_ratio=2 (got %d, %d)", a->rz, a->sampling_ratio);
+        return SMOT_ERR_UNSUPPORTED;
+    }
+    return launch_extract_cache(a->feats, a->heights, a->widths, a->scales, a->num_levels, a->C, a->act_boxes,
+                                a->n_det + a->n_trk, a->rz, a->pad_pixels, (float)((double)a->search_expansion / 2.0),
+                                (float)((double)a->search_expansion * 2.0), a->min_search_wh, a->next_templates, a->next_sr,
+                                a->pool_state + 4, a->next_order_hint, (hipStream_t)stream,
+                                (stages & SMOT_STAGE_CARRY) ? a->carry_rows : 0);
 }

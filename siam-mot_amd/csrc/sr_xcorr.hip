@@ -48,6 +48,10 @@ struct SrOut {
                           // (fx_write_hint below; [R] entries of SMOT_HINT_FLOATS floats) or nullptr
     const float* hint_in; // pooling + correlation kernel: such a list for ITS rois (written by the extraction that made
                           // them), read instead of ranking the rois again in every workgroup; or nullptr
+    int hint_extra;       // hint writer with n_valid: the list ranks *n_valid + hint_extra rows — the rows the caller appended behind
+                          // the valid ones before this launch (the tracking frame's carried dormant tracks: their boxes stand
+                          // in `boxes` behind the active rows, and a dormant row's search region is search_region_of(its box),
+                          // bit for bit what the extraction that created it wrote)
     int plan_pad[SMOT_MAX_LEVELS];   // hint writer: zero-pad cells per level of the NEXT frame's search-region pooling
                           // (the extraction itself pools un-padded maps); the finished sample tables in a hint entry are
                           // built against them
@@ -137,7 +141,7 @@ template <int RXN, int G>
 __device__ __forceinline__ void fx_write_hint(const LevelParams& P, const float* __restrict__ boxes, const SrOut& S,
                                               int NT, int x, int wave, int lane) {
     if (NT > 256 || wave >= 2) return;                         // (the consumer keeps grid order beyond 256 rois)
-    const int nv = (S.n_valid != nullptr) ? min(*S.n_valid, NT) : NT;
+    const int nv = (S.n_valid != nullptr) ? min(*S.n_valid + S.hint_extra, NT) : NT;
     if (x >= nv) return;
     unsigned long long mask[4][3];
     int cnt[3] = {0, 0, 0};
@@ -904,7 +908,7 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
 int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, const float* level_boxes, int R,
                               int out_size, float* out, int32_t* levels_out, hipStream_t st) {
     dim3 grid(R, (C + FX_CH - 1) / FX_CH);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order(), nullptr, nullptr};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, 0, nullptr, fused_order(), nullptr, nullptr, 0};
     if (out_size == 30) {
         launch_fused<30, false>(grid, st, P, C, rois, level_boxes, nullptr, nullptr, out, levels_out, none);
     } else if (out_size == 7) {        // the box head's 7x7 pooler (box_head.py:46, roi_heads.py:60-84): same kernel
@@ -919,7 +923,7 @@ int launch_roi_pool_separable(const LevelParams& P, int C, const float* rois, co
 int launch_extract_cache(const float* const* feats, const int* heights, const int* widths, const float* scales,
                          int num_levels, int C, const float* boxes, int N, int rz, float pad_pixels, float half_e,
                          float two_e, float min_wh, float* templates, float* sr, const int* n_valid, float* order_hint,
-                         hipStream_t st) {
+                         hipStream_t st, int hint_extra_rows) {
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, nullptr, scales, num_levels, "emm_extract_cache");
     if (rc) return rc;
@@ -929,7 +933,8 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
                  "emm_extract_cache: the order hint must be 32-byte aligned (and the boxes 16-byte aligned)");
     // with a hint to write: one extra row of workgroups in front, of which the first ranks the rois (fx_write_hint)
     dim3 grid(N, (C + FX_CH - 1) / FX_CH + (order_hint != nullptr ? 1 : 0));
-    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order(), order_hint, nullptr};
+    SrOut S = {sr, pad_pixels, half_e, two_e, min_wh, g_trace, 0, n_valid, fused_order(), order_hint, nullptr,
+               n_valid != nullptr ? hint_extra_rows : 0};
     // the next frame's search-region pooling runs on maps zero-padded by int(pad_pixels / stride) cells per level
     // (track_utils.py:94-96); the hint's finished tables are built against exactly that
     for (int l = 0; l < num_levels && l < SMOT_MAX_LEVELS; ++l) S.plan_pad[l] = (int)(pad_pixels * scales[l]);
@@ -980,7 +985,7 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
     }
 #endif
     timer_mark(0, 0, st);
-    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint};
+    SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint, 0};
 #ifdef SMOT_DEBUG
     // A/B (measurement library, SMOT_FUSED_ABL=4): four channels per workgroup, twice the workgroups (960 of four waves at
     // 30 tracks: finer balance, twice the table builds).  Bit-identical; 17.7 vs 17.7 us at 30 tracks, 39.0 vs 39.7 at 100

@@ -228,7 +228,7 @@ class TrackingLoop(torch.nn.Module):
         # per-frame caches (ctypes blocks, library handles, the trusted-memory marker) are rebuilt on demand: a copy or a
         # pickle of the loop carries none of them
         d = self.__dict__.copy()
-        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head", "_prev_n_trk", "_early_head", "_prev_K"):
+        for k in ("_plan", "_lean_static", "_own_memory", "_spec_head", "_prev_n_trk", "_early_head", "_prev_K", "_hint_extra"):
             d.pop(k, None)
         return d
 
@@ -417,7 +417,7 @@ class TrackingLoop(torch.nn.Module):
         ring = pool._ring
         view = ring.view(rec_host) if ring is not None and (rec_host is ring.bufs[0] or rec_host is ring.bufs[1]) else rec_host.numpy()
         if (pre_out is not None and view[6] == 4 and view[0] == pre_out[0] and view[1] >= 1 and not pool._dormant_ids
-                and pool._last_tables is not None and self.__dict__.get("lazy_memory", True)
+                and not self.__dict__.get("_hint_extra") and pool._last_tables is not None and self.__dict__.get("lazy_memory", True)
                 and pool.__dict__.get("mirror_skip", True)):
             # The steady frame, in as few bytecodes as it takes (this is the serial chain: the GPU waits for the next head):
             # the kernel says the id tables stand (record word 6 == 4: no overflow, no NaN score, nothing started /
@@ -478,8 +478,12 @@ class TrackingLoop(torch.nn.Module):
                     host_ids = np.concatenate([host_ids, np.asarray(dormant, dtype=host_ids.dtype)])
                     self.__dict__["_carry_ahead_kept"] = carried[2]
                 pad2 = emm.track_utils.pad_pixels * 2
+                # the extraction's order hint describes the memory's rows when it ranked exactly them: the active rows plus
+                # the dormant rows that were in place behind them when it ran (carried inside the solver's launch, and the
+                # guess about them held: `carried[2]`) — `_hint_extra` is how many such rows it was told about
+                hint_ok = A + D >= 2 and self.__dict__.get("_hint_extra", 0) == D and (D == 0 or carried[2])
                 memory = _LazyMemory(fbuf, ibuf, pre[0], pre[1], M, A + D, size, [int(size[0] + pad2), int(size[1] + pad2)],
-                                     host_ids, cls, hint_off if (A >= 2 and D == 0) else 0, A, list(dormant))
+                                     host_ids, cls, hint_off if hint_ok else 0, A, list(dormant))
                 pool.note_memory(memory, memory.host_ids)
                 self.__dict__["track_memory"] = memory
                 self.__dict__["_own_memory"] = memory
@@ -767,6 +771,9 @@ class TrackingLoop(torch.nn.Module):
             carried_ahead = (list(range(mem.n_act, mem.A)), mem.n_act)
             stages |= ops.STAGE_CARRY
             ops.MEMORY_CARRY["in_the_solver_launch"] += 1
+        # rows behind the active ones that the extraction's order hint ranks as well (smot_track_frame_fwd: the rows carried
+        # in the solver's launch stand in act_boxes when the extraction runs)
+        self.__dict__["_hint_extra"] = carry[1] if (stages & ops.STAGE_CARRY) else 0
         addr = a.poke_rest((rw, r0, r1, r2, r3, d0, d1, d2, d3,
                             fp, fp + 32 * M, ip, ip + 8 * M,                       # out_boxes, out_scores, out_ids, out_labels
                             fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,    # act_boxes, act_ids, act_labels, act_scores
@@ -797,7 +804,7 @@ class TrackingLoop(torch.nn.Module):
             # (... and that the dormant tracks stay the ones they were: their rows went behind the active rows just above)
             spec_tf = torch.empty((10 * n_trk,), dtype=torch.float32, device=dev)
             p = spec_tf.data_ptr()
-            spec_hint = hint_ptr if (n_trk >= 2 and carried_ahead is None) else 0
+            spec_hint = hint_ptr if (n_trk >= 2 and (carried_ahead is None or (stages & ops.STAGE_CARRY))) else 0
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
                                 templates.data_ptr(), spec_hint, ip + 16 * M,
                                 ip + 24 * M, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
@@ -842,7 +849,8 @@ class TrackingLoop(torch.nn.Module):
             # — and its dormant rows, if any, are the ones that were copied before that head was enqueued
             m2 = self.__dict__.get("track_memory")
             if (type(m2) is _LazyMemory and m2.fbuf is fbuf and m2.A == n_trk
-                    and (m2.A == m2.n_act or self.__dict__.get("_carry_ahead_kept"))):
+                    and (m2.A == m2.n_act or self.__dict__.get("_carry_ahead_kept"))
+                    and (not spec_hint or m2.hint_off)):      # (a hint that turned out not to describe the rows: that head's output is NaN)
                 self.__dict__["_spec_head"] = (m2, n_trk, next_features, P.a_pp, spec_tf, spec_hint, n_trk, False)
             else:
                 ops.SPECULATION["discarded"] += 1        # the row count changed, or the dormant rows are not the ones copied ahead

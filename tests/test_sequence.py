@@ -539,8 +539,13 @@ def test_dormant_rows_carried_on_the_device_equal_the_concatenated_memory(native
     assert len(pool_h[0]) == n - k and len(pool_h[1]) == k, pool_h
     assert rows_h[-1] == (False, n), rows_h
     fb0 = ops_.FALLBACKS["dormant_rows_on_the_host"]
+    uh0 = ops_.FALLBACKS["unhinted_head"]
     out_d, rows_d, mem_d, pool_d = run(True)
     mc = dict(ops_.MEMORY_CARRY)
+    if native:
+        # round 5: the extraction's order hint ranks the carried dormant rows as well, so the heads of the steady frames
+        # (3 ..) run hinted — and VERIFIED: a hint that did not describe active + dormant rows would raise (NaN rows)
+        assert ops_.FALLBACKS["unhinted_head"] - uh0 <= 3, ops_.FALLBACKS["unhinted_head"] - uh0
     # one copy per frame from frame 1 on: by the stand-alone kernel in frame 1 (the tracks have just gone dormant), from
     # then on ahead of the record — by extra workgroups of the solver's launch on the frame entry point, by the stand-alone
     # kernel enqueued before the wait on the Python-composed path — and kept (the dormant tracks stay the ones they were)
