@@ -476,15 +476,24 @@ def tracking_loop_throughput(n, dev, feats, steps=300, refine=False, native=None
     torch.cuda.synchronize()
     lean[0] = lean[1] = 0
     _ops.SPECULATION.clear()
-    t0 = time.perf_counter()
-    for k in range(k & 1, steps + (k & 1)):          # (frame parity continues: the speculative head saw feats[k & 1])
-        out = step(k)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # three equal chunks, each closed by a synchronisation; the reported time is the MEDIAN chunk's (a single 300-frame
+    # span is 25-40 ms: one scheduler hiccup or collector pause of a few ms in it showed up as +40 % on one leg of one run)
+    chunk = max(1, steps // 3)
+    k0 = k & 1                                       # (frame parity continues: the speculative head saw feats[k & 1])
+    chunk_ms = []
+    for c in range(3):
+        t0 = time.perf_counter()
+        for k in range(k0 + c * chunk, k0 + (c + 1) * chunk):
+            out = step(k)
+        torch.cuda.synchronize()
+        chunk_ms.append((time.perf_counter() - t0) / chunk * 1e3)
+    steps = 3 * chunk
+    dt = sorted(chunk_ms)[1] * 1e-3 * steps
     tracked = int((out.get_field("ids") >= 0).sum().item())
     pool = loop.solver.track_pool
     torch.set_grad_enabled(grad_was)
-    return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3, "tracks": n,
+    return {"value": steps / dt, "unit": "frames/s", "ms_per_frame": dt / steps * 1e3,
+            "ms_per_frame_chunks": [round(v, 5) for v in chunk_ms], "tracks": n,
             "tracked_in_last_frame": tracked, "track_count_held": tracked == n,
             "active_tracks": len(pool.get_active_ids()), "dormant_tracks": len(pool._dormant_ids),
             "memory_rows": len(loop.track_memory[2][0]) if loop.track_memory is not None else 0,
