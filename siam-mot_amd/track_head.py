@@ -828,9 +828,16 @@ class TrackingLoop(torch.nn.Module):
                     if a.refine else 0)
             e_tf = torch.empty((10 * M,), dtype=torch.float32, device=dev)
             p = e_tf.data_ptr()
-            a.poke_head((ops._workspace(dev, nm[0], stream.value).data_ptr(), fp + 16 * M, sr_next.data_ptr(),
+            e_ws = ops._workspace(dev, nm[0], stream.value)
+            a.poke_head((e_ws.data_ptr(), fp + 16 * M, sr_next.data_ptr(),
                          templates.data_ptr(), hint_ptr, ip + 16 * M, ip + 24 * M, p, p + 16 * M), max(n_trk, 1), ops.STAGE_HEAD)
-            early = (e_tf, stream.value, blk.a_pp)
+            # (the launch happens in the NEXT call: everything its argument block names must stay alive until then — the
+            # parameter block `blk` owns the host array of weight pointers the block's `predictor_params` points at, and
+            # ops' caches may drop both it and the workspace tensor when other modules / loops come and go in between:
+            # without these references the early launch read a freed pointer array, "predictor: null pointer" once in a
+            # full test session)
+            early = (e_tf, stream.value, blk.a_pp, (blk, getattr(blk, "pp", None), getattr(blk, "packed", None), tuple(getattr(blk, "tensors", ()))), e_ws)   # (a refresh of `blk`
+            # replaces its pointer array and packed filters: the objects themselves are held, not just their owner)
         # the frame's output BoxList, built NOW on the guess that it has as many rows as the last frame's (four strided views:
         # ~6 us that would otherwise sit between the record and the return)
         pre_out = None
@@ -867,7 +874,7 @@ class TrackingLoop(torch.nn.Module):
                 use_hint = hint_ptr if m2.hint_off else 0
                 if m2.A != max(n_trk, 1) or use_hint != hint_ptr:
                     a.fix_head(m2.A, use_hint)
-                self.__dict__["_early_head"] = (m2, m2.A, early[0], early[1], early[2], use_hint, M, P)
+                self.__dict__["_early_head"] = (m2, m2.A, early[0], early[1], early[2], use_hint, M, P, early[3], early[4])
         return out
 
     def __call__(self, features, detections, next_features=None):

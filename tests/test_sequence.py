@@ -445,6 +445,46 @@ def test_a_stale_order_hint_in_the_tracking_loop_is_reported_not_used(edit):
 
 
 @pytest.mark.gpu
+def test_the_early_head_keeps_what_its_argument_block_names_alive_between_calls():
+    """Round 5: the next call's head launch is PREPARED at the end of a call and ENQUEUED on the next call's first line.  Its
+    argument block names host memory (the parameter block's array of weight pointers) and device memory (workspace,
+    output buffer) that ops' caches own — and those caches are evicted when other modules come and go (a full test
+    session once read a freed pointer array: "predictor: null pointer").  Between every two calls this test evicts
+    the parameter and workspace caches, collects garbage, returns the allocator's cached blocks to the driver and churns
+    fresh allocations: the frames must equal an undisturbed run bit for bit, with the early head used on every frame."""
+    import gc
+    import siammot_amd.ops as ops_
+    inp, loop, feats, dets = _holding_loop()
+
+    def run(disturb):
+        loop.reset()
+        outs = []
+        for t in range(10):
+            o = loop(feats[t & 1], dets(t))
+            outs.append((o.bbox.clone(), o.get_field("scores").clone(), o.get_field("ids").clone()))
+            if disturb:
+                if disturb == "parameters":         # the next call finds a NEW parameter block: its early head is discarded
+                    ops_._param_cache.clear()       # and launched again — after having run on the old block's arrays
+                ops_._ws_cache.clear()
+                gc.collect()
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                junk = [torch.full((1 << 18,), float("nan"), device="cuda:0") for _ in range(8)]
+                del junk
+        return outs
+    ref = run(False)
+    for disturb in ("workspace", "parameters"):
+        ops_.SPECULATION.clear()
+        got = run(disturb)
+        sp = dict(ops_.SPECULATION)
+        assert sp.get("early_launched", 0) >= 8 and sp.get("early_used", 0) + sp.get("early_discarded", 0) == sp["early_launched"], sp
+        assert (sp.get("early_used", 0) >= 8) if disturb == "workspace" else (sp.get("early_discarded", 0) >= 8), sp
+        for (b0, s0, i0), (b1, s1, i1) in zip(ref, got):
+            assert torch.equal(i0, i1) and torch.equal(b0, b1) and torch.equal(s0, s1)
+    assert int((ref[-1][2] >= 0).sum()) >= 8
+
+
+@pytest.mark.gpu
 def test_a_deep_copy_of_the_loop_mid_video_runs_on_its_own_buffers():
     """the unbuilt memory used to keep the hint as a raw device ADDRESS into the original loop's buffer; a
     deep copy then ran its first head on a hint in storage it did not own.  The hint is an offset into the memory's own
