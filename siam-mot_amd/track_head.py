@@ -904,9 +904,10 @@ class TrackingLoop(torch.nn.Module):
             self.__dict__["_early_head"] = None
             mem = self.__dict__.get("track_memory")
             P = eh[7]
+            stream = ops._stream(P.dev)
             if (eh[0] is mem and mem._val is None and P is self.__dict__.get("_plan")
-                    and ops._stream(P.dev).value == eh[3] and ops._geometry_refresh(P.g, features, P.dev)):
-                ops.track_frame_addr(P.lib, P.args._addr, P.dev, ops._stream(P.dev))
+                    and stream.value == eh[3] and ops._geometry_refresh(P.g, features, P.dev)):
+                ops.track_frame_addr(P.lib, P.args._addr, P.dev, stream)
                 ops.SPECULATION["early_launched"] += 1
                 self.__dict__["_spec_head"] = (mem, eh[1], features, eh[4], eh[2], eh[5], eh[6], True)
         if self._lean_ok(detections):
