@@ -222,6 +222,13 @@ SEQ_CASES = {
     "longdormant": dict(channels=128, image_wh=(1280, 704), frames=72, seed=503, thresholds=(0.4, 0.6, 0.4),
                         max_dormant_frames=30, n_objects=6, refine=False, cls_bias=(1.6, -1.6), reg_gain=1.0,
                         long_gaps=True),
+    # dormant256: the longdormant regime with three times the objects and MAX_DORMANT_FRAMES 100 (a legal value of the key; the
+    # yamls use 30): the dormant rows keep accumulating, > 256 of them towards the end — more than one carry
+    # launch takes (siammot_amd.ops.MEMORY_CARRY_MAX_ROWS): the loop falls back to the reference's host concatenation of the
+    # dormant rows (TrackHead._update_memory_with_dormant_track, track_head.py:77-97) for those frames
+    "dormant256": dict(channels=128, image_wh=(1280, 704), frames=100, seed=505, thresholds=(0.4, 0.6, 0.4),
+                       max_dormant_frames=100, n_objects=18, refine=False, cls_bias=(1.6, -1.6), reg_gain=1.0,
+                       long_gaps=True),
     # multiclass: configs[4] maps (R-50-FPN: 256 channels, 1080p -> 1056 x 1920), two foreground classes (person + vehicle)
     # and the box head at the yamls' width in the loop: PostProcessor.filter_results regroups the refined tracks by class
     # (box_head/inference.py:164-191) while _refine_tracks keeps the matching scores in input order (roi_heads.py:67-76)

@@ -82,7 +82,7 @@ def test_closed_loop_on_cpu_equals_the_reference(name):
     assert stats["tracked_rows"] > floor and stats["raw_rows"] > floor, stats
 
 
-@pytest.mark.parametrize("name", ["plain", "refine", "amodal", "crowd", "crowd512", "longdormant", "multiclass"])
+@pytest.mark.parametrize("name", ["plain", "refine", "amodal", "crowd", "crowd512", "longdormant", "dormant256", "multiclass"])
 def test_host_glue_replays_every_frame_of_the_reference_sequences_on_recorded_head_outputs(name):
     """VERDICT r4 next #1, host half: the reference's own head (and box-head) outputs of every frame, replayed through this
     repository's TrackHead / TrackSolver / TrackPool / TrackingLoop (general path, CPU): ids, labels, scores, pool state,
@@ -123,7 +123,7 @@ def test_host_glue_replays_every_frame_of_the_reference_sequences_on_recorded_he
     assert stats["frames"] == case["frames"] and emm.calls >= case["frames"] - 2
     print("recorded replay %s: %s %s" % (name, stats, seen))
     want = {"crowd": dict(max_rows=131), "crowd512": dict(max_rows=257, max_boxes=513),
-            "longdormant": dict(dormant=60)}.get(name, {})
+            "longdormant": dict(dormant=60), "dormant256": dict(dormant=257)}.get(name, {})
     for k, v in want.items():
         assert seen[k] >= v, (k, seen)
 
@@ -153,9 +153,11 @@ def _gpu_loop(name, lean):
 # the round-5 sequences and the capacity fallback each of them must actually take on the fast paths
 # (siammot_amd.ops.FALLBACKS): crowd -> more refinement rows than the weight-streaming kernels take; crowd512 -> more rois
 # than an order hint ranks and more boxes than the one-launch solver takes (general frame + host solver);
+# dormant256 -> more dormant rows than one device copy takes (the reference's host concatenation for those frames);
 # longdormant / multiclass -> none by design (the device paths must hold up in those regimes)
-ROUND5 = ("crowd", "crowd512", "longdormant", "multiclass")
-MUST_FALL_BACK = {"crowd": ("refine_library_gemm",), "crowd512": ("host_solver", "general_frame")}
+ROUND5 = ("crowd", "crowd512", "longdormant", "dormant256", "multiclass")
+MUST_FALL_BACK = {"crowd": ("refine_library_gemm",), "crowd512": ("host_solver", "general_frame"),
+                  "dormant256": ("dormant_rows_on_the_host",)}     # more dormant rows than one carry launch takes
 
 
 @pytest.mark.gpu
@@ -242,10 +244,14 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     # so a decision whose stored margin is a few 1e-6 can fall on the other cell late in the sequence: six aligned ties
     # measured, margins 2.7e-7 .. 6.5e-6 (the replay admits a tie below max(FLIP_MARGIN, a quarter of the score error
     # measured so far)); capped here at 1e-5
-    tie_cap = 1e-5 if name == "crowd" else SR.FLIP_MARGIN
-    assert len(stats["flips"]) <= max(2, stats["raw_rows"] // 1000) and all(
-        m < tie_cap for (_, _, m, _) in stats["flips"]), stats
-    assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < (SR.SCORE_TOL if name == "crowd" else 1e-4), stats
+    long_run = name in ("crowd", "dormant256")       # (dormant256: 100 frames, ~15 k decisions — the same drift argument)
+    tie_cap = 1e-5 if long_run else SR.FLIP_MARGIN
+    # (dormant256: most of its 19,925 decisions are searches of long-dormant tracks whose confidence is ~0 — the score map is
+    # then the cosine window alone and 211 stored margins are below 2e-6, several exactly 0: ties by construction, with no
+    # effect downstream — a dormant track's entry never changes; one aligned row per hundred decisions is allowed there)
+    max_ties = stats["raw_rows"] // 100 if name == "dormant256" else max(2, stats["raw_rows"] // 1000)
+    assert len(stats["flips"]) <= max_ties and all(m < tie_cap for (_, _, m, _) in stats["flips"]), stats
+    assert stats["raw_max_box_err"] < 5e-2 and stats["raw_max_score_err"] < (SR.SCORE_TOL if long_run else 1e-4), stats
 
 
 # ---- the reference's call sequence, transcribed (tests/reference_call_sequence.py), around the head ---------------------
