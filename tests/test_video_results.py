@@ -57,6 +57,135 @@ def test_container_readers_fail_loudly_without_a_decoder(tmp_path):
             video.build_video_iterator(str(p), video_decode=kind)
 
 
+# ---- container readers against decoder stand-ins (decord / cv2 / ffmpeg-python are not installable here) ----------------
+_FAKE_VIDEOS = {}          # path -> dict(frames=[T,H,W,3] RGB uint8, rotate=degrees or None, fail_at=frame index or None)
+
+
+def _install_fake_decoders(monkeypatch):
+    """Modules ``decord``, ``cv2`` and ``ffmpeg`` with exactly the calls demos/video_iterator.py makes, backed by arrays:
+    ``decord.VideoReader(path, ctx=cpu(0))`` (len, [i].asnumpy() -> RGB), ``cv2.VideoCapture(path)`` (isOpened, get(
+    CAP_PROP_FRAME_COUNT), set(CAP_PROP_POS_FRAMES, i), read() -> (ok, BGR)), ``ffmpeg.probe(path)`` -> streams[0].tags."""
+    import sys
+    import types
+
+    class _Frame(object):
+        def __init__(self, a):
+            self.a = a
+
+        def asnumpy(self):
+            return self.a.copy()
+
+    class VideoReader(object):
+        def __init__(self, path, ctx=None):
+            self.v = _FAKE_VIDEOS[path]
+
+        def __len__(self):
+            return len(self.v["frames"])
+
+        def __getitem__(self, i):
+            return _Frame(self.v["frames"][int(i)])
+
+    class VideoCapture(object):
+        def __init__(self, path):
+            self.v = _FAKE_VIDEOS.get(path)
+            self.pos = 0
+
+        def isOpened(self):
+            return self.v is not None
+
+        def get(self, prop):
+            assert prop == cv2.CAP_PROP_FRAME_COUNT
+            return float(len(self.v["frames"]))
+
+        def set(self, prop, value):
+            assert prop == cv2.CAP_PROP_POS_FRAMES
+            self.pos = int(value)
+
+        def read(self):
+            if self.pos >= len(self.v["frames"]) or self.pos == self.v.get("fail_at"):
+                return False, None
+            f = self.v["frames"][self.pos][:, :, ::-1].copy()         # OpenCV hands out BGR
+            self.pos += 1
+            return True, f
+    decord = types.ModuleType("decord")
+    decord.VideoReader, decord.cpu = VideoReader, (lambda i=0: ("cpu", i))
+    cv2 = types.ModuleType("cv2")
+    cv2.VideoCapture, cv2.CAP_PROP_FRAME_COUNT, cv2.CAP_PROP_POS_FRAMES = VideoCapture, 7, 1
+    ffmpeg = types.ModuleType("ffmpeg")
+
+    def probe(path):
+        rot = _FAKE_VIDEOS[path].get("rotate")
+        return {"streams": [{"tags": ({"rotate": str(rot)} if rot is not None else {"language": "und"})}]}
+    ffmpeg.probe = probe
+    for name, mod in (("decord", decord), ("cv2", cv2), ("ffmpeg", ffmpeg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+
+
+def _fake_clip(path, n=7, hw=(6, 10), rotate=None, fail_at=None, seed=0):
+    rs = np.random.RandomState(seed)
+    _FAKE_VIDEOS[path] = dict(frames=rs.randint(0, 256, (n,) + hw + (3,)).astype(np.uint8), rotate=rotate, fail_at=fail_at)
+    return _FAKE_VIDEOS[path]["frames"]
+
+
+@pytest.mark.parametrize("rotate", [None, 0, 90, 180, 270])
+def test_container_readers_on_decoder_stand_ins(monkeypatch, rotate):
+    """``DecordVideoIterator`` / ``CV2VideoIterator`` (demos/video_iterator.py:9-82) executed — the decoder libraries are
+    absent from this image, so against stand-ins with the calls the reference makes: frame ids, RGB order (OpenCV's BGR
+    flipped), the rotation tag of the container applied as the reference applies it, ``frame_idxs`` selected and sorted,
+    a failing read ends the stream, ``build_video_iterator`` picks the reader by ``video_decode``."""
+    from siammot_amd import video
+    _install_fake_decoders(monkeypatch)
+    frames = _fake_clip("clip.mp4", rotate=rotate)
+    want = [np.rot90(f, k=(-(rotate // 90)) % 4) if rotate else f for f in frames]
+    for kind, cls in (("decord", video.DecordVideoIterator), ("cv2", video.CV2VideoIterator)):
+        it = video.build_video_iterator("clip.mp4", video_decode=kind)
+        assert type(it) is cls and len(it) == 7
+        got = list(it())
+        assert [i for i, _ in got] == list(range(7))
+        for (_, f), w in zip(got, want):
+            assert f.dtype == np.uint8 and np.array_equal(f, w)
+        sub = cls("clip.mp4", frame_idxs=[5, 2, 3])
+        assert len(sub) == 3 and [i for i, _ in sub()] == [2, 3, 5]
+        assert all(np.array_equal(f, want[i]) for i, f in sub())
+    assert video.DecordVideoIterator("clip.mp4").video_len() == 7
+    _fake_clip("broken.mp4", fail_at=4)
+    assert [i for i, _ in video.CV2VideoIterator("broken.mp4")()] == [0, 1, 2, 3]        # read() fails: the stream ends
+    with pytest.raises(AssertionError, match="Cannot open"):
+        video.CV2VideoIterator("missing.mp4")
+
+
+REFERENCE = os.environ.get("SIAMMOT_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "demos", "video_iterator.py")), reason="reference checkout not present")
+def test_container_readers_equal_the_reference_iterators_on_the_same_stand_ins(monkeypatch):
+    """The reference's UNMODIFIED demos/video_iterator.py imported on the same decoder stand-ins (its top-level ``import
+    decord / cv2 / ffmpeg`` resolve to them): its ``DecordVideoIterator`` / ``CV2VideoIterator`` / ``build_video_iterator``
+    and this package's yield the same frame ids and the same arrays — every rotation tag, subsets, a failing read."""
+    import importlib.util
+    from siammot_amd import video
+    _install_fake_decoders(monkeypatch)
+    spec = importlib.util.spec_from_file_location("ref_video_iterator", os.path.join(REFERENCE, "demos", "video_iterator.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    checked = 0
+    for k, rotate in enumerate((0, 90, 180, 270)):
+        path = "clip_%d.mp4" % rotate
+        _fake_clip(path, n=6, hw=(5, 9), rotate=rotate, fail_at=(4 if rotate == 180 else None), seed=10 + k)
+        for kind in ("decord", "cv2"):
+            for idxs in (None, [4, 0, 3]):
+                mine = video.build_video_iterator(path, video_decode=kind)
+                theirs = ref.build_video_iterator(path, video_decode=kind)
+                if idxs is not None:
+                    mine, theirs = type(mine)(path, frame_idxs=idxs), type(theirs)(path, frame_idxs=idxs)
+                a, b = list(mine()), list(theirs())
+                assert len(mine) == len(theirs) and [int(i) for i, _ in a] == [int(i) for i, _ in b]
+                for (_, fa), (_, fb) in zip(a, b):
+                    assert np.array_equal(fa, fb)
+                    checked += 1
+    assert checked > 60
+
+
 def test_prefetch_preserves_order_and_surfaces_errors():
     from siammot_amd.video import ArrayVideoIterator, prefetch
     frames = [np.full((4, 4, 3), i, dtype=np.uint8) for i in range(7)]
