@@ -146,9 +146,9 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x;
 #define W_TRACE(SLOT) \
-    if (trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
+    if (ABL != 15 && trace && tid == 0) trace[(size_t)blockIdx.x * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
     W_TRACE(0)
-    if (trace && tid == 0) {      // where this workgroup runs: HW_ID (cu/sh/se) and XCC_ID
+    if (ABL != 15 && trace && tid == 0) {      // where this workgroup runs: HW_ID (cu/sh/se) and XCC_ID
         trace[(size_t)blockIdx.x * 8 + 6] = (long long)__builtin_amdgcn_s_getreg(0xF804);
         trace[(size_t)blockIdx.x * 8 + 7] = (long long)__builtin_amdgcn_s_getreg(0xF814);
     }
@@ -248,6 +248,29 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
                 f[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_in, raw_voff[j], soff, 0));
         }
     };
+    // the same fetch as inline asm: hipcc's waitcnt pass does not count it, so the loop places its own s_waitcnt vmcnt(N)
+    // (round 6: a stage's fetches stay in flight across the stage's end; see WB_STAGE)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long pin = reinterpret_cast<unsigned long long>(in);
+    const i32x4 rs_in_words = {__builtin_amdgcn_readfirstlane((int)(unsigned)pin),
+                               __builtin_amdgcn_readfirstlane((int)((unsigned)(pin >> 32) & 0xffffu)),
+                               BLOCKED ? (int)((unsigned)C * MAP * 4u) : 0x7fffffff, 0x00020000};
+    auto load_raw_asm = [&](int st, float4* pr) __attribute__((always_inline)) {
+        const int soff = __builtin_amdgcn_readfirstlane(st * (W_STAGE_IC * MAP * 4));
+        if constexpr (!BLOCKED) {
+#pragma unroll
+            for (int j = 0; j < RAW4; ++j) {
+                f32x4 v;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(raw_voff[j]), "s"(rs_in_words), "s"(soff) : "memory");
+                pr[j] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            float* f = reinterpret_cast<float*>(pr);
+#pragma unroll
+            for (int j = 0; j < RAWB; ++j)
+                asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(f[j]) : "v"(raw_voff[j]), "s"(rs_in_words), "s"(soff) : "memory");
+        }
+    };
     auto store_raw = [&](float* buf, const float4* pr) {
         if constexpr (!BLOCKED) {
 #pragma unroll
@@ -290,11 +313,19 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // (inline asm: through the builtin, hipcc drains vmcnt before the next LDS read of ANY address — right after the issue;
     // here a stage's loads are waited for at the END of the stage, ~2 k cycles after their issue, with a plain vmcnt(0)
     // (no assumption on the order in which direct-to-LDS and register loads retire), and consumed two barriers later)
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
     const unsigned long long pa = reinterpret_cast<unsigned long long>(packed);
     const i32x4 rs_a_words = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
                               __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0x7fffffff, 0x00020000};
     const unsigned a_lds_byte = (unsigned)(size_t)a_lds;
+    auto dma_part = [&](int q, int kbp, int part) __attribute__((always_inline)) {
+        {
+            const int soff = __builtin_amdgcn_readfirstlane(ab_base + kbp * ab_block + (q * 3 + part) * 1024);
+            const unsigned dst = __builtin_amdgcn_readfirstlane(a_lds_byte + (unsigned)(q * (4 * 2 * 768) + al_wave + part * 256) * 4u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rs_a_words), "s"(soff) : "memory");
+        }
+    };
     auto dma_slot = [&](int q, int kbp) __attribute__((always_inline)) {       // column q of rotated block kbp, tile tile0 + nh
 #pragma unroll
         for (int part = 0; part < 3; ++part) {
@@ -312,6 +343,15 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #pragma unroll
             for (int part = 0; part < 3; ++part)
                 dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 3 + part) * 256);
+    };
+    auto load_al2 = [&](int q, u32x4 (*dst)[3]) __attribute__((always_inline)) {      // ABL 18: two parts only
+        const float* src = sm + W_RING * W_BUF + q * (4 * 2 * 768) + al_row + lane * 4;
+#pragma unroll
+        for (int o = 0; o < OCT; ++o) {
+#pragma unroll
+            for (int part = 0; part < 2; ++part) dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 3 + part) * 256);
+            dst[o][2] = dst[o][1];
+        }
     };
     f32x4 acc[OCT][4][2 * NP];
 #pragma unroll
@@ -504,7 +544,50 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // residual v - (half H of the pair P), exact.  (As one v_dot2c_f32_bf16 — P . (-1, 0) + v — it was measured slower,
     // main loop 32.7 k -> 40.3 k cycles, and not exact.)
 #define WB_RES(V, P, H) ((V) - __uint_as_float((H) ? ((P) & 0xffff0000u) : ((P) << 16)))
+    // Round 6: the residuals on the MATRIX pipe.  The unpack + exact subtraction v - h of a split (8 of its 11 vector
+    // instructions per operand pair) is "C - B" on values that already sit in a matrix layout: v_mfma_f32_4x4x4_16b_bf16
+    // computes per lane D[i] = C[i] + sum_k A[lane's block][i][k] * B[k] with B = the lane's OWN four bf16 values, so with
+    // A = -I (lane L holds -1.0 at element L % 4) one 8-cycle matrix instruction returns the four residuals of the lane's
+    // four operands — exact, because the difference is representable and the products are +-h (tools/ubench/mfma_residual.hip
+    // checks 2^28 values per exponent pattern bit for bit against the vector form).  A column's four operands (two tiles x
+    // two k-steps) are one such group: 6 conversions + 2 matrix instructions instead of 22 vector instructions.
+    // (ABL 13 = the vector form of rounds 4-5, kept in the measurement library for the A/B.)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const s16x4 negI = __builtin_bit_cast(s16x4, (u32x2){(lane & 3) == 0 ? 0x0000BF80u : ((lane & 3) == 1 ? 0xBF800000u : 0u),
+                                                         (lane & 3) == 2 ? 0x0000BF80u : ((lane & 3) == 3 ? 0xBF800000u : 0u)});
 #define WB_SPLIT(J, BA, BB)                                                                      \
+    if (ABL != 13 && ABL != 8) {                                                                 \
+        /* the four columns' chains level by level, so that a dependent instruction is four matrix instructions behind  \
+           the one it waits for (no wait states); fences keep hipcc from re-serialising the chains */                    \
+        f32x4 v4[4], r4[4];                                                                      \
+        unsigned hh[4][2], mm[4][2], ll[4][2];                                                   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+            v4[q] = (f32x4){BA[q][0], BB[q][0], BA[q][1], BB[q][1]};                             \
+            WB_CVT(hh[q][0], v4[q][0], v4[q][1]) WB_CVT(hh[q][1], v4[q][2], v4[q][3])            \
+        }                                                                                        \
+        W_FENCE                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                            \
+            r4[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(negI, __builtin_bit_cast(s16x4, (u32x2){hh[q][0], hh[q][1]}), v4[q], 0, 0, 0); \
+        W_FENCE                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+            WB_CVT(mm[q][0], r4[q][0], r4[q][1]) WB_CVT(mm[q][1], r4[q][2], r4[q][3])            \
+        }                                                                                        \
+        W_FENCE                                                                                  \
+        if (ABL != 18) _Pragma("unroll") for (int q = 0; q < 4; ++q)                             \
+            r4[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(negI, __builtin_bit_cast(s16x4, (u32x2){mm[q][0], mm[q][1]}), r4[q], 0, 0, 0); \
+        W_FENCE                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+            if (ABL == 18) { ll[q][0] = mm[q][0]; ll[q][1] = mm[q][1]; } else {                  \
+            WB_CVT(ll[q][0], r4[q][0], r4[q][1]) WB_CVT(ll[q][1], r4[q][2], r4[q][3]) }          \
+        }                                                                                        \
+        W_FENCE                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
+            Bp[0][q][0][J] = hh[q][0]; Bp[0][q][1][J] = hh[q][1];                                \
+            Bp[BF3 ? 1 : 0][q][0][J] = mm[q][0]; Bp[BF3 ? 1 : 0][q][1][J] = mm[q][1];            \
+            Bp[BF3 ? 2 : 0][q][0][J] = ll[q][0]; Bp[BF3 ? 2 : 0][q][1][J] = ll[q][1];            \
+        }                                                                                        \
+    } else                                                                                       \
     if (ABL == 8) { _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
         Bp[0][q][t][J] = __float_as_uint(BA[q][t]); Bp[BF3 ? 1 : 0][q][t][J] = __float_as_uint(BB[q][t]); } }      \
     else _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
@@ -555,8 +638,86 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     }
     // ABL 11: where a wave's time goes (s_memtime sums of wave 0: slot 6 = in the stage barriers, slot 7 = in the vmcnt waits)
     long long t_bar = 0, t_vm = 0;
+    // Round 6: the two waves of a SIMD in ANTI-PHASE ("ping-pong").  A stage is a vector phase P1 (raw store, operand transform,
+    // LDS reads of the next stage, split) and a matrix phase P2 (the column's 24 instructions); with every wave in the same
+    // phase at the same time (rounds 4-5) the SIMD's vector issue and its matrix pipe were busy one after the other: loop
+    // 33.8 k cycles for 12.3 k of matrix work and ~9 k of vector issue.  tools/ubench/mfma_residual.hip ("pingpong"): a wave
+    // that issues only bf16 matrix instructions is not slowed by a partner issuing only vector instructions (350 vs 332 us),
+    // and the partner keeps ~55 % of its rate.  So the waves 4-7 (nh = 1; wave w and w + 4 share a SIMD) run ONE INTERVAL
+    // behind the waves 0-3: a barrier between P1 and P2, one extra barrier for the late half before the loop and one for the
+    // early half after it — the k-th s_barrier of every wave pairs up, whatever its address — and at any time one wave of a
+    // SIMD is in P1 while its partner is in P2.  One code stream, no branch inside the loop.
+    // Ring / slot hazards with the half-stage lag (X = waves 0-3, Y = 4-7; X runs P1(s), P2(s) in the intervals 2s, 2s + 1, Y
+    // in 2s + 1, 2s + 2): raw planes of stage s + 2 are stored at the start of P1(s) [X 2s, Y 2s + 1] and first read in P1(s
+    // + 1) [X 2s + 2]; the slot's last readers were in P1(s - 3).  A parts of column (s + 2) % 4 are fetched at the start of
+    // P1(s), confirmed by the issuing wave's vmcnt(0) at the end of P2(s) [Y: end of 2s + 2], read in P2(s + 2) [X 2s + 5];
+    // the slot's last readers were in P2(s - 2) [Y 2s - 2].  The tail keeps the cadence (three pseudo-stages).
+    // (ABL 14 = the in-phase schedule of rounds 4-5, measurement library.)
+    constexpr bool PP = BF3 && ABL != 13 && ABL != 14 && ABL != 10 && ABL != 11;
+    constexpr int PP_VM_P1 = ABL == 16 ? 0 : (ABL == 17 ? 1 : 2);      // fetches issued in the vector phase (A/B: ABL 16, 17)
+    constexpr int PP_VMOPS = (ABL == 18 ? 2 : 3) + (BLOCKED ? RAWB : RAW4);      // vector-memory instructions a wave issues per stage
+#define WB_BAR asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // ABL 15: timeline of ONE stage (KB 2, J 1) per wave: trace[(workgroup * 8 + wave) * 8 + slot], slots: 0 before the stage's
+    // first barrier, 1 behind it, 2 staging issued, 3 transform + reads + split done, 4 behind the second barrier, 5 matrix
+    // instructions issued, 6 behind vmcnt(0)
+#define WB_STAMP(J, KB, SLOT) if (ABL == 15 && (KB) == 2 && (J) == 1 && trace && lane == 0) \
+        trace[((size_t)blockIdx.x * 8 + wave) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
 #define WB_STAGE(J, KB)                                                                          \
-    {                                                                                            \
+    if constexpr (PP) {                                                                          \
+        /* P1, vector phase: raw store, operand transform, next stage's LDS reads, split, this column's A parts requested */ \
+        WB_STAMP(J, KB, 0)                                                                       \
+        asm volatile("s_barrier" ::: "memory");                                                  \
+        WB_STAMP(J, KB, 1)                                                                       \
+        store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
+        W_FENCE                                                                                  \
+        if (ABL != 9 && PP_VM_P1 >= 1) load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]); \
+        W_FENCE                                                                                  \
+        WB_STAMP(J, KB, 2)                                                                       \
+        float ba[4][2 * NP], bb[4][2 * NP];                                                      \
+        u32x4 AB[OCT][3];                                                                        \
+        WB_XFORM(rd, ba)                               /* k-step 2s */                           \
+        W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
+        W_FENCE                                                                                  \
+        if (ABL != 9 && PP_VM_P1 >= 2) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);    \
+        W_FENCE                                                                                  \
+        WB_XFORM(rdb, bb)                              /* k-step 2s+1 */                         \
+        W_READ(((J) + 1) & 3, 1, rdb)                                                            \
+        WB_SPLIT(J, ba, bb)                                                                      \
+        if (ABL == 18) { load_al2(J, AB); } else load_al(J, AB);                                 \
+        W_FENCE                                                                                  \
+        WB_STAMP(J, KB, 3)                                                                       \
+        /* the raw stores are behind at least the 14 LDS reads above (LDS operations of a wave complete in order) */ \
+        if (ABL == 18) asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");          \
+        else asm volatile("s_waitcnt lgkmcnt(14)\n\ts_barrier" ::: "memory");                    \
+        W_FENCE                                                                                  \
+        WB_STAMP(J, KB, 4)                                                                       \
+        /* P2, matrix phase: the column's 24 instructions; this stage's fetches are issued in their shadow */ \
+        if (ABL != 18) { WB_TERM(J, 2, 0) }                                                      \
+        W_FENCE                                                                                  \
+        if (ABL != 9 && PP_VM_P1 < 1) load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]); \
+        W_FENCE                                                                                  \
+        if (ABL != 18) { WB_TERM(J, 1, 1) }                                                      \
+        W_FENCE                                                                                  \
+        /* slot (J + 2) % 4 was consumed two stages ago; its next use is two stages ahead */     \
+        if (ABL != 9 && PP_VM_P1 < 2) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);     \
+        W_FENCE                                                                                  \
+        if (ABL != 18) { WB_TERM(J, 0, 2) }                                                      \
+        W_FENCE                                                                                  \
+        if (ABL != 9) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 1);                     \
+        W_FENCE                                                                                  \
+        WB_TERM(J, 1, 0)                                                                         \
+        W_FENCE                                                                                  \
+        if (ABL != 9 && ABL != 18) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 2);        \
+        W_FENCE                                                                                  \
+        WB_TERM(J, 0, 1) WB_TERM(J, 0, 0)                                                        \
+        W_FENCE                                                                                  \
+        WB_STAMP(J, KB, 5)                                                                       \
+        /* everything older than this stage's fetches has arrived (loads retire in order): the A parts requested one stage  \
+           ago (read two stages after their request) and the raw planes stored at the start of the next stage */           \
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PP_VMOPS) : "memory");                         \
+        WB_STAMP(J, KB, 6)                                                                       \
+        W_FENCE                                                                                  \
+    } else {                                                                                     \
         const long long tb0 = ABL == 11 ? (long long)__builtin_amdgcn_s_memtime() : 0;           \
         __syncthreads();                                                                         \
         if (ABL == 11) t_bar += (long long)__builtin_amdgcn_s_memtime() - tb0;                   \
@@ -584,6 +745,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #define WB_LOOP                                                                                  \
     W_READ(0, 0, rd)                                                                             \
     W_READ(0, 1, rdb)                                                                            \
+    if (PP && nh == 1) asm volatile("s_barrier" ::: "memory");      /* the late half: one interval behind */ \
     if (nkb == 4) {        /* C = 128 unrolled: no loop-carried register shuffle (160 moves per trip otherwise) */ \
         WB_BLOCK(0) WB_BLOCK(1) WB_BLOCK(2) WB_BLOCK(3)                                          \
     } else if ((nkb & 1) == 0) {                     /* C = 64, 256, 512: two blocks per trip (half the shuffle) */ \
@@ -592,13 +754,29 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         for (int kb = 0; kb < nkb; ++kb) { WB_BLOCK(kb) }                                        \
     }                                                                                            \
     /* the last, partial blocks of the columns 0..2 (zero weights where their stages do not exist) */ \
-    __syncthreads();                                                                             \
-    if (ABL != 9) dma_slot(2, nkb);                                                              \
-    WB_Q(0)                                                                                      \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
-    __syncthreads();                                                                             \
-    WB_Q(1)                                                                                      \
-    WB_Q(2)
+    if (PP) {                                        /* three pseudo-stages in the loop's cadence */ \
+        asm volatile("s_barrier" ::: "memory");                                                  \
+        if (ABL != 9) dma_slot(2, nkb);                                                          \
+        asm volatile("s_barrier" ::: "memory");                                                  \
+        WB_Q(0)                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        /* the loop's last raw fetches (re-fetches of the last stage, never stored) have landed: their registers may die */ \
+        _Pragma("unroll") for (int j = 0; j < NRAW; ++j) asm volatile("" :: "v"(prs[0][j].x), "v"(prs[0][j].y), "v"(prs[0][j].z), "v"(prs[0][j].w), \
+                                                                        "v"(prs[1][j].x), "v"(prs[1][j].y), "v"(prs[1][j].z), "v"(prs[1][j].w)); \
+        asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                     \
+        WB_Q(1)                                                                                  \
+        asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                     \
+        WB_Q(2)                                                                                  \
+        if (nh == 0) asm volatile("s_barrier" ::: "memory");      /* the early half waits for the late one */ \
+    } else {                                                                                     \
+        __syncthreads();                                                                         \
+        if (ABL != 9) dma_slot(2, nkb);                                                          \
+        WB_Q(0)                                                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
+        __syncthreads();                                                                         \
+        WB_Q(1)                                                                                  \
+        WB_Q(2)                                                                                  \
+    }
     W_TRACE(1)
     if constexpr (BF3) {
         static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
@@ -620,6 +798,8 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     __syncthreads();
 #undef WB_LOOP
 #undef WB_STAGE
+#undef WB_STAMP
+#undef WB_BAR
 #undef WB_BLOCK
 #undef WB_XFORM
 #undef WB_Q
@@ -827,6 +1007,12 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
         if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 11) fn = reinterpret_cast<const void*>(&tower_wino_kernel<11, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 13) fn = reinterpret_cast<const void*>(&tower_wino_kernel<13, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 14) fn = reinterpret_cast<const void*>(&tower_wino_kernel<14, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 16) fn = reinterpret_cast<const void*>(&tower_wino_kernel<16, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 17) fn = reinterpret_cast<const void*>(&tower_wino_kernel<17, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 18) fn = reinterpret_cast<const void*>(&tower_wino_kernel<18, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 15) fn = reinterpret_cast<const void*>(&tower_wino_kernel<15, 2, 0, true>);
 #endif
         const int rco = ensure_lds_optin(fn, smem, "predictor towers (winograd)");
         if (rco) return rco;
@@ -842,6 +1028,12 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
             case 9: WB_LAUNCH(9); break;
             case 10: WB_LAUNCH(10); break;
             case 11: WB_LAUNCH(11); break;
+            case 13: WB_LAUNCH(13); break;      // the vector-instruction split of rounds 4-5 (correct results)
+            case 16: WB_LAUNCH(16); break;
+            case 17: WB_LAUNCH(17); break;
+            case 18: WB_LAUNCH(18); break;      // timing of a two-part / three-product form (WRONG results)
+            case 15: WB_LAUNCH(15); break;      // one stage's timeline per wave (trace layout [workgroup][wave][8])
+            case 14: WB_LAUNCH(14); break;      // the in-phase schedule of rounds 4-5 with the round-6 split (correct results)
             default: WB_LAUNCH(0); break;
         }
 #else
