@@ -1,4 +1,4 @@
-"""bf16 x 3 form of the Winograd towers (SMOT_TOWER_BF3=1, measurement library) against the fp32 form:
+"""Split form of the Winograd towers (round 6: fp16 x 2; rounds 4-5: bf16 x 3) (SMOT_TOWER_BF3=1, measurement library) against the fp32 form:
    logit error of both against an fp64 evaluation of the same predictor, and the tower kernel's duration.  JSON lines."""
 import json, os, sys
 import numpy as np, torch
@@ -33,10 +33,10 @@ for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
     resp = torch.randn(n, 128, 16, 16, device=dev) * 15
     r64 = ref64(resp)
     outs = {}
-    forms = [("fp32", dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=0)), ("bf16x3", dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1)),
+    forms = [("fp32", dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=0)), ("fp16x2", dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1)),
              ("fp32_one_tile", dict(SMOT_TOWER_OCT=1, SMOT_TOWER_BF3=0))]
     for a in [x for x in os.environ.get("ABLS", "").split(",") if x]:      # timing ablations of the bf16 x 3 form (wrong results)
-        forms.append(("bf16x3_abl%s" % a, dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1, SMOT_WINO_ABL=a)))
+        forms.append(("fp16x2_abl%s" % a, dict(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1, SMOT_WINO_ABL=a)))
     for name, env in forms:
         with ops.debug_library(**env):
             f = lambda: ops.emm_predictor(resp, P)
@@ -67,5 +67,5 @@ for n in [int(t) for t in os.environ.get("TRACKS", "30,100").split(",")]:
                           "max_abs_err_vs_fp64": float(e.max()), "mean_abs_err_vs_fp64": float(e.mean()),
                           "max_err_over_channel_scale": float((e.amax(dim=(0, 2, 3)) / scale).max()),
                           "finite": bool(torch.isfinite(o).all()), "phase_ticks_mean": phases}), flush=True)
-    d = (outs["bf16x3"] - outs["fp32"]).abs()
-    print(json.dumps({"tracks": n, "bf16x3_vs_fp32_max_abs": float(d.max()), "equal_fraction": float((d == 0).float().mean())}), flush=True)
+    d = (outs["fp16x2"] - outs["fp32"]).abs()
+    print(json.dumps({"tracks": n, "fp16x2_vs_fp32_max_abs": float(d.max()), "equal_fraction": float((d == 0).float().mean())}), flush=True)

@@ -21,9 +21,9 @@ with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1, SMOT_WINO_ABL=15):
     lib.smot_debug_trace(ops._ptr(tr)); f(); torch.cuda.synchronize(); tr.zero_(); f(); torch.cuda.synchronize()
     lib.smot_debug_trace(ops._ptr(None))
 t = tr.view(grid, 8, 8).cpu().numpy().astype(np.float64)
-t = t[t[:, 0, 6] != 0]
+t = t[t[:, 0, 5] != 0]
 base = t[:, :, 0].min(axis=1)[:, None, None]
-rel = (t[:, :, :7] - base)
-names = ["before_barrier1", "after_barrier1", "staging_issued", "vector_phase_done", "after_barrier2", "matrix_issued", "after_vmcnt0"]
+rel = (t[:, :, :6] - base)
+names = ["before_barrier1", "after_barrier1", "raw_planes_stored", "vector_phase_done", "after_vmcnt0_and_barrier2", "matrix_and_fetches_issued"]
 print(json.dumps({"tracks": n, "workgroups": int(t.shape[0]), "slots": names,
                   "mean_cycles_by_wave": {("wave%d" % w): [round(float(x), 0) for x in rel[:, w, :].mean(0)] for w in range(8)}}))

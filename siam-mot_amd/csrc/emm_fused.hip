@@ -14,7 +14,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
                    const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
                    const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out,
-                   unsigned* zero_words, bool* zeroed);
+                   unsigned* zero_words, bool* zeroed, const float* plane_max);
 int decode_impl(LogitSrc L, const float* sr, const float* boxes, const float* hann, int N, int Ho, int up, int rx,
                 int rz, float pad_pixels, float one_minus_sigma, float sigma, int use_centerness, float clip_w,
                 float clip_h, float* cand_ws, float* bb, float* conf, int64_t* idx, bool tickets_zeroed,
@@ -27,11 +27,13 @@ int launch_extract_cache(const float* const* feats, const int* heights, const in
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
-                        hipStream_t st, const int** hint_status);
+                        hipStream_t st, const int** hint_status, float* plane_max);
 int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                          const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                          const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st);
 }  // namespace smot
+
+static inline bool p12_form3(int N, int C, int ho) { return smot_emm_tower_form(N, C, ho) == 3; }
 
 extern "C" long long smot_emm_track_ws_floats(int N, int C, int rx, int rz) {
     if (N < 0 || C <= 0 || rz <= 0 || rx < rz) return -1;
@@ -62,14 +64,19 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     float* logits = tower + (size_t)N * 2 * C * ho * ho;
     float* cand = logits + (size_t)N * 8 * ho * ho;       // 7 planes used; 8 keeps the 8-byte alignment
     int rc;
+    // the response's plane maxima [N][C] for the tower kernel's split form: in the head of the logits buffer, which nothing
+    // reads before the towers and the decode kernel writes after them; nullptr = the predictor makes them itself
+    const float* plane_max = nullptr;
     const int* poison = nullptr;
     const bool no_fuse = knobs().no_fuse;             // A/B: measurement library only (constant false otherwise)
     if (rx == 30 && rz == 15 && sampling_ratio == 2 && !no_fuse) {
         // pooling feeds the correlation inside one kernel: the search-region tensor never reaches HBM
         // (a hint the kernel honours is VERIFIED against `boxes` / `sr` by it; `poison` = the list's status word)
+        float* pm = (C <= 7 * ho * ho && p12_form3(N, C, ho)) ? logits : nullptr;
         rc = sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
-                                 nullptr, order_hint, (hipStream_t)stream, &poison);
+                                 nullptr, order_hint, (hipStream_t)stream, &poison, pm);
         if (rc) return rc;
+        plane_max = pm;
     } else if (rx == 35 && rz == 7 && sampling_ratio == 2 && !no_fuse) {
         // the second yaml family's shape: gathers + correlation in one kernel (sr_xcorr_small.hip), same arithmetic
         rc = sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
@@ -89,7 +96,7 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
     bool tickets_zeroed = false;           // the Winograd tower kernel zeroes the decode kernel's tickets on its way
     rc = predictor_impl(resp, N, C, ho, p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9], p[10], p[11],
                         gn_groups, gn_eps, p[12], tower, logits, stream, &tiles, decode_tickets(cand, N, ho),
-                        &tickets_zeroed);
+                        &tickets_zeroed, plane_max);
     if (rc) return rc;
     LogitSrc L;
     L.logits = tiles > 0 ? nullptr : logits;

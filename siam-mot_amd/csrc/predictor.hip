@@ -497,7 +497,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
                    const float* cls_w, const float* cls_b, const float* center_w, const float* center_b,
                    const float* reg_w, const float* reg_b, int gn_groups, float gn_eps,
                    const float* tower_packed, float* tower_ws, float* logits, smot_stream_t stream, int* tiles_out,
-                   unsigned* zero_words, bool* zeroed) {
+                   unsigned* zero_words, bool* zeroed, const float* plane_max) {
     if (zeroed) *zeroed = false;
     if (tiles_out) *tiles_out = 0;
     SMOT_REQUIRE(N >= 0 && C > 0 && Ho > 0 && gn_groups > 0, "predictor: bad sizes N=%d C=%d Ho=%d groups=%d", N, C,
@@ -523,6 +523,17 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
     const bool pow2 = (C & (C - 1)) == 0;      // tile counts 1,2,4,...: what heads_combine is built for
     const bool mfma_ok = (Ho == 16) && (C % 32 == 0) && pow2 && (C <= 512) && (cpg <= 16) && (16 % cpg == 0);
     const bool wino = mfma_ok && tower_packed != nullptr && !knobs().tower_direct;
+    // The split (fp16 x 2) form of the Winograd towers scales every track's response by a power of two chosen from the
+    // largest |response| of its planes (tower_wino.hip).  The pooling + correlation kernel hands the plane maxima over
+    // (`plane_max`); for a response that came without them one small launch makes them, in the head of the `logits`
+    // buffer — N C <= N 7 Ho^2 floats that nothing reads before the tower kernel has and the logits overwrite afterwards.
+    if (plane_max == nullptr && tower_packed != nullptr && !knobs().tower_direct && smot_emm_tower_form(N, C, Ho) == 3 &&
+        (mfma_ok || Ho == 29)) {
+        SMOT_REQUIRE(C <= 7 * Ho * Ho, "predictor: C=%d too large for the plane maxima's scratch", C);
+        const int rcm = launch_plane_absmax(resp, N * C, Ho * Ho, logits, st);
+        if (rcm) return rcm;
+        plane_max = logits;
+    }
     if (mfma_ok) {
         // 16-channel tiles double the workgroup count: use them while 32-channel tiles would leave
         // CUs idle or single-wave (256 CUs; two workgroups per CU fit either way)
@@ -550,7 +561,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         timer_mark(1, 0, st);
         if (wino) {
             SMOT_REQUIRE(((uintptr_t)tower_packed & 15) == 0, "predictor: tower_packed must be 16-byte aligned");
-            int rcw = launch_tower_wino(resp, tower_packed, T, N, C, cpg, gn_eps, tower_ws, zero_words, st);
+            int rcw = launch_tower_wino(resp, tower_packed, T, N, C, cpg, gn_eps, tower_ws, zero_words, st, plane_max);
             if (rcw) return rcw;
             if (zeroed) *zeroed = (zero_words != nullptr);
         } else if (!narrow) {
@@ -595,7 +606,7 @@ int predictor_impl(const float* resp, int N, int C, int Ho, const float* cls_tow
         SMOT_REQUIRE(((uintptr_t)tower_packed & 15) == 0, "predictor: tower_packed must be 16-byte aligned");
         timer_mark(1, 0, st);
         rc = launch_tower_conv_wino(resp, tower_packed, T, N, C, Ho, cpg, gn_eps, cls_b, center_b, reg_b, tower_ws, logits,
-                                    zero_words, st);
+                                    zero_words, st, plane_max);
         timer_mark(1, 1, st);
     }
     if (rc == SMOT_ERR_UNSUPPORTED)
@@ -639,6 +650,6 @@ extern "C" int smot_emm_predictor_fwd(const float* resp, int N, int C, int Ho, c
                                       smot_stream_t stream) {
     return smot::predictor_impl(resp, N, C, Ho, cls_tower_w, cls_gn_w, cls_gn_b, reg_tower_w, reg_gn_w, reg_gn_b, cls_w,
                                 cls_b, center_w, center_b, reg_w, reg_b, gn_groups, gn_eps, tower_packed, tower_ws,
-                                logits, stream, nullptr, nullptr, nullptr);
+                                logits, stream, nullptr, nullptr, nullptr, nullptr);
 }
 

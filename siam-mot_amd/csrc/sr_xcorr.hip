@@ -25,6 +25,7 @@
 #include "xcorr_patch1.h"
 #include "knobs.h"
 #include <type_traits>
+namespace smot { int launch_plane_absmax(const float* resp, int planes, int hw, float* pm, hipStream_t st); }   // tower_wino.hip
 
 namespace smot {
 
@@ -55,6 +56,8 @@ struct SrOut {
     int plan_pad[SMOT_MAX_LEVELS];   // hint writer: zero-pad cells per level of the NEXT frame's search-region pooling
                           // (the extraction itself pools un-padded maps); the finished sample tables in a hint entry are
                           // built against them
+    float* plane_max;     // pooling + correlation kernel: the largest |response| of every plane [R][C], or nullptr — the tower
+                          // kernel's split form scales a track's response by a power of two chosen from them (tower_wino.hip)
 };
 // One hint entry = SMOT_HINT_FLOATS dwords: {search region x1,y1,x2,y2, FPN level, roi index, 0, 0 | ymin, ymax, xmin, xmax of the
 // touched window, pad cells / H / W of the level the tables were built against, 0 | y table [64] x int4 | x table [64] x int4}
@@ -617,8 +620,10 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     if (ymax < ymin || xmax < xmin) {
         // every sample in the virtual zero border: pooled planes are exact zeros -> zero response
         if (owns) {
-            if (XCORR)
+            if (XCORR) {
                 for (int e = lane; e < HO * HO; e += 64) resp[(size_t)plane * HO * HO + e] = 0.0f;
+                if (S.plane_max != nullptr && lane == 0) S.plane_max[plane] = 0.0f;
+            }
             if (x_debug != nullptr)
                 for (int e = lane; e < RX * RX; e += 64) x_debug[(size_t)plane * RX * RX + e] = 0.0f;
         }
@@ -866,7 +871,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         } else if (owns) {
             const float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
             const float* zs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;
-            xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane);
+            xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane, S.plane_max);
         }
     }
     FX_TRACE(4)
@@ -960,7 +965,7 @@ int fused10_plan_floats();
 int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                         const float* scales, int num_levels, int C, const float* boxes, const float* sr,
                         const float* templates, int N, float* resp, float* x_debug, const float* order_hint,
-                        hipStream_t st, const int** hint_status) {
+                        hipStream_t st, const int** hint_status, float* plane_max) {
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_fused");
     if (rc) return rc;
@@ -981,12 +986,21 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
         timer_mark(0, 0, st);
         rcp = launch_fused10(P, C, plans, templates, N, resp, x_debug, st);
         timer_mark(0, 1, st);
+        if (rcp == SMOT_OK && plane_max != nullptr) rcp = launch_plane_absmax(resp, N * C, 256, plane_max, st);
         return rcp;
     }
 #endif
     timer_mark(0, 0, st);
     SrOut none = {nullptr, 0.f, 0.f, 0.f, 0.f, g_trace, knobs().fused_abl, nullptr, fused_order(), nullptr, order_hint, 0};
+    none.plane_max = plane_max;
 #ifdef SMOT_DEBUG
+    if (plane_max != nullptr && (knobs().fused_gen == 2 || knobs().fused_abl == 5)) {      // kernels that do not write them
+        none.plane_max = nullptr;
+        launch_fused<30, true>(grid, st, P, C, sr, boxes, templates, resp, x_debug, nullptr, none);
+        timer_mark(0, 1, st);
+        const int rcl = check_launch("sr_xcorr_fused");
+        return rcl ? rcl : launch_plane_absmax(resp, N * C, 256, plane_max, st);
+    }
     // A/B (measurement library, SMOT_FUSED_ABL=4): four channels per workgroup, twice the workgroups (960 of four waves at
     // 30 tracks: finer balance, twice the table builds).  Bit-identical; 17.7 vs 17.7 us at 30 tracks, 39.0 vs 39.7 at 100
     // (measure/fused_ab.py): not worth a second configuration.
@@ -1023,7 +1037,7 @@ extern "C" int smot_debug_sr_xcorr_fused_hint_fwd(const float* const* feats, con
                                                   const float* boxes, const float* sr, const float* templates, int N,
                                                   float* resp, const float* order_hint, smot_stream_t stream) {
     return smot::sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N,
-                                     resp, nullptr, order_hint, (hipStream_t)stream, nullptr);
+                                     resp, nullptr, order_hint, (hipStream_t)stream, nullptr, nullptr);
 }
 #endif
 
@@ -1060,5 +1074,5 @@ extern "C" int smot_sr_xcorr_fused_fwd(const float* const* feats, const int* hei
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_fused: null pointer");
     return sr_xcorr_fused_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, resp,
-                               x_debug, nullptr, (hipStream_t)stream, nullptr);
+                               x_debug, nullptr, (hipStream_t)stream, nullptr, nullptr);
 }

@@ -438,13 +438,13 @@ int launch_tower_conv(const float* resp, const TowerParams& P, int N, int C, int
 // 29x29 map -> tower_ws [N][2C][HW], then GroupNorm + ReLU + partial heads per (track, tower, 16-channel tile) in place,
 // then the combine.  Needs the packed (transformed) filters of smot_emm_tower_pack.
 int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
-                             float* conv, unsigned* zero_words, hipStream_t st);                       // tower_wino.hip
+                             float* conv, unsigned* zero_words, hipStream_t st, const float* plane_max);   // tower_wino.hip
 int launch_tower_conv_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int Ho, int cpg,
                            float eps, const float* cls_b, const float* center_b, const float* reg_b, float* tower_ws,
-                           float* logits, unsigned* zero_words, hipStream_t st) {
+                           float* logits, unsigned* zero_words, hipStream_t st, const float* plane_max) {
     if (Ho != 29 || C % 32 != 0 || cpg > 16 || 16 % cpg != 0 || packed == nullptr) return SMOT_ERR_UNSUPPORTED;
     using G = ConvGeom<29>;
-    int rc = launch_tower_wino_blocks(resp, packed, P, N, C, cpg, tower_ws, zero_words, st);
+    int rc = launch_tower_wino_blocks(resp, packed, P, N, C, cpg, tower_ws, zero_words, st, plane_max);
     if (rc) return rc;
     const size_t smem = (size_t)(16 * G::PLANE + 128) * sizeof(float);
     const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_gn_heads_kernel<29>), smem,

@@ -47,20 +47,28 @@ constexpr int W_EPI_FLOATS = W_ST_OFF + 32;         // epilogue image of ONE 16-
 constexpr int w_smem_floats(int oct) {              // the epilogue images (one per tile) overlay the ring
     return (oct * W_EPI_FLOATS > W_RING * W_BUF) ? oct * W_EPI_FLOATS : W_RING * W_BUF;
 }
-constexpr int W_A_FLOATS = 4 * 4 * 2 * 3 * 256;     // BF3: bf16 A parts of one 32-channel block [q][xi][o][part][1 KB]
+constexpr int W_A_FLOATS = 4 * 4 * 2 * 2 * 256;     // BF3: fp16 A parts of one 32-channel block [q][xi][o][part][1 KB]
+constexpr int W_A_SLOT = 4 * 2 * 2 * 256;           // floats per slot (one xi column q): [xi][o][part][256]
+constexpr int W_AB_ROW = 4 * 2 * 1024;              // bytes of one xi row of a (tile, block): [q][part][lane][16 B]
 static_assert((W_RING * W_BUF + W_A_FLOATS) * 4 <= 160 * 1024, "BF3: ring + A image in one CU's LDS");
 static_assert(w_smem_floats(1) * 4 <= 64 * 1024, "OCT = 1: two workgroups per CU, no opt-in needed");
 static_assert(w_smem_floats(2) * 4 <= 160 * 1024, "OCT = 2: one workgroup per CU");
 
-__device__ __forceinline__ unsigned short bf16_rne(float v) {      // round to nearest even, finite inputs
-    const unsigned u = __float_as_uint(v);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
 // packed[tile][k = ic/4][wave][lane][q] = (G g G^T)[i = wave][j = q] of g = W[oc = 16*tile + lane%16][ic = 4k + lane/16]
 // (oc counts cls_tower channels first, then reg_tower).  One thread per (oc, ic).
+// scale 2^ku of the fp16 weight image from the largest |w| (bits): |u| <= 2.25 max|w| (rows of G have absolute sums <=
+// 1.5), so 2^ku * 2.25 * max|w| < 2^15; 1 for a zero, infinite or NaN maximum
+__device__ __forceinline__ float tower_pack_scale(unsigned wmax_bits) {
+    const int e = (int)((wmax_bits >> 23) & 0xffu);              // max|w| < 2^(e - 126)
+    if (e == 0 || e == 255) return 1.0f;
+    int k = 266 - e;                                             // |u| < 2^(e - 124): 2^ku = 2^(139 - e), biased exponent 266 - e
+    k = k < 1 ? 1 : (k > 254 ? 254 : k);
+    return __uint_as_float((unsigned)k << 23);
+}
+
 __global__ void __launch_bounds__(256)
-tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, int C, float* __restrict__ packed) {
+tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, int C, float* __restrict__ packed,
+                  unsigned* __restrict__ hdr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= 2 * C * C) return;
     const int oc = idx / C, ic = idx - oc * C;
@@ -85,30 +93,62 @@ tower_pack_kernel(const float* __restrict__ wc, const float* __restrict__ wr, in
         u.w = gg[i][2];
         *reinterpret_cast<float4*>(packed + ((((size_t)tile * nk + k) * 4 + i) * 64 + lane) * 4) = u;
         if ((C & 31) == 0) {
-            // bf16 image (tower_wino_kernel<.., BF3>): every transformed weight as THREE bf16 parts u = u1 + u2 + u3 (each
-            // part the round-to-nearest bf16 of what the parts before it leave: the residuals are exact, |u - sum| <=
-            // 2^-26 |u|), in the A-operand order of v_mfma_f32_16x16x32_bf16 (lane = oc%16 + 16*(ic%4) holds the eight
-            // channels 32 kb + 4 s + ic%4, s = 0..7), with the 32-channel blocks of xi column q ROTATED by q + 1 stages
-            // (a stage = 8 channels = one dword d = s/2 of the lane's operand): block kb' of column q holds the dwords d <=
-            // q of channel block kb' and the dwords d > q of channel block kb' - 1 (zero outside 0..C/32-1; the image is
-            // zero-filled before this kernel), so that the kernel can consume one column per stage:
-            //   bf[tile][kb' = 0..C/32][i][q][part][lane][s]   (16 B per lane)
-            unsigned short* bf = reinterpret_cast<unsigned short*>(packed + (size_t)2 * C * C * 16);
+            // fp16 image (tower_wino_kernel<.., BF3>, round 6): every transformed weight, scaled by the power of two 2^ku the
+            // header names (so that the largest |u| lies in [2^13, 2^15): the second part stays a normal fp16 number), as TWO
+            // fp16 parts u 2^ku = u1 + u2 (u1 = round-to-nearest fp16, u2 = round-to-nearest fp16 of the exact residual:
+            // |u 2^ku - u1 - u2| <= 2^-23 |u| 2^ku), in the A-operand order of v_mfma_f32_16x16x32_f16 (lane = oc%16 +
+            // 16*(ic%4) holds the eight channels 32 kb + 4 s + ic%4, s = 0..7), with the 32-channel blocks of xi column q
+            // ROTATED by q + 1 stages (a stage = 8 channels = one dword d = s/2 of the lane's operand): block kb' of column q
+            // holds the dwords d <= q of channel block kb' and the dwords d > q of channel block kb' - 1 (zero outside
+            // 0..C/32-1; the image is zero-filled before this kernel), so that the kernel can consume one column per stage:
+            //   hf[tile][kb' = 0..C/32][i][q][part][lane][s]   (16 B per lane)
+            unsigned short* hf = reinterpret_cast<unsigned short*>(packed + (size_t)2 * C * C * 16);
             const int kb = ic >> 5, sidx = (ic & 31) >> 2, nkb1 = (C >> 5) + 1;
+            const float su = tower_pack_scale(hdr[0]);
             const float uq[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int kbp = ((sidx >> 1) <= q) ? kb : kb + 1;
-                float r = uq[q];
+                float r = uq[q] * su;                 // exact (power of two, no underflow of anything that matters)
 #pragma unroll
-                for (int part = 0; part < 3; ++part) {
-                    const unsigned short h = bf16_rne(r);
-                    r -= __uint_as_float((unsigned)h << 16);
-                    bf[((((((size_t)tile * nkb1 + kbp) * 4 + i) * 4 + q) * 3 + part) * 64 + lane) * 8 + sidx] = h;
+                for (int part = 0; part < 2; ++part) {
+                    const _Float16 h = (_Float16)r;   // round to nearest even
+                    r -= (float)h;                    // exact
+                    hf[((((((size_t)tile * nkb1 + kbp) * 4 + i) * 4 + q) * 2 + part) * 64 + lane) * 8 + sidx] =
+                        __builtin_bit_cast(unsigned short, h);
                 }
             }
+            if (idx == 0 && i == 0) reinterpret_cast<float*>(hdr)[1] = 1.0f / su;      // what the kernel multiplies back
         }
     }
+}
+
+// largest |w| of both tower filters -> hdr[0] (bits of a non-negative float order as unsigned integers; NaN ignored)
+__global__ void __launch_bounds__(256)
+tower_wmax_kernel(const float* __restrict__ wc, const float* __restrict__ wr, int count, unsigned* __restrict__ hdr) {
+    float m = 0.0f;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < count; e += gridDim.x * 256) m = fmaxf(m, fmaxf(fabsf(wc[e]), fabsf(wr[e])));
+    for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(hdr, __float_as_uint(m));
+}
+
+// |resp| maximum of every (track, channel) plane -> pm[n*C + c] (one wave per plane).  The split form of the tower kernel
+// scales a track's response by a power of two chosen from these (fp16 operand parts); the pooling + correlation kernel
+// writes them itself, this launch serves responses that come from elsewhere (stand-alone operator, other shapes).
+__global__ void __launch_bounds__(256)
+plane_absmax_kernel(const float* __restrict__ resp, int planes, int hw, float* __restrict__ pm) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const float* __restrict__ src = resp + (size_t)plane * hw;
+    float m = 0.0f;
+    for (int e = lane; e < hw; e += 64) m = plane_max_step(m, src[e]);
+    m = plane_max_wave(m);
+    if (lane == 0) pm[plane] = m;
+}
+
+int launch_plane_absmax(const float* resp, int planes, int hw, float* pm, hipStream_t st) {
+    hipLaunchKernelGGL(plane_absmax_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, resp, planes, hw, pm);
+    return check_launch("predictor towers (plane maxima)");
 }
 
 // ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
@@ -135,7 +175,7 @@ template <int ABL, int OCT, int BHO = 0, bool BF3 = false>
 __global__ void __launch_bounds__(256 * OCT, OCT == 1 ? 2 : 1)
 tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ packed, TowerParams P, int N, int C,
                   int cpg, float eps, float* __restrict__ part, unsigned* __restrict__ zero_words,
-                  long long* __restrict__ trace) {
+                  long long* __restrict__ trace, const float* __restrict__ plane_max) {
     constexpr int NT = 256 * OCT;             // threads
     constexpr int NP = 2 / OCT;               // tile-row halves (pairs of N-tiles) per wave
     constexpr bool BLOCKED = BHO > 0;
@@ -271,20 +311,24 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
                 asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(f[j]) : "v"(raw_voff[j]), "s"(rs_in_words), "s"(soff) : "memory");
         }
     };
+    // BF3: the track's response scaled by the power of two 2^kv (see the BF3 form of the loop): 4 |resp| 2^kv < 2^15, kv
+    // clamped to +-100; 1 for an all-zero track and for one with an infinite maximum (its outputs are NaN / inf either way).
+    // Set behind the first fetches (the loads of the maxima travel beside them).
+    float sv = 1.0f, inv_sv = 1.0f;
     auto store_raw = [&](float* buf, const float4* pr) {
         if constexpr (!BLOCKED) {
 #pragma unroll
             for (int j = 0; j < RAW4; ++j) {
                 float* d = buf + raw_lds[j];
-                d[0] = pr[j].x;
-                d[1] = pr[j].y;
-                d[2] = pr[j].z;
-                d[3] = pr[j].w;
+                d[0] = BF3 ? pr[j].x * sv : pr[j].x;
+                d[1] = BF3 ? pr[j].y * sv : pr[j].y;
+                d[2] = BF3 ? pr[j].z * sv : pr[j].z;
+                d[3] = BF3 ? pr[j].w * sv : pr[j].w;
             }
         } else {
             const float* f = reinterpret_cast<const float*>(pr);
 #pragma unroll
-            for (int j = 0; j < RAWB; ++j) buf[raw_lds[j]] = f[j];
+            for (int j = 0; j < RAWB; ++j) buf[raw_lds[j]] = BF3 ? f[j] * sv : f[j];
         }
     };
     // A operands: packed[tile][k][xi][lane][4]
@@ -302,56 +346,38 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             }
     };
 
-    // BF3: direct-to-LDS fetch of the bf16 A parts (see the BF3 form of the loop below)
+    // BF3: direct-to-LDS fetch of the fp16 A parts (see the BF3 form of the loop below)
     const int nkb = C >> 5;
-    const int ab_block = 4 * 12288;             // bytes per (tile, kb'): [xi][q][part][lane][8 bf16]
-    const int ab_base = __builtin_amdgcn_readfirstlane(2 * C * C * 64 + ((tile0 + nh) * (nkb + 1) * 4 + xi) * 12288);
+    const int ab_block = 4 * W_AB_ROW;          // bytes per (tile, kb'): [xi][q][part][lane][8 fp16]
+    const int ab_base = __builtin_amdgcn_readfirstlane(2 * C * C * 64 + ((tile0 + nh) * (nkb + 1) * 4 + xi) * W_AB_ROW);
     typedef __attribute__((address_space(3))) float lds_float;
     lds_float* const a_lds = (lds_float*)(sm + W_RING * W_BUF);
-    const int al_wave = __builtin_amdgcn_readfirstlane((xi * 2 + nh) * 768);            // floats: this wave's DMA slots
-    const int al_row = __builtin_amdgcn_readfirstlane(xi * 2 * 768);                    // floats: the row's slots
+    const int al_wave = __builtin_amdgcn_readfirstlane((xi * 2 + nh) * 512);            // floats: this wave's DMA slots
+    const int al_row = __builtin_amdgcn_readfirstlane(xi * 2 * 512);                    // floats: the row's slots
     // (inline asm: through the builtin, hipcc drains vmcnt before the next LDS read of ANY address — right after the issue;
-    // here a stage's loads are waited for at the END of the stage, ~2 k cycles after their issue, with a plain vmcnt(0)
-    // (no assumption on the order in which direct-to-LDS and register loads retire), and consumed two barriers later)
+    // here the loop places its own s_waitcnt vmcnt(N), see WB_STAGE)
     const unsigned long long pa = reinterpret_cast<unsigned long long>(packed);
     const i32x4 rs_a_words = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa),
                               __builtin_amdgcn_readfirstlane((int)((unsigned)(pa >> 32) & 0xffffu)), 0x7fffffff, 0x00020000};
     const unsigned a_lds_byte = (unsigned)(size_t)a_lds;
-    auto dma_part = [&](int q, int kbp, int part) __attribute__((always_inline)) {
-        {
-            const int soff = __builtin_amdgcn_readfirstlane(ab_base + kbp * ab_block + (q * 3 + part) * 1024);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(a_lds_byte + (unsigned)(q * (4 * 2 * 768) + al_wave + part * 256) * 4u);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rs_a_words), "s"(soff) : "memory");
-        }
+    auto dma_part = [&](int q, int kbp, int part) __attribute__((always_inline)) {     // column q of rotated block kbp, tile tile0 + nh
+        const int soff = __builtin_amdgcn_readfirstlane(ab_base + (ABL == 12 ? 0 : kbp) * ab_block + (q * 2 + part) * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(a_lds_byte + (unsigned)(q * W_A_SLOT + al_wave + part * 256) * 4u);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rs_a_words), "s"(soff) : "memory");
     };
-    auto dma_slot = [&](int q, int kbp) __attribute__((always_inline)) {       // column q of rotated block kbp, tile tile0 + nh
-#pragma unroll
-        for (int part = 0; part < 3; ++part) {
-            const int soff = __builtin_amdgcn_readfirstlane(ab_base + kbp * ab_block + (q * 3 + part) * 1024);
-            const unsigned dst = __builtin_amdgcn_readfirstlane(a_lds_byte + (unsigned)(q * (4 * 2 * 768) + al_wave + part * 256) * 4u);
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "s"(dst), "v"(a_voff), "s"(rs_a_words), "s"(soff) : "memory");
-        }
+    auto dma_slot = [&](int q, int kbp) __attribute__((always_inline)) {
+        dma_part(q, kbp, 0);
+        dma_part(q, kbp, 1);
     };
-    auto load_al = [&](int q, u32x4 (*dst)[3]) __attribute__((always_inline)) {
-        const float* src = sm + W_RING * W_BUF + q * (4 * 2 * 768) + al_row + lane * 4;
+    auto load_al = [&](int q, u32x4 (*dst)[2]) __attribute__((always_inline)) {
+        const float* src = sm + W_RING * W_BUF + q * W_A_SLOT + al_row + lane * 4;
 #pragma unroll
         for (int o = 0; o < OCT; ++o)
 #pragma unroll
-            for (int part = 0; part < 3; ++part)
-                dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 3 + part) * 256);
-    };
-    auto load_al2 = [&](int q, u32x4 (*dst)[3]) __attribute__((always_inline)) {      // ABL 18: two parts only
-        const float* src = sm + W_RING * W_BUF + q * (4 * 2 * 768) + al_row + lane * 4;
-#pragma unroll
-        for (int o = 0; o < OCT; ++o) {
-#pragma unroll
-            for (int part = 0; part < 2; ++part) dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 3 + part) * 256);
-            dst[o][2] = dst[o][1];
-        }
+            for (int part = 0; part < 2; ++part)
+                dst[o][part] = *reinterpret_cast<const u32x4*>(src + (o * 2 + part) * 256);
     };
     f32x4 acc[OCT][4][2 * NP];
 #pragma unroll
@@ -373,6 +399,18 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         for (int o = 0; o < OCT; ++o) {
             aset[1][0][o] = aset[0][0][o];
             aset[1][1][o] = aset[0][1][o];
+        }
+    }
+    if constexpr (BF3) {
+        float m = 0.0f;
+        for (int c = lane; c < C; c += 64) m = fmaxf(m, plane_max[(size_t)n * C + c]);
+        m = plane_max_wave(m);
+        const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);      // m < 2^(e - 126)
+        if (e != 0 && e != 255) {
+            int k = 139 - e;
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            sv = __uint_as_float((unsigned)(127 + k) << 23);
+            inv_sv = __uint_as_float((unsigned)(127 - k) << 23);
         }
     }
     // (first global loads are in flight: their latency covers the fill and the weight fetch)
@@ -512,113 +550,105 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         W_STAGE(2)                                                                               \
         W_STAGE(3)                                                                               \
     }
-    // ---- BF3 form of the loop -----------------------------------------------------------------------
-    // K index of the bf16 instruction: lane group kq = lane/16 holds K = 8 kq + s, s = 0..7 <-> input channel 32 kb + 4 s +
+    // ---- BF3 form of the loop: the 16 GEMMs on the fp16 matrix pipe, two-part operands (round 6) --------------------
+    // Every fp32 operand is the sum of two fp16 parts a = a1 + a2 (a1 = RNE(a), a2 = RNE(a - a1): |a - a1 - a2| <= 2^-23 |a|),
+    // of a value scaled by a power of two so that fp16's exponent range is not an issue: the weights by 2^ku (chosen from
+    // the largest |w| by tower_pack_kernel: largest |u| 2^ku in [2^12, 2^15)), the track's response by 2^kv (chosen here
+    // from the track's largest |response|, plane_max: |V| 2^kv < 2^15 — V sums four responses); the accumulators are
+    // multiplied back by 2^-kv 2^-ku after the output transform — exact, so the result is that of the unscaled operands.  A
+    // product keeps three of the four part products,
+    //     a b ~ a1 b1 + a1 b2 + a2 b1,          dropped: a2 b2 <= 2^-22 |a b|, typically 2^-24,
+    // accumulated in fp32 by v_mfma_f32_16x16x32_f16.  Error against fp64 = the fp32 form's (tests/test_hip_parity.py holds
+    // it to 1.25 x; measure/debug/tower_bf3_check.py), at HALF the matrix instructions of the three-part bf16 form of
+    // rounds 4-5 (12 instead of 24 per stage) and a third less operand traffic.
+    // K index of the instruction: lane group kq = lane/16 holds K = 8 kq + s, s = 0..7 <-> input channel 32 kb + 4 s +
     // kq: s is the k-step inside a 32-channel block, so the lane's operand of k-step s is element s of its 8-vector and a
-    // stage (two k-steps) fills dword (stage % 4).  Bp[part][q][t] = the three bf16x8 B operands of xi column q, N-tile t.
+    // stage (two k-steps) fills dword (stage % 4).  Bp[part][q][t] = the two fp16x8 B operands of xi column q, N-tile t.
     // One xi column per stage: the K blocks of column q end with the stages = q (mod 4) (the weights are stored rotated to
-    // match, tower_pack_kernel), so every stage ends with the 24 instructions of ONE column ("mini-burst") instead of every
-    // fourth stage with 96: the operand registers are single-buffered all the same, matrix and vector work come in
-    // stage-sized pieces that overlap (the bf16 matrix instructions run beside vector instructions: loop 32.7 k cycles
-    // with, 27.6 k without them; all 96 after every fourth stage: 35 k), and the A parts of a column are needed once per
-    // four stages.  (Running the column of the PREVIOUS stage first in the second wave of each SIMD, so that the two waves
-    // alternate between matrix and vector work, was measured twice — four loop copies: 35.9 k against 34.2 k cycles; one
-    // copy with a wave-uniform branch: 38.8 k against 33.9 k — and dropped.)
-    // The loop is bound by its vector instructions (118 per wave and stage at ~4.3 cycles each on the SIMD's two waves:
-    // 28 of the operand transform, 88 of the split = 11 per operand pair, 2 addresses).
-    // A parts: the two waves of an xi row need the same 6 KB per column and block; every wave brings HALF of them (those
+    // match, tower_pack_kernel), so every stage ends with the 12 instructions of ONE column: the operand registers are
+    // single-buffered and the A parts of a column are needed once per four stages.
+    // A parts: the two waves of an xi row need the same 4 KB per column and block; every wave brings HALF of them (those
     // of tile tile0 + nh) into LDS with direct-to-LDS loads (no registers, 1 KB per instruction), two stages before the
-    // column is consumed, and both read them from there.  (Fetched per wave into registers they saturate the L2 -> CU
-    // path and their latency is exposed: measure/debug/tower_bf3_check.py.)
-    //   LDS: A image behind the ring: slot q = [xi][o][part][lane][8 bf16] = 24 KB, four slots.
-    u32x4 Bp[BF3 ? 3 : 1][4][2];
+    // column is consumed, and both read them from there.
+    //   LDS: A image behind the ring: slot q = [xi][o][part][lane][8 fp16] = 16 KB, four slots.
+    //
+    // The split.  The exact residual v - h of four operands is "C - B" on values that already sit in registers in a matrix
+    // layout: v_mfma_f32_4x4x4_16b_f16 computes per lane D[i] = C[i] + sum_k A[lane's block][i][k] * B[k] with B = the
+    // lane's OWN four fp16 values, so with A = -I (lane L holds -1.0 at element L % 4) one 8-cycle matrix instruction
+    // returns the four residuals — exact, because the difference is representable and the products are +-h
+    // (tools/ubench/mfma_residual.hip checks 2^28 values per exponent pattern bit for bit against the vector form, bf16
+    // there).  A column's four operands (two tiles x two k-steps) are one such group: 4 conversions + 1 matrix instruction.
+    //
+    // The schedule: the two waves of a SIMD in ANTI-PHASE.  A stage is a vector phase P1 (raw store, operand transform, LDS
+    // reads of the next stage, split) and a matrix phase P2 (the column's 12 instructions, the stage's fetches in their
+    // shadow).  tools/ubench/mfma_residual.hip ("pingpong"): a wave that issues only matrix instructions is not slowed by a
+    // partner issuing only vector instructions, and the partner keeps ~55 % of its rate.  So the waves 4-7 (nh = 1; wave w
+    // and w + 4 share a SIMD) run ONE INTERVAL behind the waves 0-3: a barrier between P1 and P2, one extra barrier for the
+    // late half before the loop and one for the early half after it — the k-th s_barrier of every wave pairs up, whatever
+    // its address — and at any time one wave of a SIMD is in P1 while its partner is in P2.  One code stream, no branch.
+    // Ring / slot hazards with the half-stage lag (X = waves 0-3, Y = 4-7; X runs P1(s), P2(s) in the intervals 2s, 2s + 1, Y
+    // in 2s + 1, 2s + 2): raw planes of stage s + 2 are stored at the start of P1(s) [X 2s, Y 2s + 1] and first read in P1(s
+    // + 1) [X 2s + 2]; the slot's last readers were in P1(s - 3).  A parts of column (s + 2) % 4 are requested in P2(s) [X 2s
+    // + 1, Y 2s + 2], confirmed by the issuing wave's vmcnt(0) at the end of P1(s + 1) [Y: end of 2s + 3], read in P2(s + 2)
+    // [X 2s + 5]; the slot's last readers were in P2(s - 2) [Y 2s - 2].  The tail keeps the cadence (three pseudo-stages).
+    // Fetches are inline asm (hipcc's waitcnt pass does not count them; through the builtins it drains vmcnt at the next
+    // LDS read): issued at the start of a matrix phase, waited for with ONE s_waitcnt vmcnt(0) at the end of the next vector
+    // phase — a full stage later, and with no assumption on the order in which direct-to-LDS and register loads retire (a
+    // vmcnt(N) form that relied on it produced a wrong A part in 2 of 300 workgroups of the placement test).
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x4 Bp[2][4][2];
     float rdb[NP][6][2];                        // second read set: both k-steps of the next stage are in flight
     if constexpr (BF3) {
 #pragma unroll
-        for (int e = 0; e < 24; ++e) (&Bp[0][0][0])[e] = (u32x4){0u, 0u, 0u, 0u};
+        for (int e = 0; e < 16; ++e) (&Bp[0][0][0])[e] = (u32x4){0u, 0u, 0u, 0u};
     }
-    // (v_cvt_pk_bf16_f32 through the vector conversion, NOT inline asm: the results are matrix-instruction operands a few
-    // instructions later, and hipcc's hazard recognizer does not see what an asm statement writes — with asm the column's
-    // instructions read half-written operands now and then)
-#define WB_CVT(D, A, B) D = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){A, B}, bf16x2));
-    // residual v - (half H of the pair P), exact.  (As one v_dot2c_f32_bf16 — P . (-1, 0) + v — it was measured slower,
-    // main loop 32.7 k -> 40.3 k cycles, and not exact.)
-#define WB_RES(V, P, H) ((V) - __uint_as_float((H) ? ((P) & 0xffff0000u) : ((P) << 16)))
-    // Round 6: the residuals on the MATRIX pipe.  The unpack + exact subtraction v - h of a split (8 of its 11 vector
-    // instructions per operand pair) is "C - B" on values that already sit in a matrix layout: v_mfma_f32_4x4x4_16b_bf16
-    // computes per lane D[i] = C[i] + sum_k A[lane's block][i][k] * B[k] with B = the lane's OWN four bf16 values, so with
-    // A = -I (lane L holds -1.0 at element L % 4) one 8-cycle matrix instruction returns the four residuals of the lane's
-    // four operands — exact, because the difference is representable and the products are +-h (tools/ubench/mfma_residual.hip
-    // checks 2^28 values per exponent pattern bit for bit against the vector form).  A column's four operands (two tiles x
-    // two k-steps) are one such group: 6 conversions + 2 matrix instructions instead of 22 vector instructions.
-    // (ABL 13 = the vector form of rounds 4-5, kept in the measurement library for the A/B.)
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    const s16x4 negI = __builtin_bit_cast(s16x4, (u32x2){(lane & 3) == 0 ? 0x0000BF80u : ((lane & 3) == 1 ? 0xBF800000u : 0u),
-                                                         (lane & 3) == 2 ? 0x0000BF80u : ((lane & 3) == 3 ? 0xBF800000u : 0u)});
+    const f16x4 negI = __builtin_bit_cast(f16x4, (u32x2){(lane & 3) == 0 ? 0x0000BC00u : ((lane & 3) == 1 ? 0xBC000000u : 0u),
+                                                         (lane & 3) == 2 ? 0x0000BC00u : ((lane & 3) == 3 ? 0xBC000000u : 0u)});
+    // (v_cvt_pk_f16_f32 through the vector conversion, NOT inline asm: the results are matrix-instruction operands a few
+    // instructions later, and hipcc's hazard recognizer does not see what an asm statement writes)
+#define WB_CVT(D, A, B) D = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){A, B}, f16x2));
+    // the four columns' chains level by level, so that a dependent instruction is four matrix instructions behind the one it
+    // waits for; fences keep hipcc from re-serialising the chains
 #define WB_SPLIT(J, BA, BB)                                                                      \
-    if (ABL != 13 && ABL != 8) {                                                                 \
-        /* the four columns' chains level by level, so that a dependent instruction is four matrix instructions behind  \
-           the one it waits for (no wait states); fences keep hipcc from re-serialising the chains */                    \
-        f32x4 v4[4], r4[4];                                                                      \
-        unsigned hh[4][2], mm[4][2], ll[4][2];                                                   \
+    {                                                                                            \
+        f32x4 v4[4];                                                                             \
+        unsigned hh[4][2], mm[4][2];                                                             \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
             v4[q] = (f32x4){BA[q][0], BB[q][0], BA[q][1], BB[q][1]};                             \
             WB_CVT(hh[q][0], v4[q][0], v4[q][1]) WB_CVT(hh[q][1], v4[q][2], v4[q][3])            \
         }                                                                                        \
         W_FENCE                                                                                  \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                            \
-            r4[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(negI, __builtin_bit_cast(s16x4, (u32x2){hh[q][0], hh[q][1]}), v4[q], 0, 0, 0); \
+            v4[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(f16x4, (u32x2){hh[q][0], hh[q][1]}), v4[q], 0, 0, 0); \
         W_FENCE                                                                                  \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
-            WB_CVT(mm[q][0], r4[q][0], r4[q][1]) WB_CVT(mm[q][1], r4[q][2], r4[q][3])            \
-        }                                                                                        \
-        W_FENCE                                                                                  \
-        if (ABL != 18) _Pragma("unroll") for (int q = 0; q < 4; ++q)                             \
-            r4[q] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(negI, __builtin_bit_cast(s16x4, (u32x2){mm[q][0], mm[q][1]}), r4[q], 0, 0, 0); \
-        W_FENCE                                                                                  \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
-            if (ABL == 18) { ll[q][0] = mm[q][0]; ll[q][1] = mm[q][1]; } else {                  \
-            WB_CVT(ll[q][0], r4[q][0], r4[q][1]) WB_CVT(ll[q][1], r4[q][2], r4[q][3]) }          \
+            WB_CVT(mm[q][0], v4[q][0], v4[q][1]) WB_CVT(mm[q][1], v4[q][2], v4[q][3])            \
         }                                                                                        \
         W_FENCE                                                                                  \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                          \
             Bp[0][q][0][J] = hh[q][0]; Bp[0][q][1][J] = hh[q][1];                                \
-            Bp[BF3 ? 1 : 0][q][0][J] = mm[q][0]; Bp[BF3 ? 1 : 0][q][1][J] = mm[q][1];            \
-            Bp[BF3 ? 2 : 0][q][0][J] = ll[q][0]; Bp[BF3 ? 2 : 0][q][1][J] = ll[q][1];            \
+            Bp[1][q][0][J] = mm[q][0]; Bp[1][q][1][J] = mm[q][1];                                \
         }                                                                                        \
-    } else                                                                                       \
-    if (ABL == 8) { _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
-        Bp[0][q][t][J] = __float_as_uint(BA[q][t]); Bp[BF3 ? 1 : 0][q][t][J] = __float_as_uint(BB[q][t]); } }      \
-    else _Pragma("unroll") for (int q = 0; q < 4; ++q) _Pragma("unroll") for (int t = 0; t < 2; ++t) { \
-        unsigned ph, pm, pl;                                                                     \
-        WB_CVT(ph, BA[q][t], BB[q][t])                                                           \
-        const float r0 = WB_RES(BA[q][t], ph, 0);                               /* exact */      \
-        const float r1 = WB_RES(BB[q][t], ph, 1);                                                \
-        WB_CVT(pm, r0, r1)                                                                       \
-        const float s0_ = WB_RES(r0, pm, 0);                                                     \
-        const float s1_ = WB_RES(r1, pm, 1);                                                     \
-        WB_CVT(pl, s0_, s1_)                                                                     \
-        Bp[0][q][t][J] = ph;                                                                     \
-        Bp[BF3 ? 1 : 0][q][t][J] = pm;                                                           \
-        Bp[BF3 ? 2 : 0][q][t][J] = pl;                                                           \
     }
 #define WB_MM(O, Q, T, PA, PB)                                                                   \
-    if (ABL != 7) acc[O][Q][T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AB[O][PA]), \
-                                                           __builtin_bit_cast(bf16x8, Bp[BF3 ? (PB) : 0][Q][T]), acc[O][Q][T], 0, 0, 0);
+    if (ABL != 7) acc[O][Q][T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, AB[O][PA]), \
+                                                          __builtin_bit_cast(f16x8, Bp[PB][Q][T]), acc[O][Q][T], 0, 0, 0);
 #define WB_TERM(Q, PA, PB) WB_MM(0, Q, 0, PA, PB) WB_MM(1, Q, 0, PA, PB) WB_MM(0, Q, 1, PA, PB) WB_MM(1, Q, 1, PA, PB)
     // one column: smallest terms first; four independent accumulators per term
 #define WB_Q(Q)                                                                                  \
     {                                                                                            \
-        u32x4 AB[OCT][3];                                                                        \
+        u32x4 AB[OCT][2];                                                                        \
         load_al(Q, AB);                                                                          \
         WB_QM(Q)                                                                                 \
     }
 #define WB_QM(Q)                                                                                 \
     {                                                                                            \
         if (ABL == 7) { _Pragma("unroll") for (int t = 0; t < 2; ++t) _Pragma("unroll") for (int e = 0; e < 4; ++e)  \
-            acc[0][Q][t][e] += __uint_as_float(Bp[0][Q][t][e] ^ Bp[BF3 ? 1 : 0][Q][t][e] ^ Bp[BF3 ? 2 : 0][Q][t][e] ^ AB[0][0][e] ^ AB[1][2][e]); } \
-        WB_TERM(Q, 2, 0) WB_TERM(Q, 1, 1) WB_TERM(Q, 0, 2) WB_TERM(Q, 1, 0) WB_TERM(Q, 0, 1) WB_TERM(Q, 0, 0) \
+            acc[0][Q][t][e] += __uint_as_float(Bp[0][Q][t][e] ^ Bp[1][Q][t][e] ^ AB[0][0][e] ^ AB[1][1][e]); } \
+        WB_TERM(Q, 1, 0) WB_TERM(Q, 0, 1) WB_TERM(Q, 0, 0)                                       \
     }
     // the row combination d_a +- d_b as one fused multiply-add with the wave's sign in a scalar register (exact: the
     // factor is +-1): ONE copy of the loop for all four xi rows, which leaves the instruction cache room for unrolling it
@@ -636,158 +666,86 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         BOP[2][2 * p + 1] = w[4] - w[3];                                                         \
         BOP[3][2 * p + 1] = w[3] - w[5];                                                         \
     }
-    // ABL 11: where a wave's time goes (s_memtime sums of wave 0: slot 6 = in the stage barriers, slot 7 = in the vmcnt waits)
-    long long t_bar = 0, t_vm = 0;
-    // Round 6: the two waves of a SIMD in ANTI-PHASE ("ping-pong").  A stage is a vector phase P1 (raw store, operand transform,
-    // LDS reads of the next stage, split) and a matrix phase P2 (the column's 24 instructions); with every wave in the same
-    // phase at the same time (rounds 4-5) the SIMD's vector issue and its matrix pipe were busy one after the other: loop
-    // 33.8 k cycles for 12.3 k of matrix work and ~9 k of vector issue.  tools/ubench/mfma_residual.hip ("pingpong"): a wave
-    // that issues only bf16 matrix instructions is not slowed by a partner issuing only vector instructions (350 vs 332 us),
-    // and the partner keeps ~55 % of its rate.  So the waves 4-7 (nh = 1; wave w and w + 4 share a SIMD) run ONE INTERVAL
-    // behind the waves 0-3: a barrier between P1 and P2, one extra barrier for the late half before the loop and one for the
-    // early half after it — the k-th s_barrier of every wave pairs up, whatever its address — and at any time one wave of a
-    // SIMD is in P1 while its partner is in P2.  One code stream, no branch inside the loop.
-    // Ring / slot hazards with the half-stage lag (X = waves 0-3, Y = 4-7; X runs P1(s), P2(s) in the intervals 2s, 2s + 1, Y
-    // in 2s + 1, 2s + 2): raw planes of stage s + 2 are stored at the start of P1(s) [X 2s, Y 2s + 1] and first read in P1(s
-    // + 1) [X 2s + 2]; the slot's last readers were in P1(s - 3).  A parts of column (s + 2) % 4 are fetched at the start of
-    // P1(s), confirmed by the issuing wave's vmcnt(0) at the end of P2(s) [Y: end of 2s + 2], read in P2(s + 2) [X 2s + 5];
-    // the slot's last readers were in P2(s - 2) [Y 2s - 2].  The tail keeps the cadence (three pseudo-stages).
-    // (ABL 14 = the in-phase schedule of rounds 4-5, measurement library.)
-    constexpr bool PP = BF3 && ABL != 13 && ABL != 14 && ABL != 10 && ABL != 11;
-    constexpr int PP_VM_P1 = ABL == 16 ? 0 : (ABL == 17 ? 1 : 2);      // fetches issued in the vector phase (A/B: ABL 16, 17)
-    constexpr int PP_VMOPS = (ABL == 18 ? 2 : 3) + (BLOCKED ? RAWB : RAW4);      // vector-memory instructions a wave issues per stage
-#define WB_BAR asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     // ABL 15: timeline of ONE stage (KB 2, J 1) per wave: trace[(workgroup * 8 + wave) * 8 + slot], slots: 0 before the stage's
-    // first barrier, 1 behind it, 2 staging issued, 3 transform + reads + split done, 4 behind the second barrier, 5 matrix
-    // instructions issued, 6 behind vmcnt(0)
+    // first barrier, 1 behind it, 2 raw planes stored, 3 transform + reads + split done, 4 behind the second barrier, 5 matrix
+    // instructions and fetches issued, 6 behind vmcnt(N)
 #define WB_STAMP(J, KB, SLOT) if (ABL == 15 && (KB) == 2 && (J) == 1 && trace && lane == 0) \
         trace[((size_t)blockIdx.x * 8 + wave) * 8 + (SLOT)] = (long long)__builtin_amdgcn_s_memtime();
 #define WB_STAGE(J, KB)                                                                          \
-    if constexpr (PP) {                                                                          \
+    {                                                                                            \
         /* P1, vector phase: raw store, operand transform, next stage's LDS reads, split, this column's A parts requested */ \
         WB_STAMP(J, KB, 0)                                                                       \
         asm volatile("s_barrier" ::: "memory");                                                  \
         WB_STAMP(J, KB, 1)                                                                       \
         store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
         W_FENCE                                                                                  \
-        if (ABL != 9 && PP_VM_P1 >= 1) load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]); \
-        W_FENCE                                                                                  \
         WB_STAMP(J, KB, 2)                                                                       \
         float ba[4][2 * NP], bb[4][2 * NP];                                                      \
-        u32x4 AB[OCT][3];                                                                        \
+        u32x4 AB[OCT][2];                                                                        \
         WB_XFORM(rd, ba)                               /* k-step 2s */                           \
         W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
-        W_FENCE                                                                                  \
-        if (ABL != 9 && PP_VM_P1 >= 2) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);    \
-        W_FENCE                                                                                  \
         WB_XFORM(rdb, bb)                              /* k-step 2s+1 */                         \
         W_READ(((J) + 1) & 3, 1, rdb)                                                            \
         WB_SPLIT(J, ba, bb)                                                                      \
-        if (ABL == 18) { load_al2(J, AB); } else load_al(J, AB);                                 \
+        load_al(J, AB);                                                                          \
         W_FENCE                                                                                  \
         WB_STAMP(J, KB, 3)                                                                       \
-        /* the raw stores are behind at least the 14 LDS reads above (LDS operations of a wave complete in order) */ \
-        if (ABL == 18) asm volatile("s_waitcnt lgkmcnt(12)\n\ts_barrier" ::: "memory");          \
-        else asm volatile("s_waitcnt lgkmcnt(14)\n\ts_barrier" ::: "memory");                    \
+        /* everything this wave fetched in the last matrix phase has arrived (no assumption on the order in which direct-to- \
+           LDS and register loads retire): the A parts of column (J + 1) % 4, read after the next stage's second barrier, and  \
+           the raw planes stored at the start of the next stage.  The raw stores above are behind at least the 12 LDS reads    \
+           (LDS operations of a wave complete in order). */                                    \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(12)\n\ts_barrier" ::: "memory");                \
         W_FENCE                                                                                  \
         WB_STAMP(J, KB, 4)                                                                       \
-        /* P2, matrix phase: the column's 24 instructions; this stage's fetches are issued in their shadow */ \
-        if (ABL != 18) { WB_TERM(J, 2, 0) }                                                      \
-        W_FENCE                                                                                  \
-        if (ABL != 9 && PP_VM_P1 < 1) load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]); \
-        W_FENCE                                                                                  \
-        if (ABL != 18) { WB_TERM(J, 1, 1) }                                                      \
-        W_FENCE                                                                                  \
-        /* slot (J + 2) % 4 was consumed two stages ago; its next use is two stages ahead */     \
-        if (ABL != 9 && PP_VM_P1 < 2) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);     \
-        W_FENCE                                                                                  \
-        if (ABL != 18) { WB_TERM(J, 0, 2) }                                                      \
-        W_FENCE                                                                                  \
-        if (ABL != 9) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 1);                     \
-        W_FENCE                                                                                  \
+        /* P2, matrix phase: the column's 12 instructions, this stage's fetches in their shadow (a full stage ahead of the    \
+           wait above); slot (J + 2) % 4 was consumed two stages ago, its next use is two stages ahead */ \
         WB_TERM(J, 1, 0)                                                                         \
         W_FENCE                                                                                  \
-        if (ABL != 9 && ABL != 18) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 2);        \
+        load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);                        \
+        dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);                                   \
         W_FENCE                                                                                  \
-        WB_TERM(J, 0, 1) WB_TERM(J, 0, 0)                                                        \
+        WB_TERM(J, 0, 1)                                                                         \
+        W_FENCE                                                                                  \
+        dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 1);                                   \
+        W_FENCE                                                                                  \
+        WB_TERM(J, 0, 0)                                                                         \
         W_FENCE                                                                                  \
         WB_STAMP(J, KB, 5)                                                                       \
-        /* everything older than this stage's fetches has arrived (loads retire in order): the A parts requested one stage  \
-           ago (read two stages after their request) and the raw planes stored at the start of the next stage */           \
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PP_VMOPS) : "memory");                         \
-        WB_STAMP(J, KB, 6)                                                                       \
-        W_FENCE                                                                                  \
-    } else {                                                                                     \
-        const long long tb0 = ABL == 11 ? (long long)__builtin_amdgcn_s_memtime() : 0;           \
-        __syncthreads();                                                                         \
-        if (ABL == 11) t_bar += (long long)__builtin_amdgcn_s_memtime() - tb0;                   \
-        store_raw(sm + (((J) + 2) & 3) * W_BUF, prs[(J) & 1]);                                   \
-        load_raw(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);                            \
-        W_FENCE                                                                                  \
-        /* slot (J + 2) % 4 was consumed two stages ago; its next use is two stages ahead */     \
-        if (ABL != 9) dma_slot(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0));                        \
-        W_FENCE                                                                                  \
-        float ba[4][2 * NP], bb[4][2 * NP];                                                      \
-        u32x4 AB[OCT][3];                                                                        \
-        if (ABL == 10) load_al(J, AB);                 /* A parts of the stage's column: early */ \
-        WB_XFORM(rd, ba)                               /* k-step 2s */                           \
-        W_READ(((J) + 1) & 3, 0, rd)                   /* k-step 2(s+1): next stage's buffer */  \
-        WB_XFORM(rdb, bb)                              /* k-step 2s+1 */                         \
-        W_READ(((J) + 1) & 3, 1, rdb)                                                            \
-        WB_SPLIT(J, ba, bb)                                                                      \
-        if (ABL == 10) WB_QM(J) else WB_Q(J)                                                     \
-        const long long tv0 = ABL == 11 ? (long long)__builtin_amdgcn_s_memtime() : 0;           \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     /* the A parts fetched in this stage are in LDS */        \
-        if (ABL == 11) t_vm += (long long)__builtin_amdgcn_s_memtime() - tv0;                    \
-        W_FENCE                                                                                  \
     }
 #define WB_BLOCK(KB) WB_STAGE(0, KB) WB_STAGE(1, KB) WB_STAGE(2, KB) WB_STAGE(3, KB)
 #define WB_LOOP                                                                                  \
     W_READ(0, 0, rd)                                                                             \
     W_READ(0, 1, rdb)                                                                            \
-    if (PP && nh == 1) asm volatile("s_barrier" ::: "memory");      /* the late half: one interval behind */ \
-    if (nkb == 4) {        /* C = 128 unrolled: no loop-carried register shuffle (160 moves per trip otherwise) */ \
+    if (nh == 1) asm volatile("s_barrier" ::: "memory");            /* the late half: one interval behind */ \
+    if (nkb == 4) {        /* C = 128 unrolled: no loop-carried register shuffle */              \
         WB_BLOCK(0) WB_BLOCK(1) WB_BLOCK(2) WB_BLOCK(3)                                          \
     } else if ((nkb & 1) == 0) {                     /* C = 64, 256, 512: two blocks per trip (half the shuffle) */ \
         for (int kb = 0; kb < nkb; kb += 2) { WB_BLOCK(kb) WB_BLOCK(kb + 1) }                    \
     } else {                                                                                     \
         for (int kb = 0; kb < nkb; ++kb) { WB_BLOCK(kb) }                                        \
     }                                                                                            \
-    /* the last, partial blocks of the columns 0..2 (zero weights where their stages do not exist) */ \
-    if (PP) {                                        /* three pseudo-stages in the loop's cadence */ \
-        asm volatile("s_barrier" ::: "memory");                                                  \
-        if (ABL != 9) dma_slot(2, nkb);                                                          \
-        asm volatile("s_barrier" ::: "memory");                                                  \
-        WB_Q(0)                                                                                  \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        /* the loop's last raw fetches (re-fetches of the last stage, never stored) have landed: their registers may die */ \
-        _Pragma("unroll") for (int j = 0; j < NRAW; ++j) asm volatile("" :: "v"(prs[0][j].x), "v"(prs[0][j].y), "v"(prs[0][j].z), "v"(prs[0][j].w), \
-                                                                        "v"(prs[1][j].x), "v"(prs[1][j].y), "v"(prs[1][j].z), "v"(prs[1][j].w)); \
-        asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                     \
-        WB_Q(1)                                                                                  \
-        asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                     \
-        WB_Q(2)                                                                                  \
-        if (nh == 0) asm volatile("s_barrier" ::: "memory");      /* the early half waits for the late one */ \
-    } else {                                                                                     \
-        __syncthreads();                                                                         \
-        if (ABL != 9) dma_slot(2, nkb);                                                          \
-        WB_Q(0)                                                                                  \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                         \
-        __syncthreads();                                                                         \
-        WB_Q(1)                                                                                  \
-        WB_Q(2)                                                                                  \
-    }
+    /* the last, partial blocks of the columns 0..2 (zero weights where their stages do not exist): three pseudo-stages  \
+       in the loop's cadence */                                                                  \
+    asm volatile("s_barrier" ::: "memory");                                                      \
+    dma_slot(2, nkb);                                                                            \
+    asm volatile("s_barrier" ::: "memory");                                                      \
+    WB_Q(0)                                                                                      \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                             \
+    /* the loop's last raw fetches (re-fetches of the last stage, never stored) have landed: their registers may die */ \
+    _Pragma("unroll") for (int j = 0; j < NRAW; ++j) asm volatile("" :: "v"(prs[0][j].x), "v"(prs[0][j].y), "v"(prs[0][j].z), "v"(prs[0][j].w), \
+                                                                    "v"(prs[1][j].x), "v"(prs[1][j].y), "v"(prs[1][j].z), "v"(prs[1][j].w)); \
+    asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                         \
+    WB_Q(1)                                                                                      \
+    asm volatile("s_barrier\n\ts_barrier" ::: "memory");                                         \
+    WB_Q(2)                                                                                      \
+    if (nh == 0) asm volatile("s_barrier" ::: "memory");            /* the early half waits for the late one */
     W_TRACE(1)
     if constexpr (BF3) {
-        static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL >= 7)), "BF3: two-tile workgroups of the 16 x 16 map only");
+        static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL == 7 || ABL == 12 || ABL == 15)), "BF3: two-tile workgroups only");
         {
             WB_LOOP
         }
         load_hwv();
-        if (ABL == 11 && trace && tid == 0) {
-            trace[(size_t)blockIdx.x * 8 + 6] = t_bar;
-            trace[(size_t)blockIdx.x * 8 + 7] = t_vm;
-        }
     } else if (xi == 1) {        // the xi-row 1 combination adds its two patch rows, the others subtract
         constexpr bool PLUS = true;
         W_LOOP
@@ -799,7 +757,6 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #undef WB_LOOP
 #undef WB_STAGE
 #undef WB_STAMP
-#undef WB_BAR
 #undef WB_BLOCK
 #undef WB_XFORM
 #undef WB_Q
@@ -807,7 +764,6 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 #undef WB_TERM
 #undef WB_MM
 #undef WB_SPLIT
-#undef WB_RES
 #undef WB_CVT
 #undef W_LOOP
 #undef W_FENCE
@@ -860,6 +816,15 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             y[t][0][b] = (x0[t] + x1[t]) + x2[t];
             y[t][1][b] = (x1[t] - x2[t]) - x3[t];
         }
+    }
+    if constexpr (BF3) {        // back from the scaled operands (two exact multiplications by powers of two)
+        const float inv_su = packed[(size_t)2 * C * C * 16 + (size_t)tiles * (nkb + 1) * 8192 + 1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) y[t][a][b] = (y[t][a][b] * inv_sv) * inv_su;
     }
 
     if constexpr (BLOCKED) {
@@ -970,29 +935,21 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
 
 // 16-channel tiles per workgroup of the 16 x 16 towers for N tracks (1 or 2)
 static int tower_tiles_per_workgroup(int N, int C) {
-    const int tiles = 2 * (C / 16);
-    // One or two 16-channel tiles per workgroup, whichever the dispatch-round arithmetic favours (kernel durations by
-    // start/stop events at C = 128, profiles/r04_tower_sweep.jsonl; round 2: r02_tower_forms_by_tracks.jsonl):
-    //   one tile (fp32)      : 16 workgroups per track, 2 per CU -> rounds of 512; 27 us per full round, ~15 us for a last
-    //                          round that leaves every workgroup a CU of its own (<= 256), 20 us when the WHOLE launch does;
-    //   two tiles (bf16 x 3) : 8 workgroups per track, 152 KB of LDS -> 1 per CU, rounds of 256; 3.8 + 19.8 us per round
-    //                          (fp32 form: 24.5 per full round, 22.5 for a partial one).
-    // e.g. <= 16 tracks: one tile (19.8 vs 23.3 us); 17..32: two (23.6 vs 29.3); 33..48: two (43.4 vs 44); 64: two (43.5
-    // vs 55); 100: two (82.9 vs 92.6).  The constants scale with C alike, so the comparison holds for other channel counts.
+    // Round 6: the two-tile split form (fp16 x 2 operands on the matrix pipe) for EVERY track count — it is the faster form
+    // everywhere (kernel durations by start / stop events at C = 128, measure/debug/tower_forms_by_tracks.py,
+    // profiles/r06_tower_forms_by_tracks.jsonl: 1 track 17.3 vs 18.5 us for the one-tile fp32 form, 16 tracks 18.9 vs 20.1,
+    // 30: 20.0 vs 29.5, 64: 36.7 vs 55.5, 100: 68.0 vs 92.9), and one form means that a track's logits no longer depend on how
+    // many other tracks the frame has (rounds 4-5: fp32 up to 16 tracks, three-part bf16 above).
     // SMOT_TOWER_OCT = 1 / 2 forces a form, SMOT_TOWER_BF3 = 0 the fp32 form of two tiles, in the measurement library.
-    const int np8 = ((N + 7) / 8) * 8;
-    const int w1 = np8 * tiles, w2 = np8 * (tiles / 2);
-    const float c1 = (w1 <= 256) ? 20.0f
-                                 : 27.0f * (float)(w1 / 512) + ((w1 % 512) == 0 ? 0.0f : ((w1 % 512) <= 256 ? 15.0f : 27.0f));
-    const float c2 = knobs().tower_bf3 != 0 ? 3.8f + 19.8f * (float)((w2 + 255) / 256)
-                                            : 24.5f * (float)(w2 / 256) + ((w2 % 256) == 0 ? 0.0f : 22.5f);
-    int oct = (c2 < c1) ? 2 : 1;
+    (void)N;
+    (void)C;
+    int oct = 2;
     if (knobs().tower_oct == 1 || knobs().tower_oct == 2) oct = knobs().tower_oct;
     return oct;
 }
 
 int launch_tower_wino(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg, float eps,
-                      float* part, unsigned* zero_words, hipStream_t st) {
+                      float* part, unsigned* zero_words, hipStream_t st, const float* plane_max) {
     const int tiles = 2 * (C / 16);
     const int oct = tower_tiles_per_workgroup(N, C);
     const bool bf3 = oct == 2 && knobs().tower_bf3 != 0;
@@ -1003,48 +960,33 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
                              : reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>);
 #ifdef SMOT_DEBUG
         if (bf3 && knobs().wino_abl == 7) fn = reinterpret_cast<const void*>(&tower_wino_kernel<7, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 8) fn = reinterpret_cast<const void*>(&tower_wino_kernel<8, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 11) fn = reinterpret_cast<const void*>(&tower_wino_kernel<11, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 13) fn = reinterpret_cast<const void*>(&tower_wino_kernel<13, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 14) fn = reinterpret_cast<const void*>(&tower_wino_kernel<14, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 16) fn = reinterpret_cast<const void*>(&tower_wino_kernel<16, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 17) fn = reinterpret_cast<const void*>(&tower_wino_kernel<17, 2, 0, true>);
-        if (bf3 && knobs().wino_abl == 18) fn = reinterpret_cast<const void*>(&tower_wino_kernel<18, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 12) fn = reinterpret_cast<const void*>(&tower_wino_kernel<12, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 15) fn = reinterpret_cast<const void*>(&tower_wino_kernel<15, 2, 0, true>);
 #endif
         const int rco = ensure_lds_optin(fn, smem, "predictor towers (winograd)");
         if (rco) return rco;
     }
     if (bf3) {
+        SMOT_REQUIRE(plane_max != nullptr, "predictor towers: the split form needs the response's plane maxima");
 #define WB_LAUNCH(A)                                                                                              \
     SMOT_LAUNCH((tower_wino_kernel<A, 2, 0, true>), dim3(grid), dim3(512), smem, st, resp, packed, P, N, C, cpg, eps, part, \
-                zero_words, g_trace)
+                zero_words, g_trace, plane_max)
 #ifdef SMOT_DEBUG
-        switch (knobs().wino_abl) {      // 7 = no matrix instructions, 8 = no operand split, 9 = A parts fetched once per block
-            case 7: WB_LAUNCH(7); break;
-            case 8: WB_LAUNCH(8); break;
-            case 9: WB_LAUNCH(9); break;
-            case 10: WB_LAUNCH(10); break;
-            case 11: WB_LAUNCH(11); break;
-            case 13: WB_LAUNCH(13); break;      // the vector-instruction split of rounds 4-5 (correct results)
-            case 16: WB_LAUNCH(16); break;
-            case 17: WB_LAUNCH(17); break;
-            case 18: WB_LAUNCH(18); break;      // timing of a two-part / three-product form (WRONG results)
+        switch (knobs().wino_abl) {
+            case 7: WB_LAUNCH(7); break;        // no matrix instructions (timing, WRONG results)
+            case 12: WB_LAUNCH(12); break;      // every stage fetches A block 0 (L2-hot; timing, WRONG results)
             case 15: WB_LAUNCH(15); break;      // one stage's timeline per wave (trace layout [workgroup][wave][8])
-            case 14: WB_LAUNCH(14); break;      // the in-phase schedule of rounds 4-5 with the round-6 split (correct results)
             default: WB_LAUNCH(0); break;
         }
 #else
         WB_LAUNCH(0);
 #endif
 #undef WB_LAUNCH
-        return check_launch("predictor towers (winograd, bf16 x 3)");
+        return check_launch("predictor towers (winograd, fp16 x 2)");
     }
 #define W_LAUNCH(A, O)                                                                                            \
     SMOT_LAUNCH((tower_wino_kernel<A, O>), dim3(grid), dim3(256 * O), smem, st, resp, packed, P, N, C, cpg, eps, part, \
-                zero_words, g_trace)
+                zero_words, g_trace, plane_max)
 #ifdef SMOT_DEBUG
     if (oct == 1) {
         switch (knobs().wino_abl) {          // timing ablations (wrong results): measurement library only
@@ -1092,7 +1034,7 @@ static int tower_blocks_tiles_per_workgroup(int N, int C) {
 
 // Convolution output of the two towers for a 29 x 29 response (blocked mode above): conv [N][2C][841].
 int launch_tower_wino_blocks(const float* resp, const float* packed, const TowerParams& P, int N, int C, int cpg,
-                             float* conv, unsigned* zero_words, hipStream_t st) {
+                             float* conv, unsigned* zero_words, hipStream_t st, const float* plane_max) {
     const int tiles = 2 * (C / 16);
     const int np8 = ((N + 7) / 8) * 8 * 4;
     const int oct = tower_blocks_tiles_per_workgroup(N, C);
@@ -1101,19 +1043,20 @@ int launch_tower_wino_blocks(const float* resp, const float* packed, const Tower
     if (oct == 2 && knobs().tower_bf3 != 0) {      // the three-part bf16 form of the main loop (BF3 above)
         const size_t smem3 = (size_t)(W_RING * W_BUF + W_A_FLOATS) * sizeof(float);
         const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 29, true>), smem3,
-                                         "predictor towers (winograd, 29x29 in blocks, bf16 x 3)");
+                                         "predictor towers (winograd, 29x29 in blocks, fp16 x 2)");
         if (rco) return rco;
+        SMOT_REQUIRE(plane_max != nullptr, "predictor towers: the split form needs the response's plane maxima");
         SMOT_LAUNCH((tower_wino_kernel<0, 2, 29, true>), dim3(grid), dim3(512), smem3, st, resp, packed, P, N, C, cpg, 0.0f, conv,
-                    zero_words, (long long*)nullptr);
+                    zero_words, (long long*)nullptr, plane_max);
     } else if (oct == 2) {
         const int rco = ensure_lds_optin(reinterpret_cast<const void*>(&tower_wino_kernel<0, 2, 29>), smem,
                                          "predictor towers (winograd, 29x29 in blocks)");
         if (rco) return rco;
         SMOT_LAUNCH((tower_wino_kernel<0, 2, 29>), dim3(grid), dim3(512), smem, st, resp, packed, P, N, C, cpg, 0.0f, conv,
-                    zero_words, (long long*)nullptr);
+                    zero_words, (long long*)nullptr, plane_max);
     } else {
         SMOT_LAUNCH((tower_wino_kernel<0, 1, 29>), dim3(grid), dim3(256), smem, st, resp, packed, P, N, C, cpg, 0.0f, conv,
-                    zero_words, (long long*)nullptr);
+                    zero_words, (long long*)nullptr, plane_max);
     }
     return check_launch("predictor towers (winograd, 29x29 in blocks)");
 }
@@ -1130,9 +1073,9 @@ extern "C" int smot_emm_tower_form(int N, int C, int Ho) {
 
 extern "C" long long smot_emm_tower_pack_floats(int C) {
     if (C <= 0 || C % 16 != 0) return 0;          // the packed path needs 16-channel tiles
-    // fp32 image 2 C^2 x 16, then (C % 32 == 0) the three-part bf16 image: C/32 + 1 rotated blocks of 12288 floats per
-    // 16-channel tile
-    return (long long)2 * C * C * 16 + ((C % 32 == 0) ? (long long)(2 * C / 16) * (C / 32 + 1) * 12288 : 0);
+    // fp32 image 2 C^2 x 16, then (C % 32 == 0) the two-part fp16 image: C/32 + 1 rotated blocks of 8192 floats per
+    // 16-channel tile, and a header of four words {largest |w| (bits), 2^-ku, 0, 0}
+    return (long long)2 * C * C * 16 + ((C % 32 == 0) ? (long long)(2 * C / 16) * (C / 32 + 1) * 8192 + 4 : 0);
 }
 
 extern "C" int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
@@ -1141,12 +1084,15 @@ extern "C" int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_to
     SMOT_REQUIRE(C > 0 && C % 16 == 0, "tower_pack: C=%d must be a multiple of 16", C);
     SMOT_REQUIRE(cls_tower_w && reg_tower_w && packed, "tower_pack: null pointer");
     SMOT_REQUIRE(((uintptr_t)packed & 15) == 0, "tower_pack: output must be 16-byte aligned");
+    unsigned* hdr = nullptr;
     if (C % 32 == 0) {
-        const hipError_t e = hipMemsetAsync(packed + (size_t)2 * C * C * 16, 0, (size_t)(2 * C / 16) * (C / 32 + 1) * 12288 * 4,
-                                            (hipStream_t)stream);
+        const size_t half_floats = (size_t)(2 * C / 16) * (C / 32 + 1) * 8192;
+        const hipError_t e = hipMemsetAsync(packed + (size_t)2 * C * C * 16, 0, (half_floats + 4) * 4, (hipStream_t)stream);
         SMOT_REQUIRE(e == hipSuccess, "tower_pack: memset failed: %s", hipGetErrorString(e));
+        hdr = reinterpret_cast<unsigned*>(packed + (size_t)2 * C * C * 16 + half_floats);
+        hipLaunchKernelGGL(tower_wmax_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, cls_tower_w, reg_tower_w, C * C * 9, hdr);
     }
     hipLaunchKernelGGL(tower_pack_kernel, dim3((2 * C * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls_tower_w,
-                       reg_tower_w, C, packed);
+                       reg_tower_w, C, packed, hdr);
     return check_launch("tower_pack");
 }

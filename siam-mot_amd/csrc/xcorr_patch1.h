@@ -19,9 +19,11 @@ constexpr int XP1_ZS = 16;
 // LEAN: no software prefetch of the next window / template row (one row buffer instead of two, two live template
 // rows instead of three): ~65 instead of ~90 VGPRs.  For callers that run six waves per SIMD (the fused pooling +
 // correlation kernel at three workgroups per CU), where other waves cover the LDS latency.  Same FMA order.
+// pmax != nullptr: the plane's largest |response| goes to pmax[plane] (NaN ignored, an infinite value kept) — the tower
+// kernel's split form scales a track's response by a power of two chosen from these (tower_wino.hip)
 template <int RX, int RZ, bool LEAN = false>
 __device__ __forceinline__ void xcorr_patch1_compute(const float* xs, const float* zs, int lane,
-                                                     float* __restrict__ out, int plane) {
+                                                     float* __restrict__ out, int plane, float* __restrict__ pmax = nullptr) {
     constexpr int HO = RX - RZ + 1;
     static_assert(HO == 16 && RZ == 15, "tiles a 16x16 response of a 15x15 template");
     constexpr int XS = XP1_XS, ZS = XP1_ZS;
@@ -89,6 +91,19 @@ __device__ __forceinline__ void xcorr_patch1_compute(const float* xs, const floa
     float* o = out + (size_t)plane * (HO * HO) + (2 * q) * HO + 2 * g;
     *reinterpret_cast<float2*>(o) = make_float2(acc[0][0], acc[0][1]);
     *reinterpret_cast<float2*>(o + HO) = make_float2(acc[1][0], acc[1][1]);
+    if (pmax != nullptr) {
+        // four DPP row rotations + four lane reads (no LDS crossbar trip): ~12 vector instructions per plane of ~1,300
+        float m = fmaxf(fmaxf(fabsf(acc[0][0]), fabsf(acc[0][1])), fmaxf(fabsf(acc[1][0]), fabsf(acc[1][1])));
+#define SMOT_ROR(N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x120 + (N), 0xf, 0xf, false))
+        m = fmaxf(m, SMOT_ROR(8));
+        m = fmaxf(m, SMOT_ROR(4));
+        m = fmaxf(m, SMOT_ROR(2));
+        m = fmaxf(m, SMOT_ROR(1));
+#undef SMOT_ROR
+        const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 16));
+        const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 48));
+        if (lane == 0) pmax[plane] = fmaxf(fmaxf(a, b), fmaxf(c, d));
+    }
 }
 
 }  // namespace smot

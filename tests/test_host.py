@@ -92,12 +92,14 @@ def test_argument_errors_are_reported_without_a_device():
     assert rc == -1
     rc = lib.smot_emm_predictor_fwd(null, 1, 100, 16, *([null] * 12), 32, 1e-5, null, null, null, null)
     assert rc == -1 and b"divisible" in lib.smot_last_error()
-    # fp32 image + (C % 32 == 0) the three-part bf16 image: C/32 + 1 rotated blocks of 12288 floats per 16-channel tile
-    assert lib.smot_emm_tower_pack_floats(128) == 2 * 128 * 128 * 16 + 16 * 5 * 12288
+    # fp32 image + (C % 32 == 0) the two-part fp16 image: C/32 + 1 rotated blocks of 8192 floats per 16-channel tile + a
+    # four-word header (largest |w|, the scale's inverse)
+    assert lib.smot_emm_tower_pack_floats(128) == 2 * 128 * 128 * 16 + 16 * 5 * 8192 + 4
     assert lib.smot_emm_tower_pack_floats(48) == 2 * 48 * 48 * 16 and lib.smot_emm_tower_pack_floats(100) == 0
-    # which form of the towers a track count gets (host-side arithmetic): <= 16 tracks one fp32 tile per workgroup, above
-    # that two tiles on three-part bf16 operands; no packed path for channel counts that are not powers of two
-    assert [lib.smot_emm_tower_form(n, 128, 16) for n in (1, 16, 17, 30, 100)] == [1, 1, 3, 3, 3]
+    # which form of the towers a track count gets (host-side arithmetic): since round 6 two tiles per workgroup on two-part
+    # fp16 operands at every track count (one form: a track's logits do not depend on how many tracks the frame has); no
+    # packed path for channel counts that are not powers of two
+    assert [lib.smot_emm_tower_form(n, 128, 16) for n in (1, 16, 17, 30, 100)] == [3, 3, 3, 3, 3]
     assert lib.smot_emm_tower_form(30, 96, 16) == 0 and lib.smot_emm_tower_form(30, 128, 15) == 0
     assert lib.smot_emm_tower_form(30, 128, 29) == 3
     assert lib.smot_emm_tower_pack(null, null, 100, null, null) == -1
