@@ -30,6 +30,7 @@
 //               GroupNorm + affine + ReLU, fused partial heads exactly as in predictor.hip.
 #include "tower_common.h"
 #include "knobs.h"
+#include <utility>
 
 namespace smot {
 
@@ -149,6 +150,16 @@ plane_absmax_kernel(const float* __restrict__ resp, int planes, int hw, float* _
 int launch_plane_absmax(const float* resp, int planes, int hw, float* pm, hipStream_t st) {
     hipLaunchKernelGGL(plane_absmax_kernel, dim3((planes + 3) / 4), dim3(256), 0, st, resp, planes, hw, pm);
     return check_launch("predictor towers (plane maxima)");
+}
+
+// 36 head taps (four channels) of channel group G on two alternating accumulators: tap E of the group is tap G * 36 + E of
+// the tile, its four weights = block (G * 36 + E) % 16 of weight register (G * 36 + E) / 16 (the instruction's A-broadcast
+// field must be a constant: hence the index sequence)
+template <int G, int... E>
+__device__ __forceinline__ void heads_group(const float (&hw)[9], const float (&a)[36], f32x4& h0, f32x4& h1,
+                                            std::integer_sequence<int, E...>) {
+    (((E % 2 == 0 ? h0 : h1) = __builtin_amdgcn_mfma_f32_4x4x1f32(hw[(G * 36 + E) / 16], a[E], (E % 2 == 0 ? h0 : h1), 4,
+                                                                  (G * 36 + E) % 16, 0)), ...);
 }
 
 // ABL (timing ablations for profiles/, wrong results): 1 = no raw staging inside the loop, 2 = no A-operand
@@ -401,17 +412,14 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             aset[1][1][o] = aset[0][1][o];
         }
     }
-    if constexpr (BF3) {
-        float m = 0.0f;
-        for (int c = lane; c < C; c += 64) m = fmaxf(m, plane_max[(size_t)n * C + c]);
-        m = plane_max_wave(m);
-        const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);      // m < 2^(e - 126)
-        if (e != 0 && e != 255) {
-            int k = 139 - e;
-            k = k < -100 ? -100 : (k > 100 ? 100 : k);
-            sv = __uint_as_float((unsigned)(127 + k) << 23);
-            inv_sv = __uint_as_float((unsigned)(127 - k) << 23);
-        }
+    // BF3: the plane maxima are requested here, beside the first fetches, and reduced BEHIND the zero fill (reduced here,
+    // their wait would also wait for the fetches above and push the fill behind a cold memory round trip: +1.3 us)
+    float pmv[2] = {0.0f, 0.0f};
+    if constexpr (BF3 && ABL != 10) {
+        const float* __restrict__ pmsrc = plane_max + (size_t)n * C;
+        if (lane < C) pmv[0] = pmsrc[lane];
+        if (lane + 64 < C) pmv[1] = pmsrc[lane + 64];
+        __builtin_amdgcn_sched_barrier(0);
     }
     // (first global loads are in flight: their latency covers the fill and the weight fetch)
     {   // zero the stage buffers once: the halos stay zero for the whole main loop (a halo-only fill was measured
@@ -434,6 +442,18 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
         for (int r = 0; r < 9; ++r) hwv[r] = live ? wsrc[r * 16] : 0.0f;
     };
     if constexpr (!BF3) load_hwv();          // BF3: after the main loop (nine registers the loop needs)
+    if constexpr (BF3 && ABL != 10) {
+        float m = fmaxf(pmv[0], pmv[1]);
+        for (int c = lane + 128; c < C; c += 64) m = fmaxf(m, plane_max[(size_t)n * C + c]);
+        m = plane_max_wave(m);
+        const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);      // m < 2^(e - 126)
+        if (e != 0 && e != 255) {
+            int k = 139 - e;
+            k = k < -100 ? -100 : (k > 100 ? 100 : k);
+            sv = __uint_as_float((unsigned)(127 + k) << 23);
+            inv_sv = __uint_as_float((unsigned)(127 - k) << 23);
+        }
+    }
 
     __syncthreads();                       // zero fill complete before interior writes
     // BF3: the first A parts are in LDS (the first raw planes are needed here anyway; waiting BEFORE the next fetches are
@@ -443,6 +463,13 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     store_raw(sm + W_BUF, prs[1]);
     load_raw(min(2, nstages - 1), prs[0]);
     load_raw(min(3, nstages - 1), prs[1]);
+    // GroupNorm's affine parameters of the thread's epilogue channel: requested here (two registers through the loop);
+    // fetched where they are used, their cold round trip stood in the epilogue (the barrier behind the exchange drains vmcnt)
+    float ga = 0.0f, be = 0.0f;
+    if constexpr (!BLOCKED) {
+        ga = P.gamma[tower][oc0 + (ltid >> 4)];
+        be = P.beta[tower][oc0 + (ltid >> 4)];
+    }
     __syncthreads();
 
     // rows of the 4x4 patch this wave's xi-row combines:  i=0: d0-d2, 1: d1+d2, 2: d2-d1, 3: d1-d3
@@ -701,12 +728,12 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
            wait above); slot (J + 2) % 4 was consumed two stages ago, its next use is two stages ahead */ \
         WB_TERM(J, 1, 0)                                                                         \
         W_FENCE                                                                                  \
-        load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);                        \
-        dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);                                   \
+        if (ABL != 9) load_raw_asm(min(4 * (KB) + (J) + 4, nstages - 1), prs[(J) & 1]);          \
+        if (ABL != 9) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 0);                     \
         W_FENCE                                                                                  \
         WB_TERM(J, 0, 1)                                                                         \
         W_FENCE                                                                                  \
-        dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 1);                                   \
+        if (ABL != 9) dma_part(((J) + 2) & 3, (KB) + ((J) >= 2 ? 1 : 0), 1);                     \
         W_FENCE                                                                                  \
         WB_TERM(J, 0, 0)                                                                         \
         W_FENCE                                                                                  \
@@ -741,7 +768,7 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     if (nh == 0) asm volatile("s_barrier" ::: "memory");            /* the early half waits for the late one */
     W_TRACE(1)
     if constexpr (BF3) {
-        static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL == 7 || ABL == 12 || ABL == 15)), "BF3: two-tile workgroups only");
+        static_assert(!BF3 || (OCT == 2 && (ABL == 0 || ABL == 7 || ABL == 9 || ABL == 10 || ABL == 12 || ABL == 15)), "BF3: two-tile workgroups only");
         {
             WB_LOOP
         }
@@ -856,7 +883,9 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     if (cpg == 4) {
         // a group = 4 channels = the four 16-lane rows of THIS wave: no LDS, no barrier; rows are added in channel
         // order, as the general path below does
-        mean = (((0.0f + __shfl(s, 0)) + __shfl(s, 16)) + __shfl(s, 32)) + __shfl(s, 48);
+        // (v_readlane at wave-uniform lanes, not __shfl: that is ds_bpermute — four dependent LDS round trips per sum)
+#define W_RL(V, L) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(V), (L)))
+        mean = (((0.0f + W_RL(s, 0)) + W_RL(s, 16)) + W_RL(s, 32)) + W_RL(s, 48);
     } else {
         if (x16 == 0) chs[ocl] = s;
         __syncthreads();
@@ -875,14 +904,14 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
             }
     sq = group16_sum(sq);
     if (cpg == 4) {
-        var = (((0.0f + __shfl(sq, 0)) + __shfl(sq, 16)) + __shfl(sq, 32)) + __shfl(sq, 48);
+        var = (((0.0f + W_RL(sq, 0)) + W_RL(sq, 16)) + W_RL(sq, 32)) + W_RL(sq, 48);
+#undef W_RL
     } else {
         if (x16 == 0) chs[16 + ocl] = sq;
         __syncthreads();
         for (int ch = g0; ch < g0 + cpg; ++ch) var += chs[16 + ch];
     }
     const float rstd = 1.0f / sqrtf(var * inv_cnt + eps);
-    const float ga = P.gamma[tower][oc0 + ocl], be = P.beta[tower][oc0 + ocl];
     {
         float* pl = planes + ocl * T_PLANE;
 #pragma unroll
@@ -908,22 +937,42 @@ tower_wino_kernel(const float* __restrict__ resp, const float* __restrict__ pack
     // layout the stores below need.  256 MACs per 8-cycle instruction, one LDS read (the activation) per tap, all
     // 144 offsets immediates.  One fmaf chain per output in (channel, tap) order, as in predictor.hip.
     {
-        const int py = ltid >> 4, px = ltid & 15;
-        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f};
+        // position of a thread: the two 16-lane halves of a ds_read_b32 lane group read rows r and r + 8 — 144 floats = 16
+        // banks apart, conflict-free; rows r and r + 1 (the linear order) are 18 floats apart and collide on two banks, which
+        // doubled the LDS cycles of all 1,152 reads of this phase (heads 4.7 k -> 3.x k cycles per workgroup)
+        const int py = ((ltid >> 6) << 1) + ((ltid >> 5) & 1) + (((ltid >> 4) & 1) << 3), px = ltid & 15;
         const float* pl0 = planes + py * 18 + px;
-#define W_HEAD(ID)                                                                                          \
-    hacc = __builtin_amdgcn_mfma_f32_4x4x1f32(hwv[(ID) / 16], pl0[((ID) / 9) * T_PLANE + (((ID) % 9) / 3) * 18 + ((ID) % 9) % 3], \
-                                              hacc, 4, (ID) % 16, 0);
-#define W_HEAD16(R)                                                                                         \
-    W_HEAD((R) * 16 + 0) W_HEAD((R) * 16 + 1) W_HEAD((R) * 16 + 2) W_HEAD((R) * 16 + 3) W_HEAD((R) * 16 + 4)   \
-    W_HEAD((R) * 16 + 5) W_HEAD((R) * 16 + 6) W_HEAD((R) * 16 + 7) W_HEAD((R) * 16 + 8) W_HEAD((R) * 16 + 9)   \
-    W_HEAD((R) * 16 + 10) W_HEAD((R) * 16 + 11) W_HEAD((R) * 16 + 12) W_HEAD((R) * 16 + 13)                  \
-    W_HEAD((R) * 16 + 14) W_HEAD((R) * 16 + 15)
-        W_HEAD16(0) W_HEAD16(1) W_HEAD16(2) W_HEAD16(3) W_HEAD16(4) W_HEAD16(5) W_HEAD16(6) W_HEAD16(7) W_HEAD16(8)
-#undef W_HEAD16
-#undef W_HEAD
-        // (two accumulation chains instead of one were measured: 4.70 k against 4.76 k cycles — not latency-bound)
-        float* __restrict__ dst = part + ((size_t)n * tiles + etile) * 4 * 256 + ltid;
+        // Activations of FOUR channels (36 taps) are requested one group ahead of the 36 instructions that consume them
+        // (hipcc otherwise issues a read a few instructions before its use and the phase waits on LDS latency), and the
+        // taps alternate between two accumulators (even / odd tap index: a dependent 4x4x1 instruction needs two wait states
+        // behind its predecessor), added at the end.
+        f32x4 hacc = {0.0f, 0.0f, 0.0f, 0.0f}, hacc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        float av[2][36];
+#define W_HLOAD(G, BUF) _Pragma("unroll") for (int e = 0; e < 36; ++e)                                        \
+        av[BUF][e] = pl0[((G) * 4 + e / 9) * T_PLANE + ((e % 9) / 3) * 18 + (e % 9) % 3];
+#define W_HMM(G, BUF) heads_group<G>(hwv, av[BUF], hacc, hacc1, std::make_integer_sequence<int, 36>{});
+        W_HLOAD(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HLOAD(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HMM(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HLOAD(2, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HMM(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HLOAD(3, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HMM(2, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        W_HMM(3, 1)
+#undef W_HMM
+#undef W_HLOAD
+        hacc[0] += hacc1[0];
+        hacc[1] += hacc1[1];
+        hacc[2] += hacc1[2];
+        hacc[3] += hacc1[3];
+        float* __restrict__ dst = part + ((size_t)n * tiles + etile) * 4 * 256 + py * 16 + px;
         dst[0 * 256] = hacc[0];
         dst[1 * 256] = hacc[1];
         dst[2 * 256] = hacc[2];
@@ -960,6 +1009,8 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
                              : reinterpret_cast<const void*>(&tower_wino_kernel<0, 2>);
 #ifdef SMOT_DEBUG
         if (bf3 && knobs().wino_abl == 7) fn = reinterpret_cast<const void*>(&tower_wino_kernel<7, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 9) fn = reinterpret_cast<const void*>(&tower_wino_kernel<9, 2, 0, true>);
+        if (bf3 && knobs().wino_abl == 10) fn = reinterpret_cast<const void*>(&tower_wino_kernel<10, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 12) fn = reinterpret_cast<const void*>(&tower_wino_kernel<12, 2, 0, true>);
         if (bf3 && knobs().wino_abl == 15) fn = reinterpret_cast<const void*>(&tower_wino_kernel<15, 2, 0, true>);
 #endif
@@ -974,6 +1025,8 @@ int launch_tower_wino(const float* resp, const float* packed, const TowerParams&
 #ifdef SMOT_DEBUG
         switch (knobs().wino_abl) {
             case 7: WB_LAUNCH(7); break;        // no matrix instructions (timing, WRONG results)
+            case 9: WB_LAUNCH(9); break;
+            case 10: WB_LAUNCH(10); break;
             case 12: WB_LAUNCH(12); break;      // every stage fetches A block 0 (L2-hot; timing, WRONG results)
             case 15: WB_LAUNCH(15); break;      // one stage's timeline per wave (trace layout [workgroup][wave][8])
             default: WB_LAUNCH(0); break;
