@@ -22,7 +22,7 @@ from torch import nn
 
 from . import ops
 from .registry import SIAMESE_TRACKER
-from .structures import cat
+from .structures import BoxList as _OwnBoxList, cat
 
 
 class SRPooler(nn.Module):
@@ -176,15 +176,50 @@ class EMM(nn.Module):
         params, scales, sampling_ratio, gn_groups, gn_eps = st
         # one library call: pooling -> xcorr -> predictor -> decode (+ the clamp of clip_to_image)
         one = len(sr) == 1
+        b0 = boxes[0]
+        boxes_bbox = b0.bbox
         sr_bbox = sr[0].bbox if one else cat([b.bbox for b in sr], dim=0)
-        hint = OrderHint.lookup(sr[0], boxes[0].bbox, sr_bbox, scales) if one else None
-        bb, bb_conf = ops.emm_track(features, boxes[0].bbox, sr_bbox,
-                                    template_features, params, self.rx, self.rz, scales, sampling_ratio,
-                                    self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
-                                    clip_wh=None if self.amodal else boxes[0].size,
-                                    gn_groups=gn_groups, gn_eps=gn_eps, order_hint=hint)
-        track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
+        hint = OrderHint.lookup(sr[0], boxes_bbox, sr_bbox, scales) if one else None
+        out = None
+        plan = self._pair_plan(features, boxes_bbox, params, scales, sampling_ratio)
+        if plan is not None:
+            size = b0.size
+            out = plan.track(features, boxes_bbox, sr_bbox, template_features, self.sigma, self.use_centerness,
+                             0.0 if self.amodal else float(size[0]), 0.0 if self.amodal else float(size[1]), gn_groups,
+                             gn_eps, hint)
+        if out is None:                  # anything the plan does not recognise: the general binding (raises or converts)
+            out = ops.emm_track(features, boxes_bbox, sr_bbox,
+                                template_features, params, self.rx, self.rz, scales, sampling_ratio,
+                                self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
+                                clip_wh=None if self.amodal else b0.size,
+                                gn_groups=gn_groups, gn_eps=gn_eps, order_hint=hint)
+        bb, bb_conf = out
+        if b0.__class__ is _OwnBoxList and len(b0) == bb.shape[0]:
+            # (this package's container: no re-validation of a tensor the library just wrote; boxes already clamped)
+            f = b0.extra_fields
+            track_result = [_OwnBoxList._wrap(bb, b0.size, "xyxy", {"ids": f["ids"], "labels": f["labels"], "scores": bb_conf})]
+        else:
+            track_result = wrap_results_to_boxlist(bb, bb_conf, boxes, amodal=True)   # already clamped
         return {}, track_result, {}
+
+    def _pair_plan(self, features, boxes_bbox, params, scales, sampling_ratio):
+        """The cached host plan of this module's two per-frame calls (``ops.PairPlan``), made on first use and again when a
+        configuration value, the parameter dict, the library or the device changed; None when the inputs are not plain
+        device tensors (the general binding then raises or converts)."""
+        plan = self.__dict__.get("_plan")
+        tu = self.track_utils
+        if plan is not None and plan.dev == boxes_bbox.device and not plan.stale(params, self.rx, self.rz, scales,
+                                                                                 sampling_ratio, self.pad_pixels, tu):
+            return plan
+        if not (isinstance(boxes_bbox, torch.Tensor) and boxes_bbox.is_cuda and self.rx - self.rz + 1 in (16, 29)):
+            return None
+        try:
+            plan = ops.PairPlan(features, boxes_bbox.device, params, self.rx, self.rz, scales, sampling_ratio,
+                                self.pad_pixels, tu)
+        except (RuntimeError, IndexError, TypeError, AttributeError):
+            return None                  # the general binding reports what is wrong with the inputs
+        self.__dict__["_plan"] = plan
+        return plan
 
     def track_raw(self, features, boxes, sr, template_features, image_wh, sr_boxlist=None):
         """The inference branch of ``forward`` on raw tensors: template boxes ``[N,4]``, search regions ``[N,4]``,
@@ -216,12 +251,18 @@ class EMM(nn.Module):
 
     def extract_cache(self, features, detection):
         """(template features, [search regions], [detections]) — track_core.py:81-98."""
-        detection = [detection]
+        det = detection
         tu = self.track_utils
-        det = detection[0]
         sz = self._template_pooler()
-        r = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
-                                  tu.min_search_wh, hint=self.use_order_hint)
+        r = None
+        st = self.__dict__.get("_static")
+        if st is not None and sz[0] == st[1] and sz[1] == st[2] and isinstance(det.bbox, torch.Tensor):
+            plan = self._pair_plan(features, det.bbox, st[0], st[1], st[2])
+            if plan is not None:
+                r = plan.extract(features, det.bbox, self.use_order_hint)
+        if r is None:
+            r = ops.emm_extract_cache(features, det.bbox, self.rz, sz[0], sz[1], tu.pad_pixels, tu.search_expansion,
+                                      tu.min_search_wh, hint=self.use_order_hint)
         return self.wrap_cache(r[0], r[1], det, r[2] if len(r) > 2 else None)
 
     def wrap_cache(self, x, sr_bbox, det, hint=None):
@@ -229,9 +270,13 @@ class EMM(nn.Module):
         hint the extraction wrote for exactly these rows (``[len(det), HINT_FLOATS]``) or None."""
         tu = self.track_utils
         w, h = det.size
-        sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
-        for field in det.fields():
-            sr.add_field(field, det.get_field(field))
+        if det.__class__ is _OwnBoxList:       # (this package's container: no re-validation of the library's own output)
+            sr = _OwnBoxList._wrap(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], "xyxy",
+                                   dict(det.extra_fields))
+        else:
+            sr = det.__class__(sr_bbox, [int(w + tu.pad_pixels * 2), int(h + tu.pad_pixels * 2)], mode="xyxy")
+            for field in det.fields():
+                sr.add_field(field, det.get_field(field))
         if hint is not None:
             sr.order_hint = OrderHint(hint, det.bbox, sr_bbox, self._template_pooler()[0])
         return x, [sr], [det]

@@ -724,6 +724,115 @@ def emm_extract_cache(features, boxes, rz, scales, sampling_ratio, pad_pixels, s
     return (templates, sr, oh) if hint else (templates, sr)
 
 
+try:
+    _cur_device = torch._C._cuda_getDevice                    # current device index, ~0.1 us (torch.cuda.current_device: ~0.7)
+except AttributeError:                                        # pragma: no cover - older torch
+    _cur_device = torch.cuda.current_device
+
+
+class PairPlan(object):
+    """The host side of ``EMM.forward`` / ``EMM.extract_cache`` for a caller that makes the same two calls every frame
+    (round 6): what ``emm_track`` / ``emm_extract_cache`` look up, validate and convert on every call —
+    the level geometry, the parameter block, the workspace, the Hann window, the hint's size, two dozen scalar arguments —
+    is resolved ONCE per (feature shapes, scales, device, shape family) and kept as the constant part of the library
+    call's argument tuple; a call then checks what can change between frames (the five feature tensors: shape, dtype,
+    layout, device -> their pointers; the box / search-region / template tensors; the parameter tensors' storage and
+    version), allocates its outputs and makes the ONE library call.  ``track`` / ``extract`` return None for anything they
+    do not recognise (another geometry, a strided tensor, another device, a count the plan was not made for is re-planned):
+    the caller then takes the general functions above, which raise or convert.  Results are the general functions', bit
+    for bit — same library entry points, same arguments.  There is still no CPU or eager path."""
+    __slots__ = ("dev", "dev_index", "g", "gz", "params", "blk", "rx", "rz", "ho", "scales", "sampling_ratio", "pad_pixels",
+                 "hann_ptr", "ws", "ws_n", "C", "hint_n", "hint_ok", "lib", "f_track", "f_extract", "tu")
+
+    def __init__(self, features, dev, params, rx, rz, scales, sampling_ratio, pad_pixels, tu):
+        self.lib = lib = _lib or load_library()
+        self.dev, self.dev_index = dev, dev.index
+        self.g = _geometry(features, scales, pad_pixels, dev)           # full validation (raises)
+        self.gz = _geometry(features, scales, 0, dev)
+        self.params, self.blk = params, _param_block(params)
+        self.rx, self.rz, self.ho = rx, rz, rx - rz + 1
+        self.scales, self.sampling_ratio, self.pad_pixels = scales, sampling_ratio, pad_pixels
+        self.C = self.g.C
+        if self.blk.C != self.C:
+            raise RuntimeError("siammot_amd.emm_track: predictor has %d channels, features have %d" % (self.blk.C, self.C))
+        self.hann_ptr = hann_window(self.ho * UP_SCALE, dev).data_ptr()
+        self.ws, self.ws_n = None, -1
+        self.hint_n, self.hint_ok = -1, False
+        self.f_track, self.f_extract = lib.smot_emm_track_fwd, lib.smot_emm_extract_cache_fwd
+        self.tu = (float(tu.pad_pixels), float(tu.search_expansion), float(tu.min_search_wh))
+
+    def stale(self, params, rx, rz, scales, sampling_ratio, pad_pixels, tu):
+        return (params is not self.params or rx != self.rx or rz != self.rz or scales != self.scales or
+                sampling_ratio != self.sampling_ratio or pad_pixels != self.pad_pixels or self.lib is not _lib or
+                self.tu != (float(tu.pad_pixels), float(tu.search_expansion), float(tu.min_search_wh)))
+
+    def track(self, features, boxes, sr, templates, sigma, use_centerness, clip_w, clip_h, gn_groups, gn_eps, order_hint):
+        """``emm_track`` (winograd path, no index output): (bb ``[N,4]``, conf ``[N]``) or None."""
+        dev, g, rz = self.dev, self.g, self.rz
+        if not (boxes.is_cuda and boxes.dtype is _F32 and boxes.is_contiguous() and boxes.device == dev and boxes.dim() == 2):
+            return None
+        N = boxes.shape[0]
+        if not (sr.is_cuda and sr.dtype is _F32 and sr.is_contiguous() and sr.shape == boxes.shape and boxes.shape[1] == 4 and
+                templates.is_cuda and templates.dtype is _F32 and templates.is_contiguous() and
+                templates.shape == (N, self.C, rz, rz) and sr.get_device() == self.dev_index and
+                templates.get_device() == self.dev_index and _cur_device() == self.dev_index):
+            return None
+        if not _geometry_refresh(g, features, dev):
+            return None
+        blk = self.blk.current()
+        if blk.packed is None or blk.tensors[0].get_device() != self.dev_index or blk.C != self.C:
+            return None
+        stream = _raw_stream(self.dev_index)
+        if N != self.ws_n or self.ws is None or self.ws is not _ws_cache.get((dev, stream)):
+            self.ws = _workspace(dev, self.lib.smot_emm_track_ws_floats(N, self.C, self.rx, rz), stream)
+            self.ws_n = N
+        bb = torch.empty((N, 4), dtype=_F32, device=dev)
+        conf = torch.empty((N,), dtype=_F32, device=dev)
+        hint_ptr = None
+        if order_hint is not None:
+            if (order_hint.shape != (N, HINT_FLOATS) or order_hint.get_device() != self.dev_index or
+                    order_hint.dtype is not _F32 or not order_hint.is_contiguous()):
+                return None
+            hint_ptr = order_hint.data_ptr()
+        elif self.rx == 30 and rz == 15 and 2 <= N <= 256:
+            FALLBACKS["unhinted_head"] += 1
+        rc = self.f_track(g.a_fp, g.a_hs, g.a_ws, g.a_pc, g.a_sc, g.L, self.C, boxes.data_ptr(), sr.data_ptr(),
+                          templates.data_ptr(), N, self.rx, rz, self.sampling_ratio, blk.a_pp, gn_groups, gn_eps,
+                          self.hann_ptr, UP_SCALE, self.pad_pixels, 1 - sigma, sigma, 1 if use_centerness else 0, clip_w,
+                          clip_h, self.ws.data_ptr(), bb.data_ptr(), conf.data_ptr(), None, hint_ptr, stream)
+        if rc:
+            _check(rc, "emm_track")
+        return bb, conf
+
+    def extract(self, features, boxes, hint):
+        """``emm_extract_cache`` (un-masked form): (templates, sr, order hint or None) or None."""
+        dev, g, rz = self.dev, self.gz, self.rz
+        if not (boxes.is_cuda and boxes.dtype is _F32 and boxes.is_contiguous() and boxes.device == dev and
+                boxes.dim() == 2 and boxes.shape[1] == 4 and _cur_device() == self.dev_index):
+            return None
+        if not _geometry_refresh(g, features, dev):
+            return None
+        N = boxes.shape[0]
+        templates = torch.empty((N, self.C, rz, rz), dtype=_F32, device=dev)
+        oh = None
+        if hint:
+            if N != self.hint_n:
+                self.hint_n, self.hint_ok = N, order_hint_floats(N, rz, self.sampling_ratio) > 0
+            if self.hint_ok and boxes.data_ptr() % 16 == 0:
+                both = torch.empty((N * (HINT_FLOATS + 4),), dtype=_F32, device=dev)       # one allocation: hint | sr
+                oh = both[:N * HINT_FLOATS].view(N, HINT_FLOATS)
+                sr = both[N * HINT_FLOATS:].view(N, 4)
+        if oh is None:
+            sr = torch.empty((N, 4), dtype=_F32, device=dev)
+        tu = self.tu
+        rc = self.f_extract(g.a_fp, g.a_hs, g.a_ws, g.a_sc, g.L, self.C, boxes.data_ptr(), N, rz, self.sampling_ratio,
+                            tu[0], tu[1], tu[2], templates.data_ptr(), sr.data_ptr(),
+                            oh.data_ptr() if oh is not None else None, _raw_stream(self.dev_index))
+        if rc:
+            _check(rc, "emm_extract_cache")
+        return templates, sr, oh
+
+
 TIMER_XCORR, TIMER_TOWER = 0, 1
 
 
