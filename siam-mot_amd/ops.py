@@ -1328,11 +1328,17 @@ class FrameArgs(object):
         self._II.pack_into(self._buf, self._INT0, n_trk, STAGE_HEAD)
         self._Q.pack_into(self._buf, self._HINT_OFF, hint_ptr)
 
-    def poke_rest(self, ptrs, stages, n_det, thresholds, carry=(0, 0, 0)):
+    def poke_rest(self, ptrs, stages, n_det, thresholds, carry=(0, 0, 0), n_trk=None):
         """Rewrite the per-frame pointers behind the head's (``refine_ws`` .. ``carry_scores``), ``stages``,
-        ``n_det``, the three solver thresholds and ``carry`` = (carry_src_row0, carry_rows, carry_dst_row0)."""
+        ``n_det``, the three solver thresholds and ``carry`` = (carry_src_row0, carry_rows, carry_dst_row0).
+        ``n_trk``: the row count of THIS call's propagated tracks — written here too, because the head range may have been
+        poked on a guess for a head that never ran (a frame that leaves no track is followed by a call without
+        a head; with the guessed count still in the block the solver read one row too many)."""
         self._REST_FMT.pack_into(self._buf, 8 * self._HEAD1, *ptrs)
-        self._II.pack_into(self._buf, self._INT0 + 4, stages, n_det)
+        if n_trk is None:
+            self._II.pack_into(self._buf, self._INT0 + 4, stages, n_det)
+        else:
+            self._III.pack_into(self._buf, self._INT0, n_trk, stages, n_det)
         self._III.pack_into(self._buf, self._CARRY_INT0, *carry)
         self._FFF.pack_into(self._buf, self._FLT0, *thresholds)
         return self._addr

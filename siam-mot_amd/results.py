@@ -191,12 +191,13 @@ def _storage_overlap(feats_a, dets_a, feats_b, dets_b):
     """True when any tensor of frame b lives in the storage of a tensor of frame a (a detector re-using its outputs)."""
     def ptrs(feats, dets):
         out = set()
-        for f in feats:
+        for f in (feats.values() if hasattr(feats, "values") else feats):       # (a dict of FPN maps iterates its KEYS)
             if isinstance(f, torch.Tensor) and f.numel():
                 out.add(f.untyped_storage().data_ptr())
-        box = getattr(dets, "bbox", None)
-        if isinstance(box, torch.Tensor) and box.numel():
-            out.add(box.untyped_storage().data_ptr())
+        fields = getattr(dets, "extra_fields", None)
+        for t in [getattr(dets, "bbox", None)] + (list(fields.values()) if isinstance(fields, dict) else []):
+            if isinstance(t, torch.Tensor) and t.numel():
+                out.add(t.untyped_storage().data_ptr())
         return out
     return bool(ptrs(feats_a, dets_a) & ptrs(feats_b, dets_b))
 

@@ -416,7 +416,7 @@ class TrackingLoop(torch.nn.Module):
             emm, pool = self.track.tracker, self.solver.track_pool
         ring = pool._ring
         view = ring.view(rec_host) if ring is not None and (rec_host is ring.bufs[0] or rec_host is ring.bufs[1]) else rec_host.numpy()
-        if (pre_out is not None and view[6] == 4 and view[0] == pre_out[0] and view[1] >= 1 and not pool._dormant_ids
+        if (pre_out is not None and view[6] == 4 and view[7] == M and view[0] == pre_out[0] and view[1] >= 1 and not pool._dormant_ids
                 and not self.__dict__.get("_hint_extra") and pool._last_tables is not None and self.__dict__.get("lazy_memory", True)
                 and pool.__dict__.get("mirror_skip", True)):
             # The steady frame, in as few bytecodes as it takes (this is the serial chain: the GPU waits for the next head):
@@ -439,6 +439,10 @@ class TrackingLoop(torch.nn.Module):
             return out
         rec = view[:8 + 4 * M + 3 * pool.DEVICE_CAPACITY].copy()
         K, A = int(rec[0]), int(rec[1])
+        if int(rec[7]) != M:
+            # the record's layout is sized by the row count the KERNEL saw: a mismatch means the argument block named another
+            # count than this call allocated and parsed for — never parse such a record
+            raise RuntimeError("siammot_amd: the solver ran on %d rows, this frame was laid out for %d" % (int(rec[7]), M))
         if rec[6] & 2:
             # a propagated track came in with a NaN score: what a head writes whose order hint failed the kernel's
             # verification (include/smot_emm.h, order_hint) — ask the hint; NaN features give NaN scores too and pass
@@ -779,7 +783,7 @@ class TrackingLoop(torch.nn.Module):
                             fp + 16 * M, ip + 16 * M, ip + 24 * M, fp + 36 * M,    # act_boxes, act_ids, act_labels, act_scores
                             rec_host.data_ptr(), templates.data_ptr(), sr_next.data_ptr(), (fp + 4 * hint_off) if hint_off else 0,
                             cz, cb, cs, ci, cl, cc),
-                           stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh), carry)
+                           stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh), carry, n_trk)
         ops.track_frame_addr(P.lib, addr, dev, stream)
         if n_trk > 0:                               # probes (tests): the box head's output of this frame
             if a.refine:
@@ -929,7 +933,12 @@ class TrackingLoop(torch.nn.Module):
             pre = rows(features, h.act_boxes, h.count) if rows is not None else None
             if pre is not None:
                 pre = tuple(pre) + (h.act_boxes,)
+            mem_before = self.track_memory
             out = self.solver.solve_finish(h)                                      # the frame's one synchronisation
+            if out.nan_track_scores:
+                # (on this path too a hint that failed the head's verification is REPORTED — the head's rows are
+                # NaN and would otherwise just drop out of the tracking; NaN features give NaN scores too and pass)
+                self._raise_on_bad_hint(mem_before)
             self.track_memory = self.track.get_track_memory(features, [out], precomputed=pre)
             return out
         dets = [detections]

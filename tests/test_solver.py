@@ -387,7 +387,7 @@ class _FrameEntryEmulation(object):
         import siammot_amd.ops as ops_
         self.ops, self.host, self.pad, self.rf = ops_, host_emu, pad, row_floats
         self.names = ops_._FRAME_PTRS + ops_._FRAME_INTS + ops_._FRAME_FLOATS
-        self.heads = self.carried = 0
+        self.heads = self.carried = self.no_head_frames = 0
 
     @staticmethod
     def _arr(ptr, n, ctype, dtype):
@@ -417,6 +417,8 @@ class _FrameEntryEmulation(object):
         if not stages & ops_.STAGE_SOLVE:
             return
         M = n_det + n_trk
+        if n_trk == 0 and n_det > 0:
+            self.no_head_frames += 1                 # a frame with rows and no propagated track: no head ran for it
         det = trk = None
         if n_det:
             det = (torch.from_numpy(self.f32(a["det_boxes"], 4 * n_det).reshape(n_det, 4).copy()),
@@ -464,7 +466,7 @@ class _FrameEntryEmulation(object):
             nsr[:A] = act + np.float32(self.pad)
 
 
-@pytest.mark.parametrize("mode", ["ahead", "early"])
+@pytest.mark.parametrize("mode", ["ahead", "early", "early_no_track_left"])
 def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(monkeypatch, mode):
     """``TrackingLoop._step_native`` — the default path: two calls of the frame entry point per frame on a block that stays
     packed, the next frame's head launched before the record is read when the caller shows the next features, the dormant
@@ -476,7 +478,12 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
     ``mode == "early"`` (round 5): the reference's one-frame contract — ``TrackingLoop.forward(features, detections)``, no
     next frame shown —: every call prepares the NEXT call's head launch while the (emulated) GPU works and the next call
     enqueues it on its first line, validating afterwards; the row count poked on a guess is corrected from the record.
-    Same comparison; the early head must be the one used on (nearly) every frame whose memory nobody looked at."""
+    Same comparison; the early head must be the one used on (nearly) every frame whose memory nobody looked at.
+    ``mode == "early_no_track_left"`` (round 6): the same contract on traffic whose first frames — and a stretch in
+    the middle — carry only detections below the start threshold: frames with rows (M >= 1) that leave NO active track, so
+    that the head range poked for the next call names a head that never runs.  The next call has no head; the row count
+    the solver sees must be that call's own (``poke_rest`` writes it), the record's row count is checked against the
+    frame's layout, and every frame equals the general path."""
     import ctypes
     import types
     import siammot_amd.ops as ops_
@@ -523,6 +530,15 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
     monkeypatch.setattr(pa, "host_record_ring", lambda dev: Ring(), raising=False)
     for key in ("launched", "used", "discarded", "early_launched", "early_used", "early_discarded"):
         ops_.SPECULATION[key] += 0
+    no_track = mode == "early_no_track_left"
+    if no_track:
+        mode = "early"
+
+    def traffic(r, f):
+        d = detections(r, f)
+        if no_track and (f < 3 or 60 <= f < 66 or 140 <= f < 143):
+            d.add_field("scores", torch.full_like(d.get_field("scores"), 0.05))       # below every threshold: nothing starts / resumes
+        return d
     if mode == "early":
         loops[0]._lean_ok = lambda d: True
         loops[0]._native_ok = lambda d: True
@@ -538,17 +554,20 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
                 sv.track_pool._max_dormant_frames = 1000
         heads0 = emu.heads
         if mode == "early":
-            a = loops[0](feats, detections(rs[0], f))
+            a = loops[0](feats, traffic(rs[0], f))
         else:
-            a = loops[0]._step_native(feats, detections(rs[0], f), next_features=feats)
+            a = loops[0]._step_native(feats, traffic(rs[0], f), next_features=feats)
         assert emu.heads - heads0 <= 2                       # (a head launched early / ahead and, at most, launched again)
-        b = loops[1](feats, detections(rs[1], f))
+        b = loops[1](feats, traffic(rs[1], f))
         assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
         assert torch.equal(a.get_field("scores"), b.get_field("scores")) and torch.equal(a.get_field("labels"), b.get_field("labels"))
         assert pa.get_active_ids() == pb.get_active_ids() and list(pa._dormant_ids.items()) == list(pb._dormant_ids.items())
         assert pa._kill_ids == pb._kill_ids and pa._max_id == pb._max_id
         if f % 3 == 2 or f > 190:
             ma, mb = loops[0].track_memory, loops[1].track_memory
+            if no_track and len(mb[2][0]) == 0:
+                assert len(ma[2][0]) == 0                     # no track left: an empty memory on both paths
+                continue
             assert type(ma) is _LazyMemory
             assert torch.equal(ma[0], mb[0]) and torch.equal(ma[1][0].bbox, mb[1][0].bbox), "memory, frame %d" % f
             assert torch.equal(ma[2][0].bbox, mb[2][0].bbox)
@@ -559,6 +578,9 @@ def test_frame_entry_point_bookkeeping_with_speculation_and_carried_rows_on_cpu(
     sp = {k: ops_.SPECULATION[k] - sp0.get(k, 0) for k in ("launched", "used", "discarded", "early_launched", "early_used",
                                                            "early_discarded")}
     mc = {k: ops_.MEMORY_CARRY[k] - mc0.get(k, 0) for k in ("in_the_solver_launch", "ahead_kept", "ahead_redone", "launched")}
+    if no_track:
+        assert emu.no_head_frames >= 3, emu.no_head_frames      # calls without a head behind frames with rows did occur
+        return
     if mode == "early":
         # every frame whose memory was left unbuilt (two of three: the comparison builds the third) started with the head
         # that the call before had prepared, whatever happened to the row count in between; none was launched twice
@@ -1070,6 +1092,50 @@ def test_lean_step_equals_general_path(native):
     assert len(lean_frames) == 16 and seen_dormant and loops[0].solver.track_pool._kill_ids
     import siammot_amd.ops as ops_
     assert ops_.MEMORY_CARRY["launched"] > carried0, "no frame copied its dormant rows on the device"
+
+
+@pytest.mark.gpu
+def test_frames_that_leave_no_track_are_followed_by_calls_without_a_head():
+    """ADVICE r5 (high): the default tracking loop prepares the NEXT call's head launch at the end of every frame with rows;
+    a frame whose detections all stay below the start threshold leaves no track, the next call has an empty memory and no
+    head — the row count the solver sees must be that call's own (it used to keep the guessed count of the head that never
+    ran: one row too many, a record laid out for another count).  Video start and a stretch in the middle, real HIP head,
+    against the general path: outputs, pool and memory identical in every frame."""
+    import golden_inputs as gi
+    from fake_tracker import detections
+    from siammot_amd.config import get_default_cfg
+    from siammot_amd.track_head import build_tracking_loop
+    dev = torch.device("cuda:0")
+    cfg = get_default_cfg(channels=32)
+    cfg.MODEL.TRACK_HEAD.MAX_DORMANT_FRAMES = 1
+    loops = [build_tracking_loop(cfg, device=dev, refine_tracks=False) for _ in range(2)]
+    loops[1].track.tracker.load_state_dict(loops[0].track.tracker.state_dict())
+    loops[1]._lean_ok = lambda d: False                     # general path
+    shapes = gi.feature_shapes((1280, 704), 32)
+    rs_f = np.random.RandomState(19)
+    rs = [np.random.RandomState(6), np.random.RandomState(6)]
+    empties = 0
+    for f in range(14):
+        feats = tuple(torch.from_numpy(rs_f.standard_normal(s).astype(np.float32)).to(dev) for s in shapes)
+        outs = []
+        for lp, r in zip(loops, rs):
+            d = detections(r, f)
+            if f < 3 or 7 <= f < 11:
+                d.add_field("scores", torch.full_like(d.get_field("scores"), 0.05))       # nothing starts; tracks starve
+                d = d[:0] if f in (8, 9) else d                                           # ... and frames with no row at all
+            outs.append(lp(feats, d.to(dev)))
+        a, b = outs
+        assert torch.equal(a.bbox, b.bbox) and torch.equal(a.get_field("ids"), b.get_field("ids")), "frame %d" % f
+        assert torch.equal(a.get_field("scores"), b.get_field("scores"))
+        pa, pb = loops[0].solver.track_pool, loops[1].solver.track_pool
+        assert pa.get_active_ids() == pb.get_active_ids() and pa._dormant_ids == pb._dormant_ids and pa._max_id == pb._max_id
+        ma, mb = loops[0].track_memory, loops[1].track_memory
+        assert len(ma[2][0]) == len(mb[2][0])
+        if len(mb[2][0]):
+            assert torch.equal(ma[0], mb[0]) and torch.equal(ma[2][0].bbox, mb[2][0].bbox), "memory, frame %d" % f
+        else:
+            empties += 1
+    assert empties >= 3 and loops[0].solver.track_pool._max_id >= 5, (empties, loops[0].solver.track_pool._max_id)
 
 
 @pytest.mark.gpu

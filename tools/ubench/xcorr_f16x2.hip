@@ -1,0 +1,234 @@
+// Prototype + microbenchmark (round 6): the 30x30 * 15x15 -> 16x16 depthwise cross-correlation of one plane on the fp16
+// matrix pipe with two-part operands, against the product's one-plane-per-wave fp32 FMA phase (xcorr_patch1.h), both fed
+// from the SAME LDS state the fused pooling + correlation kernel has when its correlation starts (search plane at row stride
+// 40 floats, template at row stride 16).
+//
+//   out[y][x] = sum_i sum_j X[y+i][x+j] Z[i][j]   ==   sum_i  A_i[16 x 32] * B_i[32 x 16],
+//   A_i[y][c] = X[y+i][c]  (row y+i of the plane: 8 consecutive halves per lane, aligned),
+//   B_i[c][x] = Z[i][c-x]  (Toeplitz window of template row i: 8 consecutive halves at a lane-dependent HALF-WORD offset —
+//                           ds_read_b128 at 2-byte alignment, tools/ubench/lds_unaligned.hip)
+// 15 rows x 3 part products (x2 z1, x1 z2, x1 z1) = 45 v_mfma_f32_16x16x32_f16 per plane instead of 900 v_fmac_f32 per lane.
+//   hipcc --offload-arch=gfx950 -O3 -I siam-mot_amd/csrc tools/ubench/xcorr_f16x2.hip -o tools/ubench/xcorr_f16x2
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include "xcorr_patch1.h"
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int XS = 40, ZS = 16;
+constexpr int XP = 30 * XS;          // floats of one search plane
+constexpr int XH_ROW = 40;           // halves per row of the fp16 image (80 B: rows 20 dwords apart -> conflict-free b128 reads)
+constexpr int ZT_ROW = 48;           // halves per Toeplitz row: index q = t + 16, t = c - x in [-15, 31]
+constexpr int ZT_BYTES = 2 * 15 * ZT_ROW * 2;      // two parts
+constexpr int PLANE_BYTES = XP * 4 + ZT_BYTES;     // x image (fp32, later the two half images) | Toeplitz rows
+
+__device__ __forceinline__ float wave_absmax(float v) {
+#define ROR(N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (N), 0xf, 0xf, false))
+    v = fmaxf(v, ROR(8)); v = fmaxf(v, ROR(4)); v = fmaxf(v, ROR(2)); v = fmaxf(v, ROR(1));
+#undef ROR
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+// power of two s with m * s in [2^13, 2^14) (1 for m = 0 / inf / nan), and its inverse
+__device__ __forceinline__ void pow2_scale(float m, float* s, float* inv) {
+    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+    *s = 1.0f; *inv = 1.0f;
+    if (e != 0 && e != 255) {
+        int k = 140 - e; k = k < -60 ? -60 : (k > 60 ? 60 : k);
+        *s = __uint_as_float((unsigned)(127 + k) << 23);
+        *inv = __uint_as_float((unsigned)(127 - k) << 23);
+    }
+}
+#define CVT(A, B) __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){A, B}, f16x2))
+
+// the correlation of ONE plane by one wave: xs (fp32 [30][XS], overwritten by the half images), zs (fp32 [15][ZS]), zt = the
+// wave's Toeplitz area (ZT_BYTES)
+template <int ABL>
+__device__ __forceinline__ void xcorr_f16x2_wave(float* xs, const float* zs, unsigned short* zt, int lane, float* __restrict__ out, int plane) {
+    const f16x4 negI = __builtin_bit_cast(f16x4, (u32x2){(lane & 3) == 0 ? 0x0000BC00u : ((lane & 3) == 1 ? 0xBC000000u : 0u),
+                                                         (lane & 3) == 2 ? 0x0000BC00u : ((lane & 3) == 3 ? 0xBC000000u : 0u)});
+    // ---- search plane: all reads first (450 pairs of neighbours, 8 per lane of which the last is partial), maximum, split,
+    // then the half images over the fp32 image (LDS operations of a wave complete in order: reads before writes)
+    f32x4 xv[4];          // lane's 8 pairs as 4 groups of two pairs
+    int prow[8], pcol[8];
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int p = lane + 64 * t;                    // pair index: row p / 15, columns 2 (p % 15), +1
+        const bool live = p < 450;
+        const int r = live ? (p * 4370) >> 16 : 0, c2 = live ? p - r * 15 : 0;      // p / 15 for p < 450
+        prow[t] = r; pcol[t] = c2;
+        const float2 v = *reinterpret_cast<const float2*>(xs + r * XS + 2 * c2);
+        xv[t >> 1][(t & 1) * 2] = live ? v.x : 0.0f;
+        xv[t >> 1][(t & 1) * 2 + 1] = live ? v.y : 0.0f;
+        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+    }
+    float sx, isx;
+    pow2_scale(wave_absmax(m), &sx, &isx);
+    unsigned xh1[8], xh2[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v = xv[g] * sx;
+        const unsigned a0 = CVT(v[0], v[1]), a1 = CVT(v[2], v[3]);
+        v = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(f16x4, (u32x2){a0, a1}), v, 0, 0, 0);
+        xh1[2 * g] = a0; xh1[2 * g + 1] = a1;
+        xh2[2 * g] = CVT(v[0], v[1]); xh2[2 * g + 1] = CVT(v[2], v[3]);
+    }
+    // ---- template: 225 values, 4 per lane (the last partial); maximum, split, Toeplitz rows (one copy per part)
+    float zv[4];
+    float mz = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = lane + 64 * t;
+        const int i = e < 225 ? (e * 4370) >> 16 : 0, j = e < 225 ? e - i * 15 : 0;
+        zv[t] = e < 225 ? zs[i * ZS + j] : 0.0f;
+        mz = fmaxf(mz, fabsf(zv[t]));
+    }
+    float sz, isz;
+    pow2_scale(wave_absmax(mz), &sz, &isz);
+    __builtin_amdgcn_sched_barrier(0);
+    // zero the Toeplitz rows (pads must be zeros), then the half images, then the template halves
+    {
+        u32x4* z4 = reinterpret_cast<u32x4*>(zt);
+        for (int e = lane; e < ZT_BYTES / 16; e += 64) z4[e] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    unsigned* xh = reinterpret_cast<unsigned*>(xs);                 // [part][30][XH_ROW / 2] dwords
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (lane + 64 * t < 450) {
+            xh[prow[t] * (XH_ROW / 2) + pcol[t]] = xh1[t];
+            xh[30 * (XH_ROW / 2) + prow[t] * (XH_ROW / 2) + pcol[t]] = xh2[t];
+        }
+    }
+    // columns 30, 31 (K = 32) meet zero weights but must be finite: zero them (dword 15 of every row, both parts)
+    if (lane < 60) xh[(lane / 30) * 30 * (XH_ROW / 2) + (lane % 30) * (XH_ROW / 2) + 15] = 0u;
+    {
+        f32x4 v = {zv[0] * sz, zv[1] * sz, zv[2] * sz, zv[3] * sz};
+        const unsigned a0 = CVT(v[0], v[1]), a1 = CVT(v[2], v[3]);
+        v = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(f16x4, (u32x2){a0, a1}), v, 0, 0, 0);
+        const unsigned b0 = CVT(v[0], v[1]), b1 = CVT(v[2], v[3]);
+        const unsigned short h1[4] = {(unsigned short)a0, (unsigned short)(a0 >> 16), (unsigned short)a1, (unsigned short)(a1 >> 16)};
+        const unsigned short h2[4] = {(unsigned short)b0, (unsigned short)(b0 >> 16), (unsigned short)b1, (unsigned short)(b1 >> 16)};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 225) {
+                const int i = (e * 4370) >> 16, j = e - i * 15;
+                zt[i * ZT_ROW + 16 + j] = h1[t];
+                zt[15 * ZT_ROW + i * ZT_ROW + 16 + j] = h2[t];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- 15 template rows x 3 part products
+    const int y = lane & 15, kq = lane >> 4;
+    const unsigned a_addr = (unsigned)(size_t)xs + (unsigned)(y * XH_ROW * 2 + kq * 16);                  // + i * 80 (+ 2400 for part 2)
+    const unsigned b_addr = (unsigned)(size_t)zt + (ABL == 3 ? (unsigned)(((8 * kq - y + 16) * 2) & ~3) : (unsigned)((8 * kq - y + 16) * 2));                     // + i * 96 (+ 1440 for part 2)
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    // operands of row i + 1 are requested before the three instructions of row i are issued (two register sets)
+    u32x4 A1[2], A2[2], B1[2], B2[2];
+#define RD(I, S)                                                                                                   \
+    asm volatile("ds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\tds_read_b128 %2, %5 offset:%8\n\tds_read_b128 %3, %5 offset:%9" \
+                 : "=&v"(A1[S]), "=&v"(A2[S]), "=&v"(B1[S]), "=&v"(B2[S])                                          \
+                 : "v"(a_addr), "v"(b_addr), "n"((I) * XH_ROW * 2), "n"(30 * XH_ROW * 2 + (I) * XH_ROW * 2), "n"((I) * ZT_ROW * 2), \
+                   "n"(15 * ZT_ROW * 2 + (I) * ZT_ROW * 2) : "memory");
+#define MM(S)                                                                                                      \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A2[S]), __builtin_bit_cast(f16x8, B1[S]), acc0, 0, 0, 0); \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A1[S]), __builtin_bit_cast(f16x8, B2[S]), acc1, 0, 0, 0); \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A1[S]), __builtin_bit_cast(f16x8, B1[S]), acc2, 0, 0, 0);
+#define STEP(I)                                                                                                    \
+    if ((I) + 1 < 15) { RD((I) + 1, ((I) + 1) & 1) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); }            \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    MM((I) & 1)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 2) {
+    RD(0, 0)
+    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14)
+    }
+#undef STEP
+#undef MM
+#undef RD
+    // D: lane (n = lane % 16 = x, g = lane / 16) holds rows m = 4 g .. 4 g + 3 (= y)
+    const float us = isx * isz;
+    float* o = out + (size_t)plane * 256 + (lane >> 4) * 4 * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * 16] = ((acc0[r] + acc1[r]) + acc2[r]) * us;
+}
+
+template <int MODE>       // 0: fp32 FMA phase of the product (xcorr_patch1_compute, LEAN), 1: fp16 x 2 on the matrix pipe
+__global__ void __launch_bounds__(512) xcorr_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out, int planes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int plane = blockIdx.x * 8 + wave;
+    if (plane >= planes) return;
+    float* xs = reinterpret_cast<float*>(smem + wave * (PLANE_BYTES + 15 * ZS * 4));
+    float* zs = xs + XP + ZT_BYTES / 4;
+    unsigned short* zt = reinterpret_cast<unsigned short*>(xs + XP);
+    for (int e = lane; e < 900; e += 64) xs[(e / 30) * XS + e % 30] = x[(size_t)plane * 900 + e];
+    for (int e = lane; e < 225; e += 64) zs[(e / 15) * ZS + e % 15] = z[(size_t)plane * 225 + e];
+    __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 0) smot::xcorr_patch1_compute<30, 15, true>(xs, zs, lane, out, plane);
+    else xcorr_f16x2_wave<MODE>(xs, zs, zt, lane, out, plane);
+}
+
+int main(int argc, char** argv) {
+    const int planes = argc > 1 ? atoi(argv[1]) : 3840;
+    std::vector<float> hx((size_t)planes * 900), hz((size_t)planes * 225), ho((size_t)planes * 256), ho2((size_t)planes * 256);
+    srand(7);
+    auto rnd = []() { float s = 0; for (int k = 0; k < 12; ++k) s += rand() / (float)RAND_MAX; return s - 6.0f; };
+    for (auto& v : hx) v = rnd();
+    for (auto& v : hz) v = rnd();
+    for (int k = 0; k < 900; ++k) hx[900 * 5 + k] *= 1e-6f;              // a plane of tiny values
+    for (int k = 0; k < 900; ++k) hx[900 * 6 + k] *= 3e4f;               // and one of large ones
+    float *dx, *dz, *dout;
+    (void)hipMalloc(&dx, hx.size() * 4); (void)hipMalloc(&dz, hz.size() * 4); (void)hipMalloc(&dout, ho.size() * 4);
+    (void)hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dz, hz.data(), hz.size() * 4, hipMemcpyHostToDevice);
+    const size_t smem = 8 * (PLANE_BYTES + 15 * ZS * 4);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    const dim3 grid((planes + 7) / 8);
+    for (int mode = 0; mode < 4; ++mode) {
+        hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int r = 0; r < 6; ++r) {
+            (void)hipEventRecord(e0, 0);
+            if (mode == 0) hipLaunchKernelGGL(xcorr_kernel<0>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else if (mode == 1) hipLaunchKernelGGL(xcorr_kernel<1>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else if (mode == 2) hipLaunchKernelGGL(xcorr_kernel<2>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else hipLaunchKernelGGL(xcorr_kernel<3>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+            float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+        }
+        (void)hipMemcpy(mode == 0 ? ho.data() : ho2.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost);
+        // error against fp64 on the first 64 planes, relative to sum |x z|
+        double worst = 0;
+        for (int p = 0; p < 64 && p < planes; ++p)
+            for (int yy = 0; yy < 16; ++yy)
+                for (int xx = 0; xx < 16; ++xx) {
+                    double s = 0, sa = 0;
+                    for (int i = 0; i < 15; ++i)
+                        for (int j = 0; j < 15; ++j) {
+                            const double t = (double)hx[(size_t)p * 900 + (yy + i) * 30 + xx + j] * (double)hz[(size_t)p * 225 + i * 15 + j];
+                            s += t; sa += fabs(t);
+                        }
+                    const double got = (mode == 0 ? ho : ho2)[(size_t)p * 256 + yy * 16 + xx];
+                    worst = fmax(worst, fabs(got - s) / sa);
+                }
+        printf("{\"form\": \"%s\", \"planes\": %d, \"us\": %.2f, \"max_abs_err_over_sum_abs_xz\": %.3e, \"hip\": \"%s\"}\n",
+               mode == 0 ? "fp32 FMA phase (xcorr_patch1_compute, LEAN)" : mode == 1 ? "fp16 x 2 on the matrix pipe (45 x v_mfma_f32_16x16x32_f16)" : mode == 2 ? "ablation: conversion only (no matrix loop)" : "ablation: B windows at 4-byte alignment (wrong results)", planes, best * 1e3,
+               worst, hipGetErrorString(hipGetLastError()));
+    }
+    return 0;
+}
