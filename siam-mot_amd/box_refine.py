@@ -236,9 +236,6 @@ class TrackBoxHead(nn.Module):
                                  conf, (fe.fc6.weight, fe.fc6.bias, fe.fc7.weight, fe.fc7.bias, cs.weight, cs.bias,
                                         bp.weight, bp.bias), bc.weights, bc.bbox_xform_clip,
                                  None if pp.amodal_inference else image_wh, tracktor)
-            hook = self.__dict__.get("raw_output_hook")      # tests / probes: (boxes, scores, ids, labels) of the refinement
-            if hook is not None:
-                hook(*out)
             return out
         x = ops.roi_align_levels(features, boxes, boxes, pooler.output_size[0], pooler.scales, pooler.sampling_ratio)
         x = x.view(x.shape[0], -1)
@@ -262,9 +259,6 @@ class TrackBoxHead(nn.Module):
         KR = self.predictor.bbox_pred.out_features // 4
         res = ops.box_refine_post(out, K, KR, boxes, labels, ids, conf, bc.weights, bc.bbox_xform_clip,
                                   None if pp.amodal_inference else image_wh, tracktor)
-        hook = self.__dict__.get("raw_output_hook")          # (as in the one-call form above)
-        if hook is not None:
-            hook(*res)
         return res
 
 

@@ -237,9 +237,6 @@ class EMM(nn.Module):
                             self.pad_pixels, sigma=self.sigma, use_centerness=self.use_centerness,
                             clip_wh=None if self.amodal else image_wh, gn_groups=gn_groups, gn_eps=gn_eps,
                             order_hint=hint)
-        hook = self.__dict__.get("raw_output_hook")          # tests / probes: the head's output before refinement / solver
-        if hook is not None:
-            hook(out[0], out[1])
         return out
 
     def _template_pooler(self):

@@ -213,6 +213,18 @@ def _GLOBAL_HOOKS():
 class TrackingLoop(torch.nn.Module):
     """One tracking step per frame: ``forward(features, detections) -> BoxList`` with track ids."""
 
+    # The frame entry point runs head, refinement and solver behind two library calls; the only way to look at the head's
+    # (or the box head's) raw output of a frame in between is from inside `_step_native`.  The product never does: the two
+    # calls below are made only by a subclass that sets `_probed` (tests/sequence_replay.py::ProbedTrackingLoop — the
+    # closed-loop replays record the raw rows there).  No attribute of a product object is consulted for a callback.
+    _probed = False
+
+    def _head_output_enqueued(self, boxes, scores):                  # pragma: no cover - subclasses only
+        raise NotImplementedError
+
+    def _refined_output_enqueued(self, boxes, scores, ids, labels):  # pragma: no cover - subclasses only
+        raise NotImplementedError
+
     def __init__(self, track_head, solver, refine_tracks=None):
         super(TrackingLoop, self).__init__()
         self.track = track_head
@@ -727,10 +739,8 @@ class TrackingLoop(torch.nn.Module):
             addr = a.poke_head((ops._workspace(dev, need[0], stream.value).data_ptr(), p_tbb, p_sr, p_z, p_hint, p_ids,
                                 p_lab, p, p + 16 * n_trk), n_trk, ops.STAGE_HEAD)
             ops.track_frame_addr(P.lib, addr, dev, stream)                         # the head is running from here on
-        if n_trk > 0:                               # probes (tests): the head's output of this frame, BEFORE anything consumes
-            hook = emm.__dict__.get("raw_output_hook")     # it (stream order: a probe may look at it or edit it in place)
-            if hook is not None:
-                hook(tf[:4 * n_trk].view(n_trk, 4), tf[4 * tf_cap:4 * tf_cap + n_trk])
+        if self._probed and n_trk > 0:              # (a test-only subclass: tests/sequence_replay.ProbedTrackingLoop)
+            self._head_output_enqueued(tf[:4 * n_trk].view(n_trk, 4), tf[4 * tf_cap:4 * tf_cap + n_trk])
         # ---- while the head runs: detections, output buffers, the remaining stages --------------------------------------
         seg = solver._segment(detections)
         n_det = 0
@@ -785,12 +795,9 @@ class TrackingLoop(torch.nn.Module):
                             cz, cb, cs, ci, cl, cc),
                            stages, n_det, (solver.track_thresh, solver.start_thresh, solver.resume_track_thresh), carry, n_trk)
         ops.track_frame_addr(P.lib, addr, dev, stream)
-        if n_trk > 0:                               # probes (tests): the box head's output of this frame
-            if a.refine:
-                hook = self.refine_tracks.box.__dict__.get("raw_output_hook")
-                if hook is not None:
-                    hook(tf[5 * tf_cap:5 * tf_cap + 4 * n_trk].view(n_trk, 4), tf[9 * tf_cap:9 * tf_cap + n_trk], ti[:n_trk],
-                         ti[n_trk:])
+        if self._probed and n_trk > 0 and a.refine:
+            self._refined_output_enqueued(tf[5 * tf_cap:5 * tf_cap + 4 * n_trk].view(n_trk, 4), tf[9 * tf_cap:9 * tf_cap + n_trk],
+                                          ti[:n_trk], ti[n_trk:])
         hint_ptr = (fp + 4 * hint_off) if hint_off else 0
         spec_tf = None
         if carried_ahead is None:

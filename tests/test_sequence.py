@@ -158,6 +158,9 @@ def _gpu_loop(name, lean):
 ROUND5 = ("crowd", "crowd512", "longdormant", "dormant256", "multiclass")
 MUST_FALL_BACK = {"crowd": ("refine_library_gemm",), "crowd512": ("host_solver", "general_frame"),
                   "dormant256": ("dormant_rows_on_the_host",)}     # more dormant rows than one carry launch takes
+# rows aligned to the reference's side of an arg-max tie, per sequence: the count MEASURED on MI355X with the round-6 kernels
+# (the largest over the four paths; printed by every replay); the test allows one more.  Sequences not named: none.
+MAX_ALIGNED_ROWS = {"crowd": 5, "dormant256": 1}        # (crowd: stored margins 9.5e-7 .. 6.5e-6; dormant256: 3.0e-8)
 
 
 @pytest.mark.gpu
@@ -212,7 +215,7 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     try:
         stats = SR.replay(loop, inp, golden, "cuda:0", probe=SR.probe_tracker(emm),
                           box_probe=SR.probe_box_head(loop.refine_tracks) if loop.refine_tracks is not None else None,
-                          prefetch=ahead)
+                          prefetch=ahead, tie_margin=SR.TIE_MARGIN_LONG if name in ("crowd", "dormant256") else SR.FLIP_MARGIN)
     finally:
         if lean is True:
             ops_.FrameArgs.poke_head = poke
@@ -245,12 +248,15 @@ def test_closed_loop_with_the_hip_head_equals_the_reference(name, lean):
     # measured, margins 2.7e-7 .. 6.5e-6 (the replay admits a tie below max(FLIP_MARGIN, a quarter of the score error
     # measured so far)); capped here at 1e-5
     long_run = name in ("crowd", "dormant256")       # (dormant256: 100 frames, ~15 k decisions — the same drift argument)
-    tie_cap = 1e-5 if long_run else SR.FLIP_MARGIN
+    # Rows aligned to the reference's side of a tie (sequence_replay.probe_tracker): the margin bound is FIXED at the point of
+    # alignment (FLIP_MARGIN; TIE_MARGIN_LONG = 1e-5 for the two long runs — passed to the replay above), and the NUMBER of
+    # such rows is an absolute, recorded count per sequence: what the round-6 kernels measured on MI355X, + 1 of slack
     # (dormant256: most of its 19,925 decisions are searches of long-dormant tracks whose confidence is ~0 — the score map is
     # then the cosine window alone and 211 stored margins are below 2e-6, several exactly 0: ties by construction, with no
-    # effect downstream — a dormant track's entry never changes; one aligned row per hundred decisions is allowed there)
-    max_ties = stats["raw_rows"] // 100 if name == "dormant256" else max(2, stats["raw_rows"] // 1000)
-    assert len(stats["flips"]) <= max_ties and all(m < tie_cap for (_, _, m, _) in stats["flips"]), stats
+    # effect downstream — a dormant track's entry never changes).
+    print("rows aligned to the reference's side of an arg-max tie (frame, id, stored margin, px):", stats["flips"])
+    tie_cap = SR.TIE_MARGIN_LONG if long_run else SR.FLIP_MARGIN
+    assert len(stats["flips"]) <= MAX_ALIGNED_ROWS.get(name, 0) + 1 and all(m < tie_cap for (_, _, m, _) in stats["flips"]), stats
     # closed-loop score drift: the long runs, and since round 6 `longdormant` (72 frames, 5.3 k decisions: 1.4e-4 with the
     # two-part fp16 towers, whose single-frame logit error equals the fp32 form's; ids / labels / pool / memory order
     # identical in all 72 frames, no flip), are held to the replay's own per-frame bound; the short sequences to 1e-4
