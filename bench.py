@@ -523,10 +523,10 @@ TIMER_NOTE = ("kernel start/stop events on the launch stream (hipExtLaunchKernel
 def tower_roofline(n, total_ms, launches, ho=16):
     """The towers against the matrix pipes.  ``frac`` divides the multiply-adds of the Winograd algorithm (F(2x2,3x3): 16/36
     of the direct convolution's) by the dense fp32 MFMA peak — what an fp32 implementation of the same algorithm could
-    reach at best, <= 1 for the fp32 forms; the three-part bf16 form (``form`` 3) executes six bf16 instructions of K = 32
-    where the fp32 forms execute eight of K = 4 and is bound by the vector instructions that split its operands
-    (DESIGN.md §3), so its own pipe fraction is reported beside it (``bf16_mfma``).  ``effective_tflops`` is the
-    direct-convolution figure the reference computes, for comparison with other implementations."""
+    reach at best, <= 1 for the fp32 forms; the split form (``form`` 3; round 6: two-part fp16 operands, three part products)
+    executes three fp16 instructions of K = 32 where the fp32 forms execute eight of K = 4, so its own pipe fraction is
+    reported beside it (``f16_mfma``).  ``effective_tflops`` is the direct-convolution figure the reference computes, for
+    comparison with other implementations."""
     import siammot_amd.ops as ops
     algo = 2.0 * n * 2 * CHANNELS * ho * ho * 9 * CHANNELS
     executed = algo * 16.0 / 36.0
@@ -540,13 +540,15 @@ def tower_roofline(n, total_ms, launches, ho=16):
         "launches_timed": launches,
     }
     if form == 3:
-        # per workgroup (two tiles x all 64 output tiles of a track): 8 waves x (C/8 + 3) columns x 24 instructions of
-        # 16 x 16 x 32 multiply-adds (the three partial K blocks of the rotation included)
-        insts = ((n + 7) // 8 * 8) * (2 * CHANNELS // 32) * 8 * (CHANNELS // 8 + 3) * 24
+        # per workgroup (two tiles x all 64 output tiles of a track): 8 waves x (C/8 + 3) columns x 12 instructions of
+        # 16 x 16 x 32 multiply-adds (the three partial K blocks of the rotation included) + 4 small residual instructions
+        # (v_mfma_f32_4x4x4_16b_f16) per wave and stage, not counted
+        insts = ((n + 7) // 8 * 8) * (2 * CHANNELS // 32) * 8 * (CHANNELS // 8 + 3) * 12
         flops = insts * 2.0 * 16 * 16 * 32
-        out["bf16_mfma"] = {"executed_flops_per_launch": flops, "achieved": flops / sec / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                            "frac": flops / sec / 1e12 / 2500.0,
-                            "note": "vector-bound: 118 vector instructions per wave and stage beside 24 matrix instructions"}
+        out["f16_mfma"] = {"executed_flops_per_launch": flops, "achieved": flops / sec / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                           "frac": flops / sec / 1e12 / 2500.0,
+                           "note": "two-part fp16 operands, 3 part products (DESIGN.md §3 K3 round 6); the loop is bound by "
+                                   "the sum of its vector issue, matrix issue and operand fetches on a SIMD with two waves"}
     return out
 
 
@@ -1060,7 +1062,10 @@ def main():
                      "note": "host_enqueue = Python + ctypes time to enqueue one frame pair (4 launches), no "
                              "synchronisation; headroom = ms_per_step - host_enqueue"},
         "vs_baseline": None,
-        "dtype": "f32",
+        # arithmetic type of the path: fp32 in and out of every kernel; the towers' transform-domain GEMMs run on the fp16 matrix
+        # pipe with every fp32 operand as two fp16 parts of a power-of-two-scaled value (3 of 4 part products, fp32 accumulate):
+        # logits within the fp32 form's error of an fp64 evaluation (tests/test_hip_parity.py, 1.25 x bound)
+        "dtype": "f32 (towers: fp16x2 operands on MFMA, fp32 accumulate, fp32-equivalent error)",
         "data": "synthetic",
         "config": {
             "workload": "EMM tracker-head frame pair (EMM.forward + EMM.extract_cache) on %s FPN maps "
@@ -1125,6 +1130,21 @@ def main():
         out["other_configs"] = other_config_runs(args)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n)
+    # the last thing on the line (a log tail keeps it): the numbers a reviewer looks for first, compact
+    rt, am = out.get("roofline_tower") or {}, ((out.get("parity") or {}).get("argmax_statistics") or {})
+    out["summary"] = {
+        "frame_pairs_per_s": out["value"], "ms_per_step": out["ms_per_step"],
+        "graded_kernel_us": out["roofline"]["avg_launch_us"], "graded_kernel_frac_of_hbm_peak": out["roofline"]["frac"],
+        "tower_us": rt.get("avg_launch_us"), "tower_form": rt.get("form"),
+        "tower_f16_mfma_frac": (rt.get("f16_mfma") or {}).get("frac"),
+        "host_enqueue_us_per_step": max(rank_host_us),
+        "argmax_statistics": {k: am.get(k) for k in ("frame_pairs", "tracks_total", "argmax_exact", "min_iou",
+                                                     "tracks_below_1e-3_iou_bar")} if am else None,
+        "other_configs_ms_per_step": {k: v.get("ms_per_step") for k, v in (out.get("other_configs") or {}).items()},
+        "cpu_baseline_frame_pairs_per_s": (out.get("cpu_baseline") or {}).get("value"),
+        "methodology_version": "r06 (tracking_loop legs: median of three chunks, detections as ready-made BoxLists — as r05; "
+                               "r01-r04 built a BoxList per frame inside the timed loop: ~4 us per frame more)",
+    }
     print(json.dumps(out))
     sys.stdout.flush()
     parallel.shutdown()

@@ -41,8 +41,13 @@ typedef void* smot_stream_t; /* hipStream_t */
  * 12: order-hint entries of 536 floats — behind the tables every entry carries the by-roi record the consumer VERIFIES against
  *     its own boxes / search regions, and entry 0 the list's status word; the geometry stamp includes the level's scale;
  *     smot_emm_track_fwd writes NaN rows when the verification fails; record word 6 of the solver became a bit field;
- *     smot_emm_order_hint_status added. */
-#define SMOT_ABI_VERSION 12
+ *     smot_emm_order_hint_status added.
+ * 13: the second image of smot_emm_tower_pack is the TWO-part fp16 image (C/32 + 1 rotated blocks of 8192 floats per
+ *     16-channel tile) followed by a four-word header {largest |w| bits, 2^-ku, 0, 0}: ask smot_emm_tower_pack_floats — an
+ *     image packed by a version-12 library has another size and layout; smot_emm_tower_form returns 3 at every track count
+ *     (one form); smot_emm_predictor_fwd may use the head of its `logits` output as scratch before it writes the logits.
+ */
+#define SMOT_ABI_VERSION 13
 
 /* ABI version of the loaded library (checked by the host layer at load time). */
 int smot_abi_version(void);
@@ -190,19 +195,24 @@ int smot_sr_xcorr_gather_fwd(const float* const* feats, const int* heights, cons
  *   Winograd F(2x2,3x3)-transformed tower filters in the order the matrix-core kernel consumes them.
  *   With it (and Ho == 16) the towers run as a Winograd convolution on the matrix cores — 2.25x fewer
  *   multiplies, results equal to the direct convolution up to fp32 rounding order; without it the direct
- *   fp32 kernel runs.  Two forms, chosen by the number of tracks: fp32 matrix instructions on the fp32
- *   image, or (C % 32 == 0, more than 16 tracks) bf16 matrix instructions on operands split into three
- *   bf16 parts each (weights: split once into the second image; activations: split in registers), which
- *   keeps every product to 2^-24 of its size with fp32 accumulation: fp32 accuracy at twice the rate.
+ *   fp32 kernel runs.  For C % 32 == 0 (a power of two, <= 512) the transform-domain GEMMs run on fp16 matrix
+ *   instructions with every fp32 operand as TWO fp16 parts of a power-of-two-scaled value (weights: scaled and
+ *   split once into the second image; a track's response: scaled by 2^kv chosen from its planes' largest
+ *   |response| and split in registers; three of the four part products, fp32 accumulation, the scales taken
+ *   out exactly afterwards): the logits' error against an fp64 evaluation equals the fp32 form's, at every
+ *   track count (one form: a track's logits do not depend on how many tracks the call has).  Other channel
+ *   counts with C % 16 == 0 run the fp32 matrix instructions on the fp32 image.
+ *   The plane maxima come from the pooling + correlation kernel inside smot_emm_track_fwd; a stand-alone call
+ *   computes them with one small launch into the head of `logits` (N*C floats) before the logits are written.
  *   It is a pure function of the two tower weight tensors: recompute it whenever they change (the Python
  *   layer keys it on the tensors' versions).
  */
 /* floats of the packed image: 2*C*C*16 (fp32 image; C % 16 == 0, else 0 = no packed path), plus for C % 32 == 0 the
- * three-part bf16 image, (2*C/16) * (C/32 + 1) * 12288 */
+ * two-part fp16 image, (2*C/16) * (C/32 + 1) * 8192, and its four-word header */
 long long smot_emm_tower_pack_floats(int C);
 /* which form of the packed towers N tracks get (reporting: bench.py, tools/): 0 = none (the direct kernel: C not a power
  * of two, C % 32 != 0, C > 512 or a response map other than 16 x 16 / 29 x 29), 1 = one 16-channel tile per workgroup
- * (fp32), 2 = two tiles (fp32), 3 = two tiles, three-part bf16 operands */
+ * (fp32; measurement library only since ABI 13), 2 = two tiles (fp32), 3 = two tiles, two-part fp16 operands */
 int smot_emm_tower_form(int N, int C, int Ho);
 int smot_emm_tower_pack(const float* cls_tower_w, const float* reg_tower_w, int C, float* packed,
                         smot_stream_t stream);

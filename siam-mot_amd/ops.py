@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm.so")
 # measurement build (-DSMOT_DEBUG): older kernel generations, A/B switches, timing ablations.  Never loaded
 # implicitly — only through ``debug_library()`` (tools/, A/B tests).
 DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libsmot_emm_debug.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 UP_SCALE = 16          # reference track_core.py:69-73
 
 
@@ -851,7 +851,7 @@ SPECULATION = _collections.Counter()
 
 TOWER_FORMS = {0: "direct fp32 (no packed path)", 1: "Winograd, one 16-channel tile per workgroup, fp32 matrix instructions",
                2: "Winograd, two tiles per workgroup, fp32 matrix instructions",
-               3: "Winograd, two tiles per workgroup, three-part bf16 operands on v_mfma_f32_16x16x32_bf16"}
+               3: "Winograd, two tiles per workgroup, two-part fp16 operands on v_mfma_f32_16x16x32_f16"}
 
 
 def tower_form(n, channels, ho=16):
