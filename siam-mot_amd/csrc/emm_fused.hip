@@ -30,7 +30,8 @@ int sr_xcorr_fused_impl(const float* const* feats, const int* heights, const int
                         hipStream_t st, const int** hint_status, float* plane_max);
 int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                          const float* scales, int num_levels, int C, const float* boxes, const float* sr,
-                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st);
+                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st,
+                         float* plane_max);
 }  // namespace smot
 
 static inline bool p12_form3(int N, int C, int ho) { return smot_emm_tower_form(N, C, ho) == 3; }
@@ -79,9 +80,11 @@ extern "C" int smot_emm_track_fwd(const float* const* feats, const int* heights,
         plane_max = pm;
     } else if (rx == 35 && rz == 7 && sampling_ratio == 2 && !no_fuse) {
         // the second yaml family's shape: gathers + correlation in one kernel (sr_xcorr_small.hip), same arithmetic
+        float* pm = (C <= 7 * ho * ho && p12_form3(N, C, ho)) ? logits : nullptr;
         rc = sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
-                                  sampling_ratio, resp, (hipStream_t)stream);
+                                  sampling_ratio, resp, (hipStream_t)stream, pm);
         if (rc) return rc;
+        plane_max = pm;
     } else {
         rc = smot_roi_align_levels_fwd(feats, heights, widths, pad_cells, scales, num_levels, C, sr, boxes, N, rx, rx,
                                        sampling_ratio, x, nullptr, stream);

@@ -21,6 +21,7 @@
 //              one 10-float segment feeds 28 FMAs; plane after plane.
 #include "roi_common.h"
 #include "knobs.h"
+#include "tower_common.h"      // plane_max_wave
 
 namespace smot {
 
@@ -29,7 +30,7 @@ constexpr int SX_CH = 4;             // channels per workgroup
 template <int RX, int RZ, int G>
 __global__ void __launch_bounds__(256)
 sr_xcorr_gather_kernel(LevelParams P, int C, const float* __restrict__ rois, const float* __restrict__ level_boxes,
-                       const float* __restrict__ z, float* __restrict__ resp) {
+                       const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ plane_max) {
     constexpr int HO = RX - RZ + 1;
     constexpr int NQ = (HO + 3) / 4;                     // column groups per response row
     constexpr int XS = ((4 * NQ + RZ - 1 + 3) / 4) * 4;  // padded LDS row of a pooled plane (floats)
@@ -41,6 +42,10 @@ sr_xcorr_gather_kernel(LevelParams P, int C, const float* __restrict__ rois, con
     __shared__ int y_lo[NS], y_hi[NS], x_lo[NS], x_hi[NS];
     __shared__ float wy_lo[NS], wy_hi[NS], wx_lo[NS], wx_hi[NS];
     __shared__ int wbound[4];              // ymin, ymax, xmin, xmax of the cells with non-zero weight
+    __shared__ unsigned pmax[SX_CH];       // largest |response| of the workgroup's planes (bits of a non-negative float): the
+                                           // tower kernel's split form scales a track's response by a power of two chosen
+                                           // from them (tower_wino.hip) — written here, no launch of its own
+    if (threadIdx.x < SX_CH) pmax[threadIdx.x] = 0u;
 
     const int r = blockIdx.x;
     const float* roi = rois + (size_t)r * 4;
@@ -107,6 +112,7 @@ sr_xcorr_gather_kernel(LevelParams P, int C, const float* __restrict__ rois, con
     if (ymax < ymin || xmax < xmin) {
         // every sample lies in the virtual zero border: pooled planes are exact zeros -> zero responses
         for (int e = threadIdx.x; e < nch * HO * HO; e += 256) resp[((size_t)r * C + c0) * (HO * HO) + e] = 0.0f;
+        if (plane_max != nullptr && (int)threadIdx.x < nch) plane_max[(size_t)r * C + c0 + threadIdx.x] = 0.0f;
         return;
     }
     // re-base the tables: map-relative row offsets; a weightless entry points at a cell inside the window
@@ -223,55 +229,70 @@ sr_xcorr_gather_kernel(LevelParams P, int C, const float* __restrict__ rois, con
 
     // ---- correlation: xcorr_dw_rowpatch_kernel's arithmetic, plane after plane ------------------------------------------
     const int i = threadIdx.x / NQ, jq = threadIdx.x - i * NQ;
-    if (i >= HO) return;
+    const bool row_live = i < HO;
     for (int cl = 0; cl < nch; ++cl) {
-        float tap[RZ * RZ];
+        float pm = 0.0f;
+        if (row_live) {
+            float tap[RZ * RZ];
 #pragma unroll
-        for (int t = 0; t < RZ * RZ; ++t) tap[t] = zs[cl][t];
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int t = 0; t < RZ * RZ; ++t) tap[t] = zs[cl][t];
+            float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int u = 0; u < RZ; ++u) {
-            const float* row = xs[cl] + (i + u) * XS + 4 * jq;
-            float seg[((SEG + 3) / 4) * 4];
+            for (int u = 0; u < RZ; ++u) {
+                const float* row = xs[cl] + (i + u) * XS + 4 * jq;
+                float seg[((SEG + 3) / 4) * 4];
 #pragma unroll
-            for (int q = 0; q < (SEG + 3) / 4; ++q) {
-                const float4 v4 = *reinterpret_cast<const float4*>(row + 4 * q);
-                seg[4 * q + 0] = v4.x;
-                seg[4 * q + 1] = v4.y;
-                seg[4 * q + 2] = v4.z;
-                seg[4 * q + 3] = v4.w;
+                for (int q = 0; q < (SEG + 3) / 4; ++q) {
+                    const float4 v4 = *reinterpret_cast<const float4*>(row + 4 * q);
+                    seg[4 * q + 0] = v4.x;
+                    seg[4 * q + 1] = v4.y;
+                    seg[4 * q + 2] = v4.z;
+                    seg[4 * q + 3] = v4.w;
+                }
+#pragma unroll
+                for (int v = 0; v < RZ; ++v)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) acc[o] = fmaf(seg[o + v], tap[u * RZ + v], acc[o]);
             }
+            float* dst = resp + ((size_t)r * C + c0 + cl) * (HO * HO) + i * HO + 4 * jq;
 #pragma unroll
-            for (int v = 0; v < RZ; ++v)
-#pragma unroll
-                for (int o = 0; o < 4; ++o) acc[o] = fmaf(seg[o + v], tap[u * RZ + v], acc[o]);
+            for (int o = 0; o < 4; ++o)
+                if (4 * jq + o < HO) {
+                    dst[o] = acc[o];
+                    pm = plane_max_step(pm, acc[o]);
+                }
         }
-        float* dst = resp + ((size_t)r * C + c0 + cl) * (HO * HO) + i * HO + 4 * jq;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (4 * jq + o < HO) dst[o] = acc[o];
+        if (plane_max != nullptr) {            // (all 64 lanes of every wave arrive here: the wave reduction needs them)
+            pm = plane_max_wave(pm);
+            if ((threadIdx.x & 63) == 0) atomicMax(&pmax[cl], __float_as_uint(pm));
+        }
+    }
+    if (plane_max != nullptr) {
+        __syncthreads();
+        if ((int)threadIdx.x < nch) plane_max[(size_t)r * C + c0 + threadIdx.x] = __uint_as_float(pmax[threadIdx.x]);
     }
 }
 
 // (35, 7, sampling ratio 2) only; returns SMOT_ERR_UNSUPPORTED for anything else (the caller runs the two-kernel form).
 int launch_sr_xcorr_gather(const LevelParams& P, int C, const float* sr, const float* boxes, const float* templates, int N,
-                           int rx, int rz, int sampling_ratio, float* resp, hipStream_t st) {
+                           int rx, int rz, int sampling_ratio, float* resp, hipStream_t st, float* plane_max) {
     if (!(rx == 35 && rz == 7 && sampling_ratio == 2)) return SMOT_ERR_UNSUPPORTED;
     if (N == 0) return SMOT_OK;
     dim3 grid(N, (C + SX_CH - 1) / SX_CH);
     timer_mark(0, 0, st);
-    SMOT_LAUNCH((sr_xcorr_gather_kernel<35, 7, 2>), grid, dim3(256), 0, st, P, C, sr, boxes, templates, resp);
+    SMOT_LAUNCH((sr_xcorr_gather_kernel<35, 7, 2>), grid, dim3(256), 0, st, P, C, sr, boxes, templates, resp, plane_max);
     timer_mark(0, 1, st);
     return check_launch("sr_xcorr_gather");
 }
 
 int sr_xcorr_gather_impl(const float* const* feats, const int* heights, const int* widths, const int* pad_cells,
                          const float* scales, int num_levels, int C, const float* boxes, const float* sr,
-                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st) {
+                         const float* templates, int N, int rx, int rz, int sampling_ratio, float* resp, hipStream_t st,
+                         float* plane_max) {
     LevelParams P;
     const int rc = fill_level_params(&P, feats, heights, widths, pad_cells, scales, num_levels, "sr_xcorr_gather");
     if (rc) return rc;
-    return launch_sr_xcorr_gather(P, C, sr, boxes, templates, N, rx, rz, sampling_ratio, resp, st);
+    return launch_sr_xcorr_gather(P, C, sr, boxes, templates, N, rx, rz, sampling_ratio, resp, st, plane_max);
 }
 
 }  // namespace smot
@@ -291,5 +312,5 @@ extern "C" int smot_sr_xcorr_gather_fwd(const float* const* feats, const int* he
     if (N == 0) return SMOT_OK;
     SMOT_REQUIRE(boxes && sr && templates && resp, "sr_xcorr_gather: null pointer");
     return sr_xcorr_gather_impl(feats, heights, widths, pad_cells, scales, num_levels, C, boxes, sr, templates, N, rx, rz,
-                                sampling_ratio, resp, (hipStream_t)stream);
+                                sampling_ratio, resp, (hipStream_t)stream, nullptr);
 }
