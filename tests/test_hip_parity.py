@@ -293,10 +293,11 @@ def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
     """The Winograd tower with two 16-channel tiles per workgroup against the one-tile form — C in {32, 64, 96, 128, 256},
     odd track counts included:
       * fp32 form of two tiles (every B operand feeds two MFMAs) == one tile, bit for bit: the same accumulation order;
-      * bf16 x 3 form of two tiles (three-part operands on the bf16 matrix pipe, the default above 16 tracks): not the same
-        bits, but the same accuracy — its error against an fp64 evaluation is bounded by the fp32 form's (x 1.25 + a few
-        ulps), for C = 128 (unrolled loop) and the other channel counts (generic loop: 1, 2 and 8 K blocks);
-      * the bf16 x 3 form is deterministic across back-to-back launches (its A parts travel through LDS with hand-placed
+      * split form of two tiles (round 6: two-part fp16 operands of power-of-two-scaled values on the fp16 matrix pipe, the
+        product's form at every track count; rounds 4-5: three-part bf16): not the same bits, but the same accuracy — its
+        error against an fp64 evaluation is bounded by the fp32 form's (x 1.25 + a few ulps), for C = 128 (unrolled loop)
+        and the other channel counts (generic loop: 1, 2 and 8 K blocks);
+      * the split form is deterministic across back-to-back launches (its A parts travel through LDS with hand-placed
         waits: stale or half-landed parts would show here);
       * the product library computes what the measurement library computes with the same switches."""
     rs = np.random.RandomState(77)
@@ -314,12 +315,12 @@ def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
         assert torch.equal(two32, one), "n=%d C=%d: max diff %g" % (n, c, float((two32 - one).abs().max()))
         with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1):
             runs = [ops.emm_predictor(resp, params) for _ in range(4)]
-        assert all(torch.equal(runs[0], r) for r in runs[1:]), "n=%d C=%d: bf16 x 3 form differs between launches" % (n, c)
+        assert all(torch.equal(runs[0], r) for r in runs[1:]), "n=%d C=%d: split form differs between launches" % (n, c)
         ref = _predictor_fp64(resp, params)
         scale = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
         e32 = float(((one.double() - ref).abs() / scale).max())
         e3 = float(((runs[0].double() - ref).abs() / scale).max())
-        assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: bf16 x 3 error %.3e vs fp32 form %.3e (relative to channel scale)" % (n, c, e3, e32)
+        assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: split form error %.3e vs fp32 form %.3e (relative to channel scale)" % (n, c, e3, e32)
         assert e32 < 2e-6
     # a track with non-finite responses poisons its own outputs only (the bf16 x 3 form multiplies stale operand parts by
     # zero weights in its last partial K blocks: that must stay inside the workgroup's own track)
@@ -338,6 +339,54 @@ def test_tower_two_tile_workgroups_equal_one_tile_workgroups(ops):
     for n in (70, 130, 300):
         out = ops.emm_predictor(_d(np.repeat(one_track, n, axis=0)), params)
         assert bool((out == out[:1]).all()), "n=%d: %d copies differ from the first" % (n, int((out != out[:1]).flatten(1).any(1).sum()))
+
+
+def test_tower_split_form_scales_every_track_by_its_own_power_of_two(ops):
+    """Round 6: the split form multiplies a track's response by 2^kv (chosen from the largest |response| of the track's planes)
+    before it makes the fp16 operand parts, the weights by 2^ku (chosen from the largest |w| by the pack kernel), and takes
+    both out of the accumulators exactly.  So (i) responses of ANY magnitude fp32 can hold keep the fp32 form's accuracy —
+    1e-20 .. 1e+15, a track of zeros, weights of 1e-6 / 1e+3; (ii) a track's logits do not depend on which other tracks
+    share the launch (its scale is its own): bit-identical alone and beside a track 1e12 times larger; (iii) scaling a
+    response UP by a power of two scales nothing but the exponents: the pre-GroupNorm arithmetic is identical, so the
+    logits are bit-identical (GroupNorm is scale-free up to its epsilon, which is below fp32 resolution of the variance
+    at these magnitudes; scaled DOWN far enough the epsilon takes over — in the reference as here: accuracy only)."""
+    rs = np.random.RandomState(131)
+    boxes = np.array([[0, 0, 80, 120]], dtype=np.float32)
+    params = {k: _d(v) for k, v in gi.predictor_params(rs, 128, boxes).items()}
+    base = (rs.standard_normal((6, 128, 16, 16)) * 15.0).astype(np.float32)
+
+    def err(out, ref):
+        scale = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
+        return float(((out.double() - ref).abs() / scale).max())
+    with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=0):
+        e32 = err(ops.emm_predictor(_d(base), params), _predictor_fp64(_d(base), params))
+    for mag in (1e-20, 1e-6, 1.0, 1e6, 1e15):       # (beyond ~1e17 GroupNorm's squares overflow fp32 in ANY fp32 implementation)
+        resp = _d((base * np.float32(mag)).astype(np.float32))
+        out = ops.emm_predictor(resp, params)
+        assert bool(torch.isfinite(out).all()), "magnitude %g" % mag
+        e = err(out, _predictor_fp64(resp, params))
+        assert e <= 1.25 * e32 + 2e-7, "response magnitude %g: error %.3e vs the fp32 form's %.3e" % (mag, e, e32)
+    # mixed magnitudes in one launch, a zero track among them: every track as if it were alone
+    mixed = base.copy()
+    mixed[1] *= np.float32(2.0 ** 40)
+    mixed[2] *= np.float32(2.0 ** 17)
+    mixed[3] = 0.0
+    out = ops.emm_predictor(_d(mixed), params)
+    assert bool(torch.isfinite(out).all())
+    for t in range(6):
+        alone = ops.emm_predictor(_d(mixed[t:t + 1]), params)
+        assert torch.equal(out[t:t + 1], alone), "track %d depends on its neighbours" % t
+    plain = ops.emm_predictor(_d(base), params)
+    assert torch.equal(out[1], plain[1]) and torch.equal(out[2], plain[2]), "a power-of-two scale of the response changed the logits"
+    assert torch.equal(out[0], plain[0]) and torch.equal(out[4], plain[4])
+    # weights far from 1: the pack kernel's scale
+    for wmag in (1e-6, 1e3):
+        p2 = dict(params)
+        for k in ("cls_tower.0.weight", "reg_tower.0.weight"):
+            p2[k] = (params[k] * wmag).contiguous()
+        o2 = ops.emm_predictor(_d(base), p2)
+        e = err(o2, _predictor_fp64(_d(base), p2))
+        assert bool(torch.isfinite(o2).all()) and e <= 1.25 * e32 + 2e-7, "tower weights x %g: error %.3e vs %.3e" % (wmag, e, e32)
 
 
 def test_blocked_winograd_towers_for_the_29x29_response(ops):
@@ -367,11 +416,11 @@ def test_blocked_winograd_towers_for_the_29x29_response(ops):
         # and what the product computes when it picks two tiles
         with ops.debug_library(SMOT_TOWER_OCT=2, SMOT_TOWER_BF3=1):
             runs = [ops.emm_predictor(resp, params) for _ in range(3)]
-        assert all(torch.equal(runs[0], r) for r in runs[1:]), "n=%d C=%d: bf16 x 3 form differs between launches" % (n, c)
+        assert all(torch.equal(runs[0], r) for r in runs[1:]), "n=%d C=%d: split form differs between launches" % (n, c)
         ref = _predictor_fp64(resp, params)
         s64 = ref.abs().amax(dim=(0, 2, 3), keepdim=True).clamp_min(1e-30)
         e32, e3 = (float(((t.double() - ref).abs() / s64).max()) for t in (one, runs[0]))
-        assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: bf16 x 3 error %.3e vs fp32 form %.3e" % (n, c, e3, e32)
+        assert e3 <= 1.25 * e32 + 2e-7, "n=%d C=%d: split form error %.3e vs fp32 form %.3e" % (n, c, e3, e32)
         assert torch.equal(blocked, runs[0]) or torch.equal(blocked, one), "n=%d C=%d" % (n, c)
         with ops.debug_library(SMOT_TOWER_DIRECT=1):
             assert torch.equal(ops.emm_predictor(resp, params), direct)
