@@ -205,7 +205,6 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
               unsigned long long* __restrict__ cand, FinalizeArgs F) {
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [7][Ho][Ho]
     __shared__ unsigned long long wbest[4 * SPLIT];
-    __shared__ unsigned wflag;
     __shared__ unsigned nom[DEC_NOM];     // flat indices of the cells nominated for exact re-scoring
     __shared__ int nom_cnt;
     if (threadIdx.x == 0) nom_cnt = 0;
@@ -418,32 +417,38 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
 
     DC_TRACE(5)
     // ---- publish the band's record (write-through 8-byte stores), take a ticket ---------------------------------
+    // Round 6: ONE wave does all of it — the wave that holds the band's winner (keys are unique per cell: exactly one; wave
+    // 0 when the band has no cell) stores the record, drains its stores and takes the workgroup's ticket itself; the other
+    // seven waves are done.  (Rounds 2-5: stores, drain, a barrier, the ticket by thread 0, a flag through LDS, another
+    // barrier, then wave 0 went on: two barriers and an LDS round trip on the last arriver's path for an ordering that only
+    // ever concerned the ONE storing wave — the hand-off recipe R1 asks every STORING wave to drain before the ticket.)
     gu64_t* rec = (gu64_t*)(cand + ((size_t)n * nband + blockIdx.y) * DEC_REC);
-    const bool winner = (we != 0ull) && (ebest == we) && (threadIdx.x & 63) == 0;   // keys are unique per cell: one wave
-    if (we == 0ull && threadIdx.x == 0) __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (winner) {
-        auto pk = [](float a, float b) {
-            return ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
-        };
-        __hip_atomic_store(rec + 1, pk(ev[0], ev[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec + 2, pk(ev[2], ev[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec + 3, pk(ev[4], ev[5]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec + 4, pk(ev[6], 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(rec, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool publisher = (we != 0ull) ? (ebest == we) : (wave == 0);              // wave-uniform
+    if (!publisher) return;
+    const int lane = threadIdx.x & 63;
+    if (lane == 0) {
+        if (we == 0ull) {
+            __hip_atomic_store(rec, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            auto pk = [](float a, float b) {
+                return ((unsigned long long)__float_as_uint(b) << 32) | (unsigned long long)__float_as_uint(a);
+            };
+            __hip_atomic_store(rec + 1, pk(ev[0], ev[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 2, pk(ev[2], ev[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 3, pk(ev[4], ev[5]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + 4, pk(ev[6], 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec, we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    // every storing wave drains its stores before the workgroup's ticket is taken (hand-off recipe R1)
+    // the storing wave drains its stores before it takes the ticket (hand-off recipe R1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add((gu32_t*)(F.ticket + n), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        wflag = (old == (unsigned)(nband - 1)) ? 1u : 0u;
-    }
-    __syncthreads();
-    DC_TRACE(6)
-    if (wflag == 0u || threadIdx.x >= 64) return;
+    unsigned old = 0u;
+    if (lane == 0) old = __hip_atomic_fetch_add((gu32_t*)(F.ticket + n), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+    if (F.trace && lane == 0) F.trace[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 8 + 6] = (long long)__builtin_amdgcn_s_memtime();
+    if (old != (unsigned)(nband - 1)) return;
 
     // ---- last workgroup of the track: arg-max over the bands' exact winners, box, confidence --------------------
-    const int lane = threadIdx.x;
     const gu64_t* recs = (const gu64_t*)(cand + (size_t)n * nband * DEC_REC);
     // every lane fetches the WHOLE record of its band(s) — key and the winner's eight values — in one round trip: the
     // lane that holds the winning key then has the values in registers (no second dependent fetch at the kernel's end)
