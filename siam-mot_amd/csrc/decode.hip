@@ -150,9 +150,14 @@ __device__ __forceinline__ float cell_score_fast(const float* v, float inv_bw, f
     const float b = v[3] * inv_bh;
     const float ab = a * b;
     const float r = fast_rcp(ab);
-    const bool pa = (a >= 1.0f) || (a < 0.0f && a >= -1.0f);
-    const bool pb = (b >= 1.0f) || (b < 0.0f && b >= -1.0f);
-    const float sws = pa ? (pb ? ab : a * a * r) : (pb ? b * b * r : r);
+    const bool pa = (a >= 1.0f) | ((a < 0.0f) & (a >= -1.0f));        // (bitwise: no short-circuit branches in the walk)
+    const bool pb = (b >= 1.0f) | ((b < 0.0f) & (b >= -1.0f));
+    // all four candidates are computed and selected (three v_cndmask): written as a nested conditional on products hipcc
+    // turned it into exec-mask branches — ~15 scalar instructions per cell in the walk's inner loop
+    const float aar = a * a * r, bbr = b * b * r;
+    float s_pa = pb ? ab : aar, s_na = pb ? bbr : r;
+    asm volatile("" : "+v"(s_pa), "+v"(s_na));
+    const float sws = pa ? s_pa : s_na;
     const float pen = fast_exp(fmaf(-sws, 0.1f, 0.1f));
     return fmaf(conf * pen, D.one_minus_sigma, D.sigma * win);
 }
@@ -210,6 +215,8 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     if (threadIdx.x == 0) nom_cnt = 0;
     const int tcol = threadIdx.x & 255, part = threadIdx.x >> 8;
     __shared__ __attribute__((aligned(16))) float wy_tab[32][4];    // vertical taps of the band's rows (up <= 32)
+    __shared__ float hy_tab[32];          // the window's row factor hann[Y] of the band's rows (round 6: the walk fetched it from
+                                          // global memory per cell, with a vmcnt wait inside its loop)
     __shared__ float dv[4][4][64];     // ranking planes {cls0-cls1, center, l+r, t+b} of the band's 4 source rows
     const int n = blockIdx.x;
     const int f = (int)blockIdx.y - 1;                 // bicubic source row of this band
@@ -257,6 +264,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         wy_tab[threadIdx.x][1] = w4[1];
         wy_tab[threadIdx.x][2] = w4[2];
         wy_tab[threadIdx.x][3] = w4[3];
+        hy_tab[threadIdx.x] = hann[y_begin + threadIdx.x];
     }
     __syncthreads();
 
@@ -306,7 +314,7 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
             float v[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
-            visit(cell_score_fast(v, inv_bw, inv_bh, hann[Y] * hx, D), Y);
+            visit(cell_score_fast(v, inv_bw, inv_bh, hy_tab[Y - y_begin] * hx, D), Y);
         }
     };
     unsigned long long best = 0ull;       // lanes without a cell carry key 0 (below every real key)
@@ -449,6 +457,11 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     if (old != (unsigned)(nband - 1)) return;
 
     // ---- last workgroup of the track: arg-max over the bands' exact winners, box, confidence --------------------
+    // (the search region and the hint's status word are requested BEFORE the records: they used to follow the arg-max over
+    // the records — a second, dependent global round trip at the very end of the kernel's critical path)
+    const float sx1 = F.sr[n * 4 + 0], sy1 = F.sr[n * 4 + 1], sx2 = F.sr[n * 4 + 2], sy2 = F.sr[n * 4 + 3];
+    const int poisoned = (F.poison != nullptr) ? *F.poison : 0;
+    __builtin_amdgcn_sched_barrier(0);
     const gu64_t* recs = (const gu64_t*)(cand + (size_t)n * nband * DEC_REC);
     // every lane fetches the WHOLE record of its band(s) — key and the winner's eight values — in one round trip: the
     // lane that holds the winning key then has the values in registers (no second dependent fetch at the kernel's end)
@@ -478,8 +491,6 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     // get_locations (track_core.py:184-225): x_k = x1 + (st+k)*((x2-x1)/(rx*up-1)), then -= pad
     const int full = F.rx * D.up;
     const int st = (F.rz / 2) * D.up;
-    const float sx1 = F.sr[n * 4 + 0], sy1 = F.sr[n * 4 + 1], sx2 = F.sr[n * 4 + 2], sy2 = F.sr[n * 4 + 3];
-    const int poisoned = (F.poison != nullptr) ? *F.poison : 0;          // (beside the search region's loads: same round trip)
     const float stride_w = div_rn(sub_rn(sx2, sx1), (float)(full - 1));
     const float stride_h = div_rn(sub_rn(sy2, sy1), (float)(full - 1));
     const float cx = sub_rn(add_rn(sx1, mul_rn((float)(st + X), stride_w)), F.pad);
