@@ -1088,6 +1088,9 @@ def main():
             "bound": "hbm", "kernel": ops.fused_kernel_name() + " (search-region ROIAlign + depthwise xcorr)",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_source,
+            # the same fraction by the bytes the counters saw instead of the algorithmic ones: at 100
+            # tracks overlapping search windows are served by L2 / MALL, so fewer bytes reach the fabric than the formula counts
+            "frac_by_counter_bytes": None if not traffic or xcorr_avg_s <= 0 else traffic / xcorr_avg_s / 1e9 / HBM_PEAK_GBS,
             # the resource that actually binds this kernel: vector-instruction issue.  A wave64
             # instruction occupies its SIMD's issue port for 4 cycles; SQ_INSTS_VALU (same counter passes and source stamp
             # as `traffic`) x 4 cycles / (256 CUs x 4 SIMDs) / clock = the time the launch needs for vector issue alone,
