@@ -23,6 +23,7 @@
 #include "roi_common.h"
 #include "xcorr_patch2.h"
 #include "xcorr_patch1.h"
+#include "xcorr_f16x2.h"
 #include "knobs.h"
 #include <type_traits>
 namespace smot { int launch_plane_absmax(const float* resp, int planes, int hw, float* pm, hipStream_t st); }   // tower_wino.hip
@@ -424,8 +425,11 @@ __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __r
     return true;
 }
 
-template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH, bool P2 = false>
-__global__ void __launch_bounds__(64 * NCH, P2 ? 4 : 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
+// MM: the correlation on the matrix pipe (xcorr_f16x2.h) — the product's form since round 6.  A plane's slot then holds its
+// image (fp32, later the two fp16 half images in place) and the even / odd Toeplitz rows of its template instead of the fp32
+// template: 9,024 B instead of 6,080 per plane, TWO workgroups per CU instead of three (76 KB of LDS each).
+template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH, bool P2 = false, bool MM = false>
+__global__ void __launch_bounds__(64 * NCH, (P2 || MM) ? 4 : 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                        const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
                        int32_t* __restrict__ levels_out, SrOut S) {
@@ -434,7 +438,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // LDS image of the one-plane-per-wave correlation (xcorr_patch1.h): row stride 40, one plane per slot
     // P2: the correlation runs on plane PAIRS with 4x2 output patches per lane (xcorr_patch2.h: half the LDS read volume
     // per FMA of the one-plane form) by waves 0..NCH/2-1; the image then has that phase's strides
-    constexpr int XS = P2 ? XP2_XS : XP1_XS, XP = P2 ? XP2_XP : 32 * XP1_XS, ZS = XP1_ZS, ZP = RZ * XP1_ZS;
+    constexpr int XS = P2 ? XP2_XS : XP1_XS, XP = P2 ? XP2_XP : 32 * XP1_XS, ZS = XP1_ZS, ZP = MM ? XH_TZ_FLOATS : RZ * XP1_ZS;
+    static_assert(!MM || (XCORR && !P2 && RX == 30 && RZ == 15), "the matrix-pipe correlation is the 30 / 15 head's");
     constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
@@ -555,7 +560,10 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int plane = n * C + c0 + wave;
     constexpr int NZ = XCORR ? (RZ * RZ + 63) / 64 : 1;
     float zreg[NZ];
-    if (XCORR && owns) {
+    float zq[4] = {0.0f, 0.0f, 0.0f, 0.0f}, isz = 1.0f;
+    if constexpr (MM) {
+        if (owns) xh_template_load(z + (size_t)plane * (RZ * RZ), lane, zq);
+    } else if (XCORR && owns) {
         const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
 #pragma unroll
         for (int t = 0; t < NZ; ++t) zreg[t] = zg[min(lane + 64 * t, RZ * RZ - 1)];
@@ -635,7 +643,10 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // measure/gpu_r04_prio.sh.  Issue arbitration is not what holds them back.)
     FX_TRACE(1)
 
-    if (XCORR && owns) {
+    if constexpr (MM) {
+        // the template's Toeplitz rows: built now, beside the pooling of the plane they will meet
+        if (owns) isz = xh_template_store(zq, reinterpret_cast<unsigned char*>(sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP), lane);
+    } else if (XCORR && owns) {
         float* zs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;    // this wave's template
 #pragma unroll
         for (int t = 0; t < NZ; ++t) {
@@ -869,9 +880,10 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                 xcorr_patch2_compute<RX, RZ, 0>(xs2, xs2 + 2 * XP, lane, resp, n * C + c0 + 2 * wave, n * C + min(C, c0 + NCH));
             }
         } else if (owns) {
-            const float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
+            float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
             const float* zs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;
-            xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane, S.plane_max);
+            if constexpr (MM) xh_correlate<RX, RZ>(xs1, reinterpret_cast<const unsigned char*>(zs1), isz, lane, resp, plane, S.plane_max);
+            else xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane, S.plane_max);
         }
     }
     FX_TRACE(4)
@@ -905,8 +917,22 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
         return;
     }
 #endif
-    SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,
-                levels_out, S);
+    if constexpr (RX == 30 && XCORR) {
+#ifdef SMOT_DEBUG
+        if (knobs().fused_abl == 8 || knobs().fused_abl == 9) {
+            // A/B (measurement library, SMOT_FUSED_ABL=8): the fp32 FMA correlation of rounds 2-5; 9: the same with 26 KB of
+            // unused dynamic LDS, i.e. at TWO workgroups per CU like the matrix form (what the third workgroup is worth)
+            SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), knobs().fused_abl == 9 ? 26000 : 0, st, P, C, rois,
+                        boxes, z, resp, out, levels_out, S);
+            return;
+        }
+#endif
+        SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR, FX_CH, false, true>), grid, dim3(512), 0, st, P, C, rois, boxes, z,
+                    resp, out, levels_out, S);
+    } else {
+        SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,
+                    levels_out, S);
+    }
 }
 
 // Separable stand-alone pooling for the two EMM pooler shapes (called by smot_roi_align_levels_fwd).

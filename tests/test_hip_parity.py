@@ -58,6 +58,29 @@ def _assert_close(got, ref, rtol, atol, what):
         what, bad.sum(), bad.size, err.max(), ref.flat[err.argmax()], np.unravel_index(err.argmax(), err.shape))
 
 
+
+# The fused kernel correlates on the matrix pipe since round 6 (two-part fp16 operands of power-of-two-scaled values,
+# fp32 accumulation: csrc/xcorr_f16x2.h), so its responses equal the stand-alone fp32 FMA kernel's to ROUNDING, not bit for
+# bit.  The bound is stated against an fp64 evaluation of the SAME pooled planes, relative to sum |x||z| of the output:
+# measured 1.0e-7 .. 3.7e-7 for the matrix form, 2.3e-7 .. 3.6e-7 for the FMA chain (measure/debug/fused_mm_check.py).
+XCORR_ERR_OVER_SUM_ABS = 6e-7
+
+
+def _assert_response_is_the_correlation(resp, pooled, z, what):
+    n, c = pooled.shape[:2]
+    x64 = pooled.double().reshape(1, n * c, pooled.shape[2], pooled.shape[3])
+    z64 = z.double().reshape(n * c, 1, z.shape[2], z.shape[3])
+    ref = torch.nn.functional.conv2d(x64, z64, groups=n * c).reshape(resp.shape)
+    den = torch.nn.functional.conv2d(x64.abs(), z64.abs(), groups=n * c).reshape(resp.shape)
+    err = (resp.double() - ref).abs()
+    assert bool(torch.isfinite(resp).all()), "%s: non-finite response" % what
+    bad = err > XCORR_ERR_OVER_SUM_ABS * den
+    assert not bool(bad.any()), "%s: %d responses off by more than %.1e * sum|x||z| (worst ratio %.3e)" % (
+        what, int(bad.sum()), XCORR_ERR_OVER_SUM_ABS, float((err / den.clamp_min(1e-300))[den > 0].max()))
+    # an all-zero plane (search region in the virtual border) gives exact zeros
+    assert float(resp[(den == 0)].abs().max() if bool((den == 0).any()) else 0.0) == 0.0
+
+
 def iou(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -817,8 +840,8 @@ def test_one_call_entry_points_equal_operator_composition(ops):
 
 def test_fused_sr_pool_xcorr(ops, golden_dir):
     """K1+K2 fused: pooled planes vs the oracle's physical-pad ROIAlign (separable factorisation: 1e-5),
-    responses bit-identical to the stand-alone xcorr kernel on those planes and within the xcorr
-    tolerance of the fp64 oracle; zero-window, odd channel tails and the wide-window slow path."""
+    responses within XCORR_ERR_OVER_SUM_ABS of an fp64 correlation of those planes (matrix-pipe form; the measurement
+    library's fp32 FMA form bit-identical to the stand-alone xcorr kernel) and within the xcorr tolerance of the reference golden; zero-window, odd channel tails and the wide-window slow path."""
     case = gi.EMM_CASES["default"]
     cfg = _cfg(case)
     inp = gi.emm_case_inputs("default")
@@ -832,7 +855,11 @@ def test_fused_sr_pool_xcorr(ops, golden_dir):
     x_ref = O.sr_pool(O.pad_features(feats_b, cfg.pad_pixels), boxes, sr, cfg.rx, cfg.scales, cfg.sampling_ratio)
     _assert_close(pooled, x_ref, 1e-5, 1e-5, "fused pooling vs oracle")
     assert float(pooled[6].abs().max()) == 0.0          # track 7: search region entirely in the virtual border
-    assert torch.equal(resp, ops.xcorr_depthwise(pooled, z.to(DEV)))
+    _assert_response_is_the_correlation(resp, pooled, z.to(DEV), "fused response vs fp64 on its own pooled planes")
+    with ops.debug_library(SMOT_FUSED_ABL=8):           # the fp32 FMA form (measurement library) is the stand-alone kernel's
+        r_fma = ops.sr_xcorr_fused([f.to(DEV) for f in feats_b], boxes.to(DEV), sr.to(DEV), z.to(DEV), cfg.rx, cfg.rz,
+                                   cfg.scales, cfg.sampling_ratio, cfg.pad_pixels)
+    assert torch.equal(r_fma, ops.xcorr_depthwise(pooled, z.to(DEV)))
     _assert_close(resp, gold["response"], 1e-4, 3e-4, "fused response vs reference golden")
     # channel counts that leave waves with one plane / none, and a track whose SR is all border
     rs = np.random.RandomState(31)
@@ -846,7 +873,7 @@ def test_fused_sr_pool_xcorr(ops, golden_dir):
         pr = O.sr_pool(O.pad_features(f, 512), b, s, 30, cfg.scales, 2)
         _assert_close(p, pr, 1e-5, 1e-5, "fused pooling C=%d" % c)
         assert float(p[2].abs().max()) == 0.0 and float(r[2].abs().max()) == 0.0
-        assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
+        _assert_response_is_the_correlation(r, p, zz.to(DEV), "fused response C=%d" % c)
     # a search region much wider than 64 cells at its level (tiny-area, extreme aspect box): slow path
     f = [_t(rs.standard_normal((1, 4, 176 // (2 ** l), 320 // (2 ** l))).astype(np.float32)) for l in range(4)]
     b = torch.tensor([[100.0, 300.0, 700.0, 312.0]])            # 600x12 px -> level 0, SR 1200 px = 300 cells wide
@@ -856,7 +883,7 @@ def test_fused_sr_pool_xcorr(ops, golden_dir):
                               return_pooled=True)
     pr = O.sr_pool(O.pad_features(f, 512), b, s, 30, cfg.scales, 2)
     _assert_close(p, pr, 1e-5, 1e-5, "fused pooling, wide window")
-    assert torch.equal(r, ops.xcorr_depthwise(p, zz.to(DEV)))
+    _assert_response_is_the_correlation(r, p, zz.to(DEV), "fused response, wide window")
     with pytest.raises(RuntimeError, match="only Rx=30"):
         ops.sr_xcorr_fused([t.to(DEV) for t in f], b.to(DEV), s.to(DEV), zz.to(DEV), 20, 5, cfg.scales, 2, 512)
 
@@ -1075,8 +1102,8 @@ def _bench_geometry(n, seed):
 @pytest.mark.parametrize("n", [30, 7])
 def test_fused_pooling_generation3_is_bitwise_generation2(ops, n):
     """Generation 3 (tables in registers, wave-uniform buffer loads, bulk gathers, plane pairs) keeps generation
-    2's arithmetic term by term: pooled planes, responses and templates must be bit-identical to the round-1
-    kernel (kept in the measurement library) at the benchmark geometry — narrow (<= 32 columns) and 33..64-column
+    2's arithmetic term by term: pooled planes and templates (and the responses of the fp32 FMA form) must be bit-identical
+    to the round-1 kernel (kept in the measurement library) at the benchmark geometry — narrow (<= 32 columns) and 33..64-column
     windows both occur."""
     feats, boxes = _bench_geometry(n, 5)
     scales = (0.25, 0.125, 0.0625, 0.03125)
@@ -1091,7 +1118,52 @@ def test_fused_pooling_generation3_is_bitwise_generation2(ops, n):
     assert torch.equal(z, z2), "template pooler: max diff %g" % float((z - z2).abs().max())
     assert torch.equal(p3, p2), "pooled planes: max diff %g" % float((p3 - p2).abs().max())
     assert torch.equal(x3, x2) and torch.equal(x3, p3)
-    assert torch.equal(r3, r2), "responses: max diff %g" % float((r3 - r2).abs().max())
+    # responses: the product correlates on the matrix pipe (rounding-level difference, bounded against fp64); its fp32 FMA
+    # form — generation 3's pooling with generation 2's correlation arithmetic — stays bit-identical to generation 2
+    _assert_response_is_the_correlation(r3, p3, z, "responses (matrix pipe)")
+    with ops.debug_library(SMOT_FUSED_ABL=8):
+        r3f = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512)
+    assert torch.equal(r3f, r2), "responses (fp32 FMA form): max diff %g" % float((r3f - r2).abs().max())
+
+
+def test_fused_matrix_pipe_correlation_scales_every_plane_by_its_own_power_of_two(ops):
+    """The matrix-pipe correlation (csrc/xcorr_f16x2.h) splits fp32 operands into two fp16 parts AFTER scaling every search
+    plane and every template by a power of two taken from its own largest value: magnitudes from 1e-20 to 1e15 in
+    neighbouring channels must all meet the fp64 bound (which is scale-free), a plane's response must not depend on its
+    neighbours' magnitudes, and scaling the feature maps by a power of two must scale the responses bit for bit."""
+    rs = np.random.RandomState(77)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    n, c = 6, 24
+    base = [rs.standard_normal((1, c, 96 // 2 ** l, 160 // 2 ** l)).astype(np.float32) for l in range(4)]
+    wh = rs.uniform(24, 200, (n, 2))
+    xy = rs.uniform(0.1, 0.9, (n, 2)) * np.array([640.0, 384.0])
+    boxes = _d(np.concatenate([xy - wh / 2, xy + wh / 2], 1).astype(np.float32))
+    sr = ops.search_region(boxes, 512, 1.0, 0)
+    z0 = rs.standard_normal((n, c, 15, 15)).astype(np.float32)
+    mag_x = (10.0 ** rs.uniform(-20, 15, c)).astype(np.float32)
+    mag_z = (10.0 ** rs.uniform(-12, 8, (n, c))).astype(np.float32)
+    mag_x[3], mag_z[:, 5] = 0.0, 0.0                       # an all-zero search plane, an all-zero template
+    feats = [_d(f * mag_x[None, :, None, None]) for f in base]
+    z = _d(z0 * mag_z[:, :, None, None])
+    r, p = ops.sr_xcorr_fused(feats, boxes, sr, z, 30, 15, scales, 2, 512, return_pooled=True)
+    _assert_response_is_the_correlation(r, p, z, "channels of magnitudes 1e-20 .. 1e15")
+    assert float(r[:, 3].abs().max()) == 0.0 and float(r[:, 5].abs().max()) == 0.0
+    # every plane on its own: the same planes among neighbours of magnitude one
+    feats1 = [_d(f) for f in base]
+    z1 = _d(z0)
+    r1 = ops.sr_xcorr_fused(feats1, boxes, sr, z1, 30, 15, scales, 2, 512)
+    for ch in (0, 7, 19):
+        lone_f = [f.clone() for f in feats1]
+        lone_z = z1.clone()
+        for f, g in zip(lone_f, feats):
+            f[:, ch] = g[:, ch]
+        lone_z[:, ch] = z[:, ch]
+        assert torch.equal(ops.sr_xcorr_fused(lone_f, boxes, sr, lone_z, 30, 15, scales, 2, 512)[:, ch], r[:, ch]), \
+            "channel %d's response depends on its neighbours' magnitudes" % ch
+    # powers of two go through bit for bit (pooling, scaling and the split all commute with them)
+    for k in (-30, 17, 40):
+        rk = ops.sr_xcorr_fused([f * (2.0 ** k) for f in feats1], boxes, sr, z1 * (2.0 ** -7), 30, 15, scales, 2, 512)
+        assert torch.equal(rk, r1 * (2.0 ** (k - 7))), "2^%d" % k
 
 
 @pytest.mark.parametrize("n", [1, 2, 30, 65, 100, 130, 260])
@@ -1346,7 +1418,9 @@ def test_fused_pooling_odd_channel_counts_and_wide_windows(ops):
         _assert_close(z, z_ref, 1e-5, 1e-5, "template pooling, C=%d" % C)
         r, p = ops.sr_xcorr_fused(fd, _d(boxes), _d(sr), z, 30, 15, scales, 2, 64, return_pooled=True)
         assert torch.equal(p, x)
-        assert torch.equal(r, ops.xcorr_depthwise(x, z))
+        _assert_response_is_the_correlation(r, x, z, "fused response, C=%d" % C)
+        with ops.debug_library(SMOT_FUSED_ABL=8):
+            assert torch.equal(ops.sr_xcorr_fused(fd, _d(boxes), _d(sr), z, 30, 15, scales, 2, 64), ops.xcorr_depthwise(x, z))
 
 
 def _random_decode_case(rs, n, logit_scale):

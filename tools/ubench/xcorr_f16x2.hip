@@ -27,7 +27,8 @@ constexpr int XP = 30 * XS;          // floats of one search plane
 constexpr int XH_ROW = 40;           // halves per row of the fp16 image (80 B: rows 20 dwords apart -> conflict-free b128 reads)
 constexpr int ZT_ROW = 48;           // halves per Toeplitz row: index q = t + 16, t = c - x in [-15, 31]
 constexpr int ZT_BYTES = 2 * 15 * ZT_ROW * 2;      // two parts
-constexpr int PLANE_BYTES = XP * 4 + ZT_BYTES;     // x image (fp32, later the two half images) | Toeplitz rows
+constexpr int TZ_AREA = 3904;                      // MODE 4's even / odd Toeplitz rows (TZ_BYTES below)
+constexpr int PLANE_BYTES = XP * 4 + TZ_AREA;      // x image (fp32, later the two half images) | Toeplitz rows
 
 __device__ __forceinline__ float wave_absmax(float v) {
 #define ROR(N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (N), 0xf, 0xf, false))
@@ -164,6 +165,136 @@ __device__ __forceinline__ void xcorr_f16x2_wave(float* xs, const float* zs, uns
     for (int r = 0; r < 4; ++r) o[r * 16] = ((acc0[r] + acc1[r]) + acc2[r]) * us;
 }
 
+
+// ---- MODE 4: the same 45 matrix instructions fed WITHOUT unaligned vector reads ---------------------------------------
+// What made MODE 1 slow: a ds_read_b128 that is not 16-byte aligned is served lane by lane (~64 LDS cycles instead of 4).
+//   * A (search plane): the two half images share the fp32 image's rows (pitch 160 B: part 1 at bytes 0..63, part 2 at
+//     64..127) — 16-byte aligned ds_read_b128 at a pitch of 40 dwords, conflict-free for the b128 lane groups;
+//   * B (Toeplitz windows of a template row): every row is kept TWICE, as dwords of halves (2p, 2p+1) and of halves
+//     (2p+1, 2p+2); a lane takes the copy its window's parity asks for and reads FOUR ALIGNED DWORDS (two ds_read2_b32).
+//     Rows are clamped to the 32 halves a window can meet a template value in (windows further out read zeros anyway):
+//     2 copies x 2 parts x 15 rows x 64 B = 3,840 B per plane; the odd copy sits 16 banks away from the even one, so the
+//     two halves of a lane group never meet on a bank.
+constexpr int TZ_ROW = 64;                         // bytes per clamped Toeplitz row (32 halves)
+constexpr int TZ_ODD = (2 * 15 * 16 + 16) * 4;     // byte offset of the odd copies (== 16 dwords mod 32)
+constexpr int TZ_BYTES = TZ_ODD + 2 * 15 * TZ_ROW;
+template <int ABL>
+__device__ __forceinline__ void xcorr_f16x2_eo_wave(float* xs, const float* zs, unsigned char* tz, int lane, float* __restrict__ out, int plane) {
+    const f16x4 negI = __builtin_bit_cast(f16x4, (u32x2){(lane & 3) == 0 ? 0x0000BC00u : ((lane & 3) == 1 ? 0xBC000000u : 0u),
+                                                         (lane & 3) == 2 ? 0x0000BC00u : ((lane & 3) == 3 ? 0xBC000000u : 0u)});
+    f32x4 xv[4];
+    int prow[8], pcol[8];
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int p = lane + 64 * t;
+        const bool live = p < 450;
+        const int r = live ? (p * 4370) >> 16 : 0, c2 = live ? p - r * 15 : 0;
+        prow[t] = r; pcol[t] = c2;
+        const float2 v = *reinterpret_cast<const float2*>(xs + r * XS + 2 * c2);
+        xv[t >> 1][(t & 1) * 2] = live ? v.x : 0.0f;
+        xv[t >> 1][(t & 1) * 2 + 1] = live ? v.y : 0.0f;
+        m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+    }
+    float zv[4];
+    float mz = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int e = lane + 64 * t;
+        const int i = e < 225 ? (e * 4370) >> 16 : 0, j = e < 225 ? e - i * 15 : 0;
+        zv[t] = e < 225 ? zs[i * ZS + j] : 0.0f;
+        mz = fmaxf(mz, fabsf(zv[t]));
+    }
+    float sx, isx, sz, isz;
+    pow2_scale(wave_absmax(m), &sx, &isx);
+    pow2_scale(wave_absmax(mz), &sz, &isz);
+    unsigned xh1[8], xh2[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 v = xv[g] * sx;
+        const unsigned a0 = CVT(v[0], v[1]), a1 = CVT(v[2], v[3]);
+        v = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(f16x4, (u32x2){a0, a1}), v, 0, 0, 0);
+        xh1[2 * g] = a0; xh1[2 * g + 1] = a1;
+        xh2[2 * g] = CVT(v[0], v[1]); xh2[2 * g + 1] = CVT(v[2], v[3]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {   // zeros under the Toeplitz rows
+        u32x4* z4 = reinterpret_cast<u32x4*>(tz);
+        for (int e = lane; e < TZ_BYTES / 16; e += 64) z4[e] = (u32x4){0u, 0u, 0u, 0u};
+    }
+    unsigned* xh = reinterpret_cast<unsigned*>(xs);                 // row r: dwords 0..15 part 1, 16..31 part 2 (pitch 40)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (lane + 64 * t < 450) {
+            xh[prow[t] * XS + pcol[t]] = xh1[t];
+            xh[prow[t] * XS + 16 + pcol[t]] = xh2[t];
+        }
+    }
+    if (lane < 60) xh[(lane >> 1) * XS + 15 + 16 * (lane & 1)] = 0u;      // columns 30, 31 of both parts
+    {
+        f32x4 v = {zv[0] * sz, zv[1] * sz, zv[2] * sz, zv[3] * sz};
+        const unsigned a0 = CVT(v[0], v[1]), a1 = CVT(v[2], v[3]);
+        v = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(f16x4, (u32x2){a0, a1}), v, 0, 0, 0);
+        const unsigned b0 = CVT(v[0], v[1]), b1 = CVT(v[2], v[3]);
+        const unsigned short h1[4] = {(unsigned short)a0, (unsigned short)(a0 >> 16), (unsigned short)a1, (unsigned short)(a1 >> 16)};
+        const unsigned short h2[4] = {(unsigned short)b0, (unsigned short)(b0 >> 16), (unsigned short)b1, (unsigned short)(b1 >> 16)};
+        unsigned short* t16 = reinterpret_cast<unsigned short*>(tz);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int e = lane + 64 * t;
+            if (e < 225) {
+                const int i = (e * 4370) >> 16, j = e - i * 15;
+                // template value j of row i sits at local half 8 + j of the even copy and 7 + j of the odd one
+                t16[i * 32 + 8 + j] = h1[t];
+                t16[(15 + i) * 32 + 8 + j] = h2[t];
+                t16[TZ_ODD / 2 + i * 32 + 7 + j] = h1[t];
+                t16[TZ_ODD / 2 + (15 + i) * 32 + 7 + j] = h2[t];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int y = lane & 15, kq = lane >> 4;
+    const unsigned a_addr = (unsigned)(size_t)xs + (unsigned)(y * XS * 4 + kq * 16);                  // + i * 160 (+ 64 for part 2)
+    int sw = 8 * kq - y + 16;                       // first half of the lane's window in the 48-half row
+    sw = sw < 8 ? 8 : (sw > 31 ? 31 : sw);
+    const int loc = sw - 8;                         // local half in the clamped row
+    const unsigned b_addr = (unsigned)(size_t)tz + (unsigned)((loc & 1) ? TZ_ODD + ((loc - 1) >> 1) * 4 : (loc >> 1) * 4);
+    const unsigned b_addr2 = b_addr + 15 * TZ_ROW;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    u32x4 A1[2], A2[2];
+    u32x2 B1[2][2], B2[2][2];
+#define RD(I, S)                                                                                                   \
+    asm volatile("ds_read_b128 %0, %6 offset:%9\n\tds_read_b128 %1, %6 offset:%10\n\t"                             \
+                 "ds_read2_b32 %2, %7 offset0:%11 offset1:%12\n\tds_read2_b32 %3, %7 offset0:%13 offset1:%14\n\t"  \
+                 "ds_read2_b32 %4, %8 offset0:%11 offset1:%12\n\tds_read2_b32 %5, %8 offset0:%13 offset1:%14"      \
+                 : "=&v"(A1[S]), "=&v"(A2[S]), "=&v"(B1[S][0]), "=&v"(B1[S][1]), "=&v"(B2[S][0]), "=&v"(B2[S][1])  \
+                 : "v"(a_addr), "v"(b_addr), "v"(b_addr2), "n"((I) * XS * 4), "n"((I) * XS * 4 + 64),              \
+                   "n"((I) * 16), "n"((I) * 16 + 1), "n"((I) * 16 + 2), "n"((I) * 16 + 3) : "memory");
+#define BB(X, S) __builtin_bit_cast(f16x8, (u32x4){X[S][0][0], X[S][0][1], X[S][1][0], X[S][1][1]})
+#define MM(S)                                                                                                      \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A2[S]), BB(B1, S), acc0, 0, 0, 0);     \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A1[S]), BB(B2, S), acc1, 0, 0, 0);     \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A1[S]), BB(B1, S), acc2, 0, 0, 0);
+#define STEP(I)                                                                                                    \
+    if ((I) + 1 < 15) { RD((I) + 1, ((I) + 1) & 1) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); }            \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    MM((I) & 1)                                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);
+    if (ABL != 5) {
+    RD(0, 0)
+    STEP(0) STEP(1) STEP(2) STEP(3) STEP(4) STEP(5) STEP(6) STEP(7) STEP(8) STEP(9) STEP(10) STEP(11) STEP(12) STEP(13) STEP(14)
+    }
+#undef STEP
+#undef MM
+#undef BB
+#undef RD
+    const float us = isx * isz;
+    float* o = out + (size_t)plane * 256 + (lane >> 4) * 4 * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * 16] = ((acc0[r] + acc1[r]) + acc2[r]) * us;
+}
+
 template <int MODE>       // 0: fp32 FMA phase of the product (xcorr_patch1_compute, LEAN), 1: fp16 x 2 on the matrix pipe
 __global__ void __launch_bounds__(512) xcorr_kernel(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ out, int planes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,12 +302,27 @@ __global__ void __launch_bounds__(512) xcorr_kernel(const float* __restrict__ x,
     const int plane = blockIdx.x * 8 + wave;
     if (plane >= planes) return;
     float* xs = reinterpret_cast<float*>(smem + wave * (PLANE_BYTES + 15 * ZS * 4));
-    float* zs = xs + XP + ZT_BYTES / 4;
+    float* zs = xs + XP + TZ_AREA / 4;
     unsigned short* zt = reinterpret_cast<unsigned short*>(xs + XP);
-    for (int e = lane; e < 900; e += 64) xs[(e / 30) * XS + e % 30] = x[(size_t)plane * 900 + e];
-    for (int e = lane; e < 225; e += 64) zs[(e / 15) * ZS + e % 15] = z[(size_t)plane * 225 + e];
+    // (sources repeat every 256 planes: the staging reads stay in L2 and the phases under test dominate the launch)
+    {
+        const float* xg = x + (size_t)(plane & 255) * 900;
+        const float* zg = z + (size_t)(plane & 255) * 225;
+        float xr[15], zr[4];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) xr[t] = xg[min(lane + 64 * t, 899)];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) zr[t] = zg[min(lane + 64 * t, 224)];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) { const int e = lane + 64 * t; if (e < 900) xs[(e / 30) * XS + e % 30] = xr[t]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int e = lane + 64 * t; if (e < 225) zs[(e / 15) * ZS + e % 15] = zr[t]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if (MODE == 6) { out[(size_t)plane * 256 + lane] = xs[lane] + zs[lane]; return; }      // ablation: staging only
+    static_assert(TZ_BYTES <= TZ_AREA && ZT_BYTES <= TZ_AREA, "Toeplitz area");
     if (MODE == 0) smot::xcorr_patch1_compute<30, 15, true>(xs, zs, lane, out, plane);
+    else if (MODE >= 4) xcorr_f16x2_eo_wave<MODE>(xs, zs, reinterpret_cast<unsigned char*>(zt), lane, out, plane);
     else xcorr_f16x2_wave<MODE>(xs, zs, zt, lane, out, plane);
 }
 
@@ -198,8 +344,11 @@ int main(int argc, char** argv) {
     (void)hipFuncSetAttribute((const void*)xcorr_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)xcorr_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     (void)hipFuncSetAttribute((const void*)xcorr_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute((const void*)xcorr_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     const dim3 grid((planes + 7) / 8);
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 7; ++mode) {
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         float best = 1e30f;
         for (int r = 0; r < 6; ++r) {
@@ -207,7 +356,10 @@ int main(int argc, char** argv) {
             if (mode == 0) hipLaunchKernelGGL(xcorr_kernel<0>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
             else if (mode == 1) hipLaunchKernelGGL(xcorr_kernel<1>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
             else if (mode == 2) hipLaunchKernelGGL(xcorr_kernel<2>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
-            else hipLaunchKernelGGL(xcorr_kernel<3>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else if (mode == 3) hipLaunchKernelGGL(xcorr_kernel<3>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else if (mode == 4) hipLaunchKernelGGL(xcorr_kernel<4>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else if (mode == 5) hipLaunchKernelGGL(xcorr_kernel<5>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
+            else hipLaunchKernelGGL(xcorr_kernel<6>, grid, dim3(512), smem, 0, dx, dz, dout, planes);
             (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
         }
@@ -227,7 +379,7 @@ int main(int argc, char** argv) {
                     worst = fmax(worst, fabs(got - s) / sa);
                 }
         printf("{\"form\": \"%s\", \"planes\": %d, \"us\": %.2f, \"max_abs_err_over_sum_abs_xz\": %.3e, \"hip\": \"%s\"}\n",
-               mode == 0 ? "fp32 FMA phase (xcorr_patch1_compute, LEAN)" : mode == 1 ? "fp16 x 2 on the matrix pipe (45 x v_mfma_f32_16x16x32_f16)" : mode == 2 ? "ablation: conversion only (no matrix loop)" : "ablation: B windows at 4-byte alignment (wrong results)", planes, best * 1e3,
+               mode == 0 ? "fp32 FMA phase (xcorr_patch1_compute, LEAN)" : mode == 1 ? "fp16 x 2 on the matrix pipe (45 x v_mfma_f32_16x16x32_f16)" : mode == 2 ? "ablation: conversion only (no matrix loop)" : mode == 3 ? "ablation: B windows at 4-byte alignment (wrong results)" : mode == 4 ? "fp16 x 2 on the matrix pipe, aligned reads only (even / odd Toeplitz rows, 4 dwords per window)" : mode == 5 ? "ablation of the aligned form: conversion only" : "ablation: staging only (no correlation of either form)", planes, best * 1e3,
                worst, hipGetErrorString(hipGetLastError()));
     }
     return 0;
