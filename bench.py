@@ -92,7 +92,7 @@ def fused_source_sha1():
     no git history, the sources travel)."""
     import hashlib
     h = hashlib.sha1()
-    for f in ("sr_xcorr.hip", "roi_common.h", "xcorr_patch1.h", "smot_common.h"):
+    for f in ("sr_xcorr.hip", "roi_common.h", "xcorr_f16x2.h", "xcorr_patch1.h", "smot_common.h"):
         h.update(open(os.path.join(ROOT, "siam-mot_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
@@ -1100,9 +1100,10 @@ def main():
                 "issue_bound_us": valu_insts * 4.0 / 1024.0 / (CLOCK_GHZ * 1e3),
                 "frac_of_duration": valu_insts * 4.0 / 1024.0 / (CLOCK_GHZ * 1e3) / (xcorr_avg_s * 1e6),
                 "note": "static counter (profiles/xcorr_traffic.json, SQ_INSTS_VALU of a separate --pmc pass at this source "
-                        "state), not measured by this run; un-packed fp32 FMAs with three distinct operands issue at 4 cycles "
-                        "(DESIGN.md §3): with the 8.8 us start-up / pooling chain that does not overlap them this is why the "
-                        "HBM fraction above cannot reach the north star's 0.6 on this operator"},
+                        "state), not measured by this run.  Since round 6 the correlation runs on the matrix pipe (45 fp16 matrix "
+                        "instructions per plane on two-part operands instead of 900 v_fmac_f32 per lane): vector issue is no longer "
+                        "what binds the kernel — its time is the start-up / pooling chain (dependent memory round trips) plus an "
+                        "LDS-bound correlation phase (DESIGN.md §3)"},
             "algorithmic_bytes_per_launch": fused_bytes,
             "avg_launch_us": xcorr_avg_s * 1e6, "launches_timed": xcorr_launches, "timer": TIMER_NOTE,
             # an EMPTY kernel of the same launch shape bracketed by the same pair of events: an UPPER bound on the fixed cost

@@ -40,13 +40,16 @@ for n in counts:
             tr = torch.zeros(n * 16 * 8, dtype=torch.int64, device=dev)
             run(tr); torch.cuda.synchronize()
         t = tr.view(n, 16, 8).cpu().numpy().astype(np.float64)
-        ran = t[:, :, 4] > 0
+        ran = (t[:, :, 4] > 0) & (t[:, :, 0] > 0)
         d = np.diff(t[:, :, :5], axis=2)
         t0 = t[:, :, 0][ran].min()
         end = t[:, :, 4][ran]
+        starts = np.sort(t[:, :, 0][ran] - t0)
+        ends = np.sort(end - t0)
         print(json.dumps({"tracks": n, "variant": var, "same_feature_set_us": round(us, 2),
                           "phase_ticks_mean(tables,z,pool,xcorr)": [round(float(x)) for x in d[ran].mean(0)],
                           "phase_p90": [round(float(x)) for x in np.percentile(d[ran], 90, axis=0)],
-                          "phase_max": [int(x) for x in d[ran].max(0)], "span": int(end.max() - t0),
-                          "start_spread": int(t[:, :, 0][ran].max() - t0), "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
+                          "phase_max": [int(x) for x in d[ran].max(0)], "span": int(end.max() - t0), "workgroups_traced": int(ran.sum()),
+                          "start_percentiles(50,90,100)": [int(np.percentile(starts, q)) for q in (50, 90, 100)],
+                          "end_percentiles(50,90,99,100)": [int(np.percentile(ends, q)) for q in (50, 90, 99, 100)], "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
                           "total_max": int((t[:, :, 4] - t[:, :, 0])[ran].max())}), flush=True)

@@ -428,8 +428,9 @@ __device__ __forceinline__ bool fx_assign(const LevelParams& P, const float* __r
 // MM: the correlation on the matrix pipe (xcorr_f16x2.h) — the product's form since round 6.  A plane's slot then holds its
 // image (fp32, later the two fp16 half images in place) and the even / odd Toeplitz rows of its template instead of the fp32
 // template: 9,024 B instead of 6,080 per plane, TWO workgroups per CU instead of three (76 KB of LDS each).
-template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH, bool P2 = false, bool MM = false>
-__global__ void __launch_bounds__(64 * NCH, (P2 || MM) ? 4 : 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
+// MM == 2: the LEAN layout of the same (xl_*: 5,760 B per plane) — three workgroups per CU again.
+template <int RX, int RZ, int G, bool XCORR, int NCH = FX_CH, bool P2 = false, int MM = 0>
+__global__ void __launch_bounds__(64 * NCH, (P2 || MM == 1) ? 4 : 6) // <= 80 VGPRs: THREE workgroups (24 waves) per CU (LDS allows three)
 sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const float* __restrict__ boxes,
                        const float* __restrict__ z, float* __restrict__ resp, float* __restrict__ x_debug,
                        int32_t* __restrict__ levels_out, SrOut S) {
@@ -438,12 +439,14 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // LDS image of the one-plane-per-wave correlation (xcorr_patch1.h): row stride 40, one plane per slot
     // P2: the correlation runs on plane PAIRS with 4x2 output patches per lane (xcorr_patch2.h: half the LDS read volume
     // per FMA of the one-plane form) by waves 0..NCH/2-1; the image then has that phase's strides
-    constexpr int XS = P2 ? XP2_XS : XP1_XS, XP = P2 ? XP2_XP : 32 * XP1_XS, ZS = XP1_ZS, ZP = MM ? XH_TZ_FLOATS : RZ * XP1_ZS;
-    static_assert(!MM || (XCORR && !P2 && RX == 30 && RZ == 15), "the matrix-pipe correlation is the 30 / 15 head's");
+    constexpr int XS = P2 ? XP2_XS : (MM == 2 ? XL_XS : XP1_XS), XP = P2 ? XP2_XP : (MM == 2 ? 30 * XL_XS : 32 * XP1_XS), ZS = XP1_ZS,
+                  ZP = MM == 1 ? XH_TZ_FLOATS : (MM == 2 ? XL_TZ_FLOATS : RZ * XP1_ZS);
+    static_assert(MM == 0 || (XCORR && !P2 && RX == 30 && RZ == 15), "the matrix-pipe correlation is the 30 / 15 head's");
+    static_assert(MM != 2 || ((XP * 4) % 128 == 0 && ((2 * XP + 2 * ZP) * 4) % 128 == 0), "lean layout: 128-byte aligned plane images");
     constexpr int RH = (RX + 1) / 2;             // pooled rows per batch
     static_assert((!XCORR || RX - RZ + 1 == 16) && RX <= 32 && G == 2 && RX * XS <= XP && 2 * RH * G <= 64,
                   "specialised for pooled sizes <= 32, g = 2 (and the 30/15/16 correlation geometry)");
-    __shared__ __attribute__((aligned(16))) float sm[(NCH / 2) * (2 * XP + 2 * ZP)];
+    __shared__ __attribute__((aligned(128))) float sm[(NCH / 2) * (2 * XP + 2 * ZP)];
     __shared__ __attribute__((aligned(16))) int4 tab[2][64 + 2 * RH * G];   // y / x sample tables (+ zero pad)
     __shared__ int wbound[4];
 
@@ -561,7 +564,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     constexpr int NZ = XCORR ? (RZ * RZ + 63) / 64 : 1;
     float zreg[NZ];
     float zq[4] = {0.0f, 0.0f, 0.0f, 0.0f}, isz = 1.0f;
-    if constexpr (MM) {
+    if constexpr (MM != 0) {
         if (owns) xh_template_load(z + (size_t)plane * (RZ * RZ), lane, zq);
     } else if (XCORR && owns) {
         const float* __restrict__ zg = z + (size_t)plane * (RZ * RZ);
@@ -643,9 +646,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     // measure/gpu_r04_prio.sh.  Issue arbitration is not what holds them back.)
     FX_TRACE(1)
 
-    if constexpr (MM) {
-        // the template's Toeplitz rows: built now, beside the pooling of the plane they will meet
-        if (owns) isz = xh_template_store(zq, reinterpret_cast<unsigned char*>(sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP), lane);
+    if constexpr (MM != 0) {
+        // (the template's Toeplitz rows are built inside the pooling, behind the issue of its first batch of row loads)
     } else if (XCORR && owns) {
         float* zs = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;    // this wave's template
 #pragma unroll
@@ -704,6 +706,90 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         const int row0 = PAIR ? (wave & 1) * RH : 0;           // first pooled row of this wave (wave-uniform)
         const int nrows = PAIR ? RH : RX;
         const int nchunk = CHUNKED ? (ww + 63) >> 6 : 1;
+        if constexpr (X2 && MM == 1) {
+            // 33..64-column windows, matrix form (two workgroups per CU: 128 registers): the batches of a wave in a TWO-STAGE
+            // PIPELINE — the next batch's row loads are issued as soon as this batch's vertical taps have consumed its load
+            // registers, so that their memory round trip runs beside this batch's staging and horizontal taps instead of
+            // behind them: ONE exposed round trip per wave instead of one per batch.  Three batches of five rows (40 load
+            // registers in flight; two of eight rows spilled 30 registers).  Same loads, same FMA chains: bit-identical.
+            typedef int v2i_t __attribute__((ext_vector_type(2)));
+            constexpr int GR = (ROWS + 1) / 2, SW = 64;
+            static_assert(RH % ROWS == 0 && GR * SW <= ROWS * XS, "full batches; staging fits a batch's own rows");
+            const int wcol = min(2 * col, ww - 2);
+            const unsigned voff = (unsigned)(xmin + wcol) * 4u + lane_plane;
+            v2i_t vl[ROWS][G], vh[ROWS][G];
+            int4 ye = tab[0][min(lane + row0 * G, 63 + 2 * RH * G)];
+#define SMOT_FX_ISSUE()                                                                                             \
+            _Pragma("unroll") for (int b = 0; b < ROWS; ++b)                                                        \
+                _Pragma("unroll") for (int iy = 0; iy < G; ++iy) {                                                  \
+                    vl[b][iy] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, __builtin_amdgcn_readlane(ye.x, b * G + iy), 0); \
+                    vh[b][iy] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, __builtin_amdgcn_readlane(ye.y, b * G + iy), 0); \
+                }
+            SMOT_FX_ISSUE()
+            __builtin_amdgcn_sched_barrier(0);
+            if (owns) {
+                unsigned char* tzw = reinterpret_cast<unsigned char*>(sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP);
+                isz = xh_template_store(zq, tzw, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int r0 = row0; r0 < row0 + nrows; r0 += ROWS) {
+                const float wl = __int_as_float(ye.z), wh = __int_as_float(ye.w);
+                float cs[ROWS][NV];
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b)
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        float c_ = 0.0f;
+#pragma unroll
+                        for (int iy = 0; iy < G; ++iy) {
+                            const int e = b * G + iy;
+                            c_ = fmaf(rl_f(wl, e), __int_as_float(vl[b][iy][k]), c_);
+                            c_ = fmaf(rl_f(wh, e), __int_as_float(vh[b][iy][k]), c_);
+                        }
+                        cs[b][k] = c_;
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (r0 + ROWS < row0 + nrows) {                      // (wave-uniform) the next batch's entries and row loads
+                    ye = tab[0][min(lane + (r0 + ROWS) * G, 63 + 2 * RH * G)];
+                    SMOT_FX_ISSUE()
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float acc[ROWS];
+                float* stage = xdst + r0 * XS;
+#pragma unroll
+                for (int g0 = 0; g0 < ROWS; g0 += GR) {
+#pragma unroll
+                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) stage[(b - g0) * SW + wcol + k] = cs[b][k];
+                    float p[GR][G][2];
+#pragma unroll
+                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            p[b - g0][ix][0] = stage[(b - g0) * SW + sxl[ix]];
+                            p[b - g0][ix][1] = stage[(b - g0) * SW + sxh[ix]];
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int b = g0; b < g0 + GR && b < ROWS; ++b)
+#pragma unroll
+                        for (int ix = 0; ix < G; ++ix) {
+                            acc[b] = fmaf(hxw[ix], p[b - g0][ix][0], ix == 0 ? 0.0f : acc[b]);
+                            acc[b] = fmaf(lxw[ix], p[b - g0][ix][1], acc[b]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int b = 0; b < ROWS; ++b) {
+                    const int ph = r0 + b;
+                    if (col < RX && ph < row0 + nrows && ph < RX && mine) xdst[ph * XS + col] = acc[b] * (1.0f / (float)(G * G));
+                }
+            }
+#undef SMOT_FX_ISSUE
+            return;
+        }
 #pragma unroll 1
         for (int r0 = row0; r0 < row0 + nrows; r0 += ROWS) {
             // this block's y entries: entry (b, iy) into lane b*G + iy (constant-lane readlanes below); entries past
@@ -746,6 +832,15 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                     }
                 // fences: hipcc otherwise sinks the loads to their first use (4 loads, wait, use, next 4 loads ...)
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MM != 0) {
+                    // the template's Toeplitz rows, while the first batch of row loads is in flight (the template's own loads
+                    // were issued at the kernel's start: ~1 k cycles of conversion and LDS stores off the workgroup's chain)
+                    if (r0 == row0 && ch == 0 && owns) {
+                        unsigned char* tzw = reinterpret_cast<unsigned char*>(sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP);
+                        isz = MM == 2 ? xl_template_store(zq, tzw, lane) : xh_template_store(zq, tzw, lane);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 float cs[ROWS][NV];
 #pragma unroll
                 for (int b = 0; b < ROWS; ++b)
@@ -770,7 +865,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
                 // gather; LDS operations of one wave execute in order, so neither a wait nor a barrier is needed).
                 // Rows are processed in two groups to keep the register peak (column sums + gathered taps + tables)
                 // where the correlation phase is scheduled for.  Same values, same FMA order: bit-identical.
-                constexpr int GR = (P2 && X2) ? 3 : (ROWS + 1) / 2;
+                constexpr int GR = ((P2 || MM == 2) && X2) ? 3 : (ROWS + 1) / 2;
                 if constexpr (!CHUNKED) {
                     constexpr int SW = (X2 || !PAIR) ? 64 : 32;                      // staged floats per row (and plane)
                     static_assert(GR * SW <= (RH - (RH / ROWS) * ROWS == 0 ? ROWS : RH - (RH / ROWS) * ROWS) * XS,
@@ -851,11 +946,12 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     if (ww <= 32) {
         pool(std::true_type{}, std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
 #ifdef SMOT_DEBUG
-    } else if (ww <= 64 && S.abl == 3) {      // A/B (measurement library, SMOT_FUSED_ABL=3): one plane per wave, two batches
-        pool(std::false_type{}, std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
+    } else if (ww <= 64 && S.abl == 3 && MM != 2) {      // A/B (measurement library, SMOT_FUSED_ABL=3): one plane per wave, two batches
+        if constexpr (MM != 2) pool(std::false_type{}, std::false_type{}, std::false_type{}, std::integral_constant<int, RH>{});
 #endif
     } else if (ww <= 64) {
-        pool(std::true_type{}, std::false_type{}, std::true_type{}, std::integral_constant<int, (RH + 1) / 2>{});
+        if constexpr (MM == 1) pool(std::true_type{}, std::false_type{}, std::true_type{}, std::integral_constant<int, RH / 3>{});
+        else pool(std::true_type{}, std::false_type{}, std::true_type{}, std::integral_constant<int, (RH + 1) / 2>{});
     } else {
         pool(std::false_type{}, std::true_type{}, std::false_type{}, std::integral_constant<int, (RH + 2) / 3>{});
     }
@@ -882,7 +978,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
         } else if (owns) {
             float* xs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + (wave & 1) * XP;
             const float* zs1 = sm + (wave >> 1) * (2 * XP + 2 * ZP) + 2 * XP + (wave & 1) * ZP;
-            if constexpr (MM) xh_correlate<RX, RZ>(xs1, reinterpret_cast<const unsigned char*>(zs1), isz, lane, resp, plane, S.plane_max);
+            if constexpr (MM == 1) xh_correlate<RX, RZ>(xs1, reinterpret_cast<const unsigned char*>(zs1), isz, lane, resp, plane, S.plane_max);
+            else if constexpr (MM == 2) xl_correlate<RX, RZ>(xs1, reinterpret_cast<const unsigned char*>(zs1), isz, lane, resp, plane, S.plane_max);
             else xcorr_patch1_compute<RX, RZ, true>(xs1, zs1, lane, resp, plane, S.plane_max);
         }
     }
@@ -927,7 +1024,17 @@ static void launch_fused(dim3 grid, hipStream_t st, const LevelParams& P, int C,
             return;
         }
 #endif
-        SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR, FX_CH, false, true>), grid, dim3(512), 0, st, P, C, rois, boxes, z,
+#ifdef SMOT_DEBUG
+        if (knobs().fused_abl == 10) {
+            // A/B (SMOT_FUSED_ABL=10): the matrix form's LEAN layout (5,760 B per plane, three workgroups per CU).  Measured,
+            // same session, hinted: 15.66 vs 15.35 us at 30 tracks, 38.8 vs 39.65 at 100 — the third workgroup buys back what
+            // the extra reads and funnel shifts cost (correlation phase 7.5 k vs 5.8 k cycles per workgroup) and no more.
+            SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR, FX_CH, false, 2>), grid, dim3(512), 0, st, P, C, rois, boxes, z,
+                        resp, out, levels_out, S);
+            return;
+        }
+#endif
+        SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR, FX_CH, false, 1>), grid, dim3(512), 0, st, P, C, rois, boxes, z,
                     resp, out, levels_out, S);
     } else {
         SMOT_LAUNCH((sr_xcorr_fused9_kernel<RX, 15, 2, XCORR>), grid, dim3(512), 0, st, P, C, rois, boxes, z, resp, out,

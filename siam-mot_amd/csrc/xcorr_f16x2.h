@@ -215,6 +215,158 @@ __device__ __forceinline__ void xh_correlate(float* xs, const unsigned char* tz,
         if (lane == 0) pmax[plane] = mo;
     }
 }
+
+// ---- the LEAN layout: the same correlation in 5,760 B of LDS per plane instead of 9,024 — three workgroups per CU ----------
+// (at more than two workgroups per CU and launch — 100 tracks, the 256-channel configuration — the third resident
+// workgroup is worth more than the reads it costs)
+//   * image rows of 32 dwords (128 B, the fp32 row's own size): a row holds the 8 sixteen-byte chunks (part, kq) of both
+//     half images ROTATED by the row index — chunk c of row r at position (c + r) mod 8 — which makes the A reads
+//     conflict-free at this pitch (searched: tools notes in DESIGN.md);
+//   * ONE copy of the Toeplitz rows (dwords of halves (2p, 2p+1)): a lane reads FIVE aligned dwords and, when its window
+//     starts at an odd half, funnel-shifts neighbouring dwords by 16 bits (v_alignbit_b32 with a per-lane shift of 0 or 16).
+constexpr int XL_XS = 32;
+constexpr int XL_TZ_BYTES = 2 * 15 * XH_TZ_ROW;            // 1,920
+constexpr int XL_TZ_FLOATS = XL_TZ_BYTES / 4;
+
+__device__ __forceinline__ float xl_template_store(const float zq[4], unsigned char* tz, int lane) {
+    const int j = lane & 15, r0 = lane >> 4;
+    float zv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zv[t] = (j < 15 && r0 + 4 * t < 15) ? zq[t] : 0.0f;
+    float mz = fmaxf(fmaxf(fabsf(zv[0]), fabsf(zv[1])), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
+    float sz, isz;
+    xh_pow2_scale(xh_wave_absmax(mz), &sz, &isz);
+    {
+        xh_u32x4* z4 = reinterpret_cast<xh_u32x4*>(tz);
+#pragma unroll
+        for (int e = 0; e < (XL_TZ_BYTES / 16 + 63) / 64; ++e)
+            if (lane + 64 * e < XL_TZ_BYTES / 16) z4[lane + 64 * e] = (xh_u32x4){0u, 0u, 0u, 0u};
+    }
+    xh_f32x4 v = {zv[0] * sz, zv[1] * sz, zv[2] * sz, zv[3] * sz};
+    const unsigned a0 = SMOT_XH_CVT(v[0], v[1]), a1 = SMOT_XH_CVT(v[2], v[3]);
+    v = __builtin_amdgcn_mfma_f32_4x4x4f16(xh_neg_identity(lane), __builtin_bit_cast(xh_f16x4, (xh_u32x2){a0, a1}), v, 0, 0, 0);
+    const unsigned b0 = SMOT_XH_CVT(v[0], v[1]), b1 = SMOT_XH_CVT(v[2], v[3]);
+    const unsigned h1[4] = {a0 & 0xffffu, a0 >> 16, a1 & 0xffffu, a1 >> 16};
+    const unsigned h2[4] = {b0 & 0xffffu, b0 >> 16, b1 & 0xffffu, b1 >> 16};
+    // even j: dword (8 + j) / 2 = (Z[j], Z[j+1]) — the right neighbour's value by a row rotation; odd lanes store nothing
+    unsigned* dst = reinterpret_cast<unsigned*>(tz + r0 * XH_TZ_ROW + ((8 + j) >> 1) * 4);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned n1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)h1[t], 0x12F, 0xf, 0xf, false);
+        const unsigned n2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)h2[t], 0x12F, 0xf, 0xf, false);
+        if ((j & 1) == 0 && r0 + 4 * t < 15) {
+            dst[t * 4 * (XH_TZ_ROW / 4)] = h1[t] | (n1 << 16);
+            dst[(15 + t * 4) * (XH_TZ_ROW / 4)] = h2[t] | (n2 << 16);
+        }
+    }
+    return isz;
+}
+
+// `xs`: the plane's fp32 image at row pitch XL_XS = 32 floats, 128-BYTE ALIGNED (30 rows; overwritten by its half images)
+template <int RX, int RZ>
+__device__ __forceinline__ void xl_correlate(float* xs, const unsigned char* tz, float isz, int lane, float* __restrict__ out,
+                                             int plane, float* __restrict__ pmax) {
+    static_assert(RX == 30 && RZ == 15, "the 30 / 15 / 16 geometry");
+    constexpr int XS = XL_XS;
+    const xh_f16x4 negI = xh_neg_identity(lane);
+    const int c2 = lane & 15, r0 = lane >> 4;
+    const bool tail = r0 < 2;                                   // rows 28 + r0 exist
+    float* xrow = xs + r0 * XS + 2 * c2;
+    xh_f32x4 xv[4];
+    float m = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const bool live = c2 < 15 && (t < 7 || tail);
+        const float2 v = *reinterpret_cast<const float2*>((t < 7 || tail) ? xrow + t * 4 * XS : xrow);
+        xv[t >> 1][(t & 1) * 2] = live ? v.x : 0.0f;
+        xv[t >> 1][(t & 1) * 2 + 1] = live ? v.y : 0.0f;
+        m = fmaxf(m, live ? fmaxf(fabsf(v.x), fabsf(v.y)) : 0.0f);
+    }
+    float sx, isx;
+    xh_pow2_scale(xh_wave_absmax(m), &sx, &isx);
+    // pair c2 of row r = r0 + 4 t: part 1 is dword c2 & 3 of chunk c2 >> 2, part 2 of chunk 4 + (c2 >> 2); chunk c of row r
+    // stands at position (c + r) & 7.  (c2 >> 2) + r0 + 4 t: even t -> cb, odd t -> cb ^ 4; part 2 is always the other one.
+    const int cb = ((c2 >> 2) + r0) & 7;
+    unsigned* xe = reinterpret_cast<unsigned*>(xs) + r0 * XS + cb * 4 + (c2 & 3);           // part 1 of even t, part 2 of odd t
+    unsigned* xo = reinterpret_cast<unsigned*>(xs) + r0 * XS + (cb ^ 4) * 4 + (c2 & 3);     // part 2 of even t, part 1 of odd t
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        xh_f32x4 v = xv[g] * sx;
+        const unsigned a0 = SMOT_XH_CVT(v[0], v[1]), a1 = SMOT_XH_CVT(v[2], v[3]);
+        v = __builtin_amdgcn_mfma_f32_4x4x4f16(negI, __builtin_bit_cast(xh_f16x4, (xh_u32x2){a0, a1}), v, 0, 0, 0);
+        const unsigned b0 = SMOT_XH_CVT(v[0], v[1]), b1 = SMOT_XH_CVT(v[2], v[3]);
+        xe[(2 * g) * 4 * XS] = a0;
+        xo[(2 * g) * 4 * XS] = b0;
+        if (g < 3 || tail) {
+            xo[(2 * g + 1) * 4 * XS] = a1;
+            xe[(2 * g + 1) * 4 * XS] = b1;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int x = lane & 15, kq = lane >> 4;
+    const unsigned a_base = (unsigned)(size_t)xs + (unsigned)(x * XS * 4);        // row y = x of A; + i * 128 by the offset field
+    const int c0 = kq + x;                                                       // chunk kq of row x + i stands at (c0 + i) & 7
+    int sw = 8 * kq - x + 16;
+    sw = sw < 8 ? 8 : (sw > 31 ? 31 : sw);
+    const int loc = sw - 8;
+    const unsigned sh = (unsigned)(loc & 1) * 16u;
+    const unsigned b_addr = (unsigned)(size_t)tz + (unsigned)((loc >> 1) * 4);
+    const unsigned b_addr2 = b_addr + 15 * XH_TZ_ROW;
+    xh_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0;
+    xh_u32x4 A1[2], A2[2];
+    xh_u32x2 B1[2][2], B2[2][2];
+    unsigned B1t[2], B2t[2];
+#define SMOT_XL_RD(I, S)                                                                                           \
+    {                                                                                                              \
+        const unsigned o1 = (unsigned)((c0 + (I)) & 7) << 4;                                                       \
+        const unsigned a1_ = a_base + o1, a2_ = a_base + (o1 ^ 64u);                                               \
+        asm volatile("ds_read_b128 %0, %8 offset:%12\n\tds_read_b128 %1, %9 offset:%12\n\t"                        \
+                     "ds_read2_b32 %2, %10 offset0:%13 offset1:%14\n\tds_read2_b32 %3, %10 offset0:%15 offset1:%16\n\t" \
+                     "ds_read_b32 %4, %10 offset:%17\n\t"                                                          \
+                     "ds_read2_b32 %5, %11 offset0:%13 offset1:%14\n\tds_read2_b32 %6, %11 offset0:%15 offset1:%16\n\t" \
+                     "ds_read_b32 %7, %11 offset:%17"                                                              \
+                     : "=&v"(A1[S]), "=&v"(A2[S]), "=&v"(B1[S][0]), "=&v"(B1[S][1]), "=&v"(B1t[S]), "=&v"(B2[S][0]),   \
+                       "=&v"(B2[S][1]), "=&v"(B2t[S])                                                              \
+                     : "v"(a1_), "v"(a2_), "v"(b_addr), "v"(b_addr2), "n"((I) * XS * 4), "n"((I) * 16), "n"((I) * 16 + 1), \
+                       "n"((I) * 16 + 2), "n"((I) * 16 + 3), "n"((I) * 64 + 16) : "memory");                       \
+    }
+#define SMOT_XL_AL(HI, LO) __builtin_amdgcn_alignbit(HI, LO, sh)
+#define SMOT_XL_B(X, XT, S) __builtin_bit_cast(xh_f16x8, (xh_u32x4){SMOT_XL_AL(X[S][0][1], X[S][0][0]), SMOT_XL_AL(X[S][1][0], X[S][0][1]), \
+                                                                     SMOT_XL_AL(X[S][1][1], X[S][1][0]), SMOT_XL_AL(XT[S], X[S][1][1])})
+#define SMOT_XL_MM(S)                                                                                              \
+    {                                                                                                              \
+        const xh_f16x8 b1_ = SMOT_XL_B(B1, B1t, S), b2_ = SMOT_XL_B(B2, B2t, S);                                   \
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh_f16x8, A2[S]), b1_, acc0, 0, 0, 0);    \
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh_f16x8, A1[S]), b2_, acc1, 0, 0, 0);    \
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xh_f16x8, A1[S]), b1_, acc2, 0, 0, 0);    \
+    }
+#define SMOT_XL_STEP(I)                                                                                            \
+    if ((I) + 1 < 15) { SMOT_XL_RD((I) + 1, ((I) + 1) & 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); }    \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    SMOT_XL_MM((I) & 1)                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);
+    SMOT_XL_RD(0, 0)
+    SMOT_XL_STEP(0) SMOT_XL_STEP(1) SMOT_XL_STEP(2) SMOT_XL_STEP(3) SMOT_XL_STEP(4) SMOT_XL_STEP(5) SMOT_XL_STEP(6) SMOT_XL_STEP(7)
+    SMOT_XL_STEP(8) SMOT_XL_STEP(9) SMOT_XL_STEP(10) SMOT_XL_STEP(11) SMOT_XL_STEP(12) SMOT_XL_STEP(13) SMOT_XL_STEP(14)
+#undef SMOT_XL_STEP
+#undef SMOT_XL_MM
+#undef SMOT_XL_B
+#undef SMOT_XL_AL
+#undef SMOT_XL_RD
+    float* o = out + (size_t)plane * 256 + kq * 4 * 16 + x;
+    float mo = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float v = (((acc0[r] + acc1[r]) + acc2[r]) * isx) * isz;
+        o[r * 16] = v;
+        mo = fmaxf(mo, fabsf(v));
+    }
+    if (pmax != nullptr) {
+        mo = xh_wave_absmax(mo);
+        if (lane == 0) pmax[plane] = mo;
+    }
+}
 #undef SMOT_XH_CVT
 
 }  // namespace smot

@@ -863,7 +863,7 @@ def tower_form(n, channels, ho=16):
 def fused_kernel_name():
     """Name of the kernel ``smot_emm_track_fwd`` runs for search-region pooling + cross-correlation at the
     DLA shape family (what bench.py's roofline and the rocprofv3 summaries in profiles/ refer to)."""
-    return "sr_xcorr_fused9_kernel<30,15,2,true>"
+    return "sr_xcorr_fused9_kernel<30,15,2,true,8,false,1>"       # (..., planes per workgroup, no plane-pair FMA phase, matrix-pipe correlation)
 
 
 def kernel_timer_begin(slot, max_launches, stride=1):
