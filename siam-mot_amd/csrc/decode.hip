@@ -134,32 +134,28 @@ __device__ __forceinline__ float cell_score(const float* v, float box_w, float b
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
-// v = {cls0 - cls1, center, l + r, t + b}: the four derived planes are interpolated instead of the seven logits
-// (bicubic interpolation is linear, so this differs from the seven-plane result by rounding only).
-__device__ __forceinline__ float cell_score_fast(const float* v, float inv_bw, float inv_bh, float win,
-                                                 const DecodeParams& D) {
+// v = the four RANKING planes, interpolated instead of the seven logits (bicubic interpolation is linear, so this differs
+// from the seven-plane result by rounding only), each already carrying the constant its use needs (round 6: the planes are
+// scaled once per band when they are built, not once per cell):
+//   v0 = (cls0 - cls1) * log2(e),  v1 = -center * log2(e),  v2 = (l + r) / box_w,  v3 = (t + b) / box_h;
+// swin = sigma * window.  38 full-rate + 6 quarter-rate instructions per cell with the key and the running best (it was 55 + 5).
+__device__ __forceinline__ float cell_score_fast(const float* v, float swin, const DecodeParams& D) {
     // softmax over two classes and the centerness sigmoid share one reciprocal:
-    //   p1 * sig = 1 / ((1 + exp(v0 - v1)) * (1 + exp(-v2)))
-    float den = 1.0f + fast_exp(v[0]);
-    if (D.use_centerness) den *= 1.0f + fast_exp(-v[1]);
+    //   p1 * sig = 1 / ((1 + exp(cls0 - cls1)) * (1 + exp(-center)))
+    float den = 1.0f + __builtin_amdgcn_exp2f(v[0]);
+    if (D.use_centerness) {
+        const float t1 = 1.0f + __builtin_amdgcn_exp2f(v[1]);
+        den = den * t1;
+    }
     const float conf = fast_rcp(den);
-    // max(a, 1/a) * max(b, 1/b) with ONE reciprocal r = 1/(a*b) (1/a = b*r, 1/b = a*r).  max(a, 1/a) is a
-    // itself for a >= 1 and for -1 <= a < 0 (bicubic overshoot can make the sizes negative), else 1/a.
-    // NaN in a or b makes r NaN and every comparison false -> NaN (propagates, as max_nan does in the exact path).
-    const float a = v[2] * inv_bw;
-    const float b = v[3] * inv_bh;
-    const float ab = a * b;
-    const float r = fast_rcp(ab);
-    const bool pa = (a >= 1.0f) | ((a < 0.0f) & (a >= -1.0f));        // (bitwise: no short-circuit branches in the walk)
-    const bool pb = (b >= 1.0f) | ((b < 0.0f) & (b >= -1.0f));
-    // all four candidates are computed and selected (three v_cndmask): written as a nested conditional on products hipcc
-    // turned it into exec-mask branches — ~15 scalar instructions per cell in the walk's inner loop
-    const float aar = a * a * r, bbr = b * b * r;
-    float s_pa = pb ? ab : aar, s_na = pb ? bbr : r;
-    asm volatile("" : "+v"(s_pa), "+v"(s_na));
-    const float sws = pa ? s_pa : s_na;
-    const float pen = fast_exp(fmaf(-sws, 0.1f, 0.1f));
-    return fmaf(conf * pen, D.one_minus_sigma, D.sigma * win);
+    // max(a, 1/a) * max(b, 1/b): one hardware reciprocal and one v_max_f32 each.  The maximum picks a for a >= 1 and for
+    // -1 <= a < 0 (bicubic overshoot can make the sizes negative), 1/a otherwise; 0 -> inf (penalty 0, as in the exact
+    // path); NaN propagates (max(NaN, NaN)).  (Rounds 2-5 shared ONE reciprocal of a*b between the two: three more
+    // multiplications, six comparisons and three selects per cell.)
+    const float sa = fmaxf(v[2], fast_rcp(v[2]));
+    const float sb = fmaxf(v[3], fast_rcp(v[3]));
+    const float pen = __builtin_amdgcn_exp2f(fmaf(sa * sb, -0.1f * 1.44269504088896341f, 0.1f * 1.44269504088896341f));
+    return fmaf(conf * pen, D.one_minus_sigma, swin);
 }
 
 __device__ __forceinline__ float interp4_fma(float a, float b, float c, float d, const float* w) {
@@ -268,6 +264,9 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     }
     __syncthreads();
 
+    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
+    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
+    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
     int rows[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) rows[k] = clampi(f - 1 + k, 0, Ho - 1);
@@ -275,16 +274,14 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
         const int k = e / Ho, col = e - k * Ho;
         const float* q = lg + rows[k] * Ho + col;
         const int hw = Ho * Ho;
-        dv[0][k][col] = q[0] - q[hw];
-        dv[1][k][col] = q[2 * hw];
-        dv[2][k][col] = q[5 * hw] + q[3 * hw];
-        dv[3][k][col] = q[6 * hw] + q[4 * hw];
+        // the ranking planes with the constants of cell_score_fast folded in (the search pass only ranks)
+        dv[0][k][col] = (q[0] - q[hw]) * 1.44269504088896341f;
+        dv[1][k][col] = q[2 * hw] * -1.44269504088896341f;
+        dv[2][k][col] = (q[5 * hw] + q[3 * hw]) * inv_bw;
+        dv[3][k][col] = (q[6 * hw] + q[4 * hw]) * inv_bh;
     }
     __syncthreads();
     DC_TRACE(1)
-    const float box_w = sub_rn(boxes[n * 4 + 2], boxes[n * 4 + 0]);
-    const float box_h = sub_rn(boxes[n * 4 + 3], boxes[n * 4 + 1]);
-    const float inv_bw = div_rn(1.0f, box_w), inv_bh = div_rn(1.0f, box_h);
     const int rows_per_part = (y_end - y_begin + SPLIT - 1) / SPLIT;
     const int y0p = y_begin + part * rows_per_part, y1p = min(y_end, y0p + rows_per_part);
 
@@ -307,29 +304,34 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
                 const float* rowp = dv[ch][k];
                 h[ch][k] = interp4_fma(rowp[cols[0]], rowp[cols[1]], rowp[cols[2]], rowp[cols[3]], wx);
             }
-        const float hx = hann[X];
+        const float hx = D.sigma * hann[X];
         for (int Y = ya; Y < yb; ++Y) {
             const float4 w4 = *reinterpret_cast<const float4*>(wy_tab[Y - y_begin]);
             const float wy[4] = {w4.x, w4.y, w4.z, w4.w};
             float v[4];
 #pragma unroll
             for (int ch = 0; ch < 4; ++ch) v[ch] = interp4_fma(h[ch][0], h[ch][1], h[ch][2], h[ch][3], wy);
-            visit(cell_score_fast(v, inv_bw, inv_bh, hy_tab[Y - y_begin] * hx, D), Y);
+            visit(cell_score_fast(v, hy_tab[Y - y_begin] * hx, D), Y);
         }
     };
-    unsigned long long best = 0ull;       // lanes without a cell carry key 0 (below every real key)
+    // The lane's best is kept as (score key, flat index) with a STRICT comparison on the score key alone: which of two
+    // equal-scored cells of a lane is remembered does not matter — equal (or within DEC_TOL) means the second-best key is in
+    // range as well, and the lane then nominates every cell in range (`several` below).
+    unsigned bsk = 0u, bidx = 0u;         // lanes without a cell carry key 0 (below every real key)
     unsigned sk2 = 0u;                    // second-best fast score key of this lane (0 = none)
 #pragma unroll 1
     for (int j = 0; j < DEC_MAX_COLS; ++j) {
         const int X = tcol + 256 * j;
         if (X >= G) break;
         walk(X, y0p, y1p, [&](float s, int Y) {
-            const unsigned long long key = make_key(s, (unsigned)(Y * G + X));
-            const unsigned sk = (unsigned)(key >> 32), sk1 = (unsigned)(best >> 32);
-            sk2 = max(sk2, min(sk, sk1));                 // the smaller of (new, current best) competes for second
-            best = (key > best) ? key : best;
+            const unsigned sk = score_key(s);
+            asm("v_med3_u32 %0, %1, %2, %0" : "+v"(sk2) : "v"(sk), "v"(bsk));      // the second largest of (new, best, second): sk2 <= bsk always
+            const bool gt = sk > bsk;
+            bsk = gt ? sk : bsk;
+            bidx = gt ? (unsigned)(Y * G + X) : bidx;
         });
     }
+    const unsigned long long best = bsk != 0u ? (((unsigned long long)bsk << 32) | (unsigned long long)(0xFFFFFFFFu - bidx)) : 0ull;
     DC_TRACE(2)
     // only the best fast SCORE of the band is needed here (the nomination threshold): a 32-bit maximum
     const unsigned ws = wave_max_u32((unsigned)(best >> 32));

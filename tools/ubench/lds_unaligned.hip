@@ -59,6 +59,53 @@ float time_rate(unsigned* d) {
     return best * 1e3f;
 }
 
+// rate of one read shape: WIDTH bytes per lane at byte offset lane * STRIDE + SKEW (+ 4 offsets per iteration), 8 waves per CU
+template <int WIDTH, int STRIDE, int SKEW>
+__global__ void __launch_bounds__(512) shape_rate_kernel(unsigned* out) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[16384];
+    for (int e = threadIdx.x; e < 16384; e += 512) lds[e] = (unsigned short)e;
+    __syncthreads();
+    const unsigned base = (unsigned)(size_t)lds + (threadIdx.x & 63) * STRIDE + SKEW + (threadIdx.x >> 6) * 2048;
+    unsigned acc = 0;
+    for (int it = 0; it < 2048; ++it) {
+        if (WIDTH == 16) {
+            u32x4 a, b, c, d;
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:1024\n\tds_read_b128 %2, %4 offset:16\n\tds_read_b128 %3, %4 offset:1040\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(base) : "memory");
+            acc += a[0] ^ b[1] ^ c[2] ^ d[3];
+        } else if (WIDTH == 8) {
+            u32x2 a, b, c, d;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:1024\n\tds_read_b64 %2, %4 offset:8\n\tds_read_b64 %3, %4 offset:1032\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(base) : "memory");
+            acc += a[0] ^ b[1] ^ c[0] ^ d[1];
+        } else {
+            unsigned a, b, c, d;
+            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:1024\n\tds_read_b32 %2, %4 offset:4\n\tds_read_b32 %3, %4 offset:1028\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(base) : "memory");
+            acc += a ^ b ^ c ^ d;
+        }
+    }
+    out[blockIdx.x * 512 + threadIdx.x] = acc;
+}
+template <int WIDTH, int STRIDE, int SKEW>
+float time_shape(unsigned* d) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((shape_rate_kernel<WIDTH, STRIDE, SKEW>), dim3(256), dim3(512), 0, 0, d);
+    (void)hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int r = 0; r < 5; ++r) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((shape_rate_kernel<WIDTH, STRIDE, SKEW>), dim3(256), dim3(512), 0, 0, d);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    // LDS cycles per wave instruction: 8 waves x 2048 x 4 instructions per CU, 2.4 GHz
+    return best * 1e-3f * 2.4e9f / (8.0f * 2048.0f * 4.0f);
+}
+
 int main() {
     unsigned* d; (void)hipMalloc(&d, 256 * 512 * 4 * 4);
     unsigned h[256];
@@ -84,5 +131,10 @@ int main() {
                hipGetErrorString(e), bad);
     }
     printf("{\"rate_us_4x_ds_read_b128_x2048_per_wave\": {\"aligned_16\": %.1f, \"skew_4\": %.1f, \"skew_2\": %.1f}}\n", time_rate<0>(d) , time_rate<4>(d), time_rate<2>(d));
+    printf("{\"lds_cycles_per_wave_instruction_at_2.4GHz\": {\"b128_stride16_aligned\": %.1f, \"b128_stride16_skew8\": %.1f, \"b128_stride16_skew4\": %.1f, "
+           "\"b64_stride8_aligned\": %.1f, \"b64_stride8_skew4\": %.1f, \"b64_stride8_skew2\": %.1f, \"b32_stride4\": %.1f, \"b32_stride4_skew2\": %.1f, "
+           "\"b64_stride4_overlapping_aligned4\": %.1f, \"b64_stride2_overlapping\": %.1f}}\n",
+           time_shape<16, 16, 0>(d), time_shape<16, 16, 8>(d), time_shape<16, 16, 4>(d), time_shape<8, 8, 0>(d), time_shape<8, 8, 4>(d),
+           time_shape<8, 8, 2>(d), time_shape<4, 4, 0>(d), time_shape<4, 4, 2>(d), time_shape<8, 4, 0>(d), time_shape<8, 2, 0>(d));
     return 0;
 }
