@@ -107,7 +107,7 @@ def other_config_runs(args):
     out = {}
     for name, extra in runs.items():
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "200", "--warmup", "50", "--prewarm-ms", "200",
-               "--no-cpu-baseline", "--no-graph", "--extra-streams", "0", "--no-other-configs", "--other-config-worker",
+               "--no-cpu-baseline", "--no-graph", "--extra-streams", "0", "--no-tracking-loop", "--no-other-configs", "--other-config-worker",
                "--argmax-pairs", "30" if name == "configs[2]" else "0"] + extra
         try:
             r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
@@ -798,6 +798,8 @@ def main():
                          "round 6: the replay buys HOST time (3 us per frame pair instead of ~42), not GPU time — 58.3 vs 57.3 us "
                          "per step — so it is a deployment option for host-bound callers, not a faster benchmark leg")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)          # (accepted: the leg is off by default)
+    ap.add_argument("--no-tracking-loop", action="store_true",
+                    help="skip the tracking-loop legs (head + solver + track memory per frame; ~20 s)")
     ap.add_argument("--extra-streams", type=int, default=0,
                     help="after the timed region, also measure S independent video streams on S HIP streams of the same "
                          "GPU (reported as `multi_stream`, not as `value`); 0 disables")
@@ -934,6 +936,7 @@ def main():
             graph_stats = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if world == 1 and args.extra_streams > 1:
         multi = multi_stream_throughput(emm, feats, det, args.extra_streams, dev)
+    if world == 1 and not args.no_tracking_loop:
         loop_stats = tracking_loop_throughput(n, dev, feats)
         loop_stats["with_refinement"] = tracking_loop_throughput(n, dev, feats, refine=True)
         # the same loops with every call shown the next frame's features (a streaming caller): the next head is launched a
@@ -1146,6 +1149,9 @@ def main():
         "tower_us": rt.get("avg_launch_us"), "tower_form": rt.get("form"),
         "tower_f16_mfma_frac": (rt.get("f16_mfma") or {}).get("frac"),
         "host_enqueue_us_per_step": max(rank_host_us),
+        "tracking_loop_ms_per_frame": None if not loop_stats else {
+            "plain": loop_stats.get("ms_per_frame"), "with_refinement": (loop_stats.get("with_refinement") or {}).get("ms_per_frame"),
+            "next_frame_shown": (loop_stats.get("next_frame_shown") or {}).get("ms_per_frame")},
         "argmax_statistics": {k: am.get(k) for k in ("frame_pairs", "tracks_total", "argmax_exact", "min_iou",
                                                      "tracks_below_1e-3_iou_bar")} if am else None,
         "other_configs_ms_per_step": {k: v.get("ms_per_step") for k, v in (out.get("other_configs") or {}).items()},

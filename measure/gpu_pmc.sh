@@ -5,7 +5,7 @@ TAG=${1:-r03}
 N=${2:-30}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-B="python $R/bench.py --tracks $N --steps 40 --warmup 5 --prewarm-ms 0 --no-cpu-baseline --no-parity --no-kernel-timer --extra-streams 0"
+B="python $R/bench.py --tracks $N --steps 40 --warmup 5 --prewarm-ms 0 --no-cpu-baseline --no-parity --no-kernel-timer --no-tracking-loop --extra-streams 0"
 cd /tmp
 timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $R/gpurun_out/pmc_${TAG}_sq -o sq -- $B > $R/gpurun_out/pmc_${TAG}_sq.log 2>&1
 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE -d $R/gpurun_out/pmc_${TAG}_fetch -o fetch -- $B > $R/gpurun_out/pmc_${TAG}_fetch.log 2>&1

@@ -26,8 +26,8 @@ stats() {   # name, command...
   echo "== $name"; head -10 gpurun_out/${TAG}_${name}_kernel_stats.md | awk -F'|' 'NR>4{print substr($2,1,58), $3, $4, $5}'
   rm -rf gpurun_out/prof_$name
 }
-stats n30 python $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-parity --no-other-configs
-stats n100 python $R/bench.py --tracks 100 --steps 200 --warmup 30 --no-cpu-baseline --no-parity --no-other-configs
-stats cfg4 python $R/bench.py --tracks 50 --channels 256 --net-hw 1056 1920 --steps 150 --warmup 20 --no-cpu-baseline --no-parity --no-other-configs
+stats n30 python $R/bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-parity --no-tracking-loop --no-other-configs
+stats n100 python $R/bench.py --tracks 100 --steps 200 --warmup 30 --no-cpu-baseline --no-parity --no-tracking-loop --no-other-configs
+stats cfg4 python $R/bench.py --tracks 50 --channels 256 --net-hw 1056 1920 --steps 150 --warmup 20 --no-cpu-baseline --no-parity --no-tracking-loop --no-other-configs
 stats aot python $R/tools/aot_bench.py
 stats loop python $R/measure/debug/loop_kernels.py
