@@ -333,6 +333,12 @@ decode_kernel(LogitSrc L, const float* __restrict__ boxes, const float* __restri
     }
     const unsigned long long best = bsk != 0u ? (((unsigned long long)bsk << 32) | (unsigned long long)(0xFFFFFFFFu - bidx)) : 0ull;
     DC_TRACE(2)
+    // (Round 6, measured and dropped — both bit-identical to this flow, interleaved A/B of two library builds in one session,
+    // measure/lib_ab.py: (i) nominating against the WAVE's best score with per-wave nominee lists — no threshold barrier, the
+    // nominees are a superset of the band's — 13.9 instead of 12.7 us: in the flat, low-scored corners of the window whole
+    // waves nominate dozens of cells at ~2.5 k cycles of exact evaluation each; (ii) the band's threshold as below but
+    // per-wave lists and evaluation, one barrier fewer: 53.3 vs 53.0 us per frame pair — the barrier it removes was not
+    // on the winner wave's path, the eight list counters and wave fences are.)
     // only the best fast SCORE of the band is needed here (the nomination threshold): a 32-bit maximum
     const unsigned ws = wave_max_u32((unsigned)(best >> 32));
     const int wave = threadIdx.x >> 6;
