@@ -45,7 +45,9 @@ typedef void* smot_stream_t; /* hipStream_t */
  * 13: the second image of smot_emm_tower_pack is the TWO-part fp16 image (C/32 + 1 rotated blocks of 8192 floats per
  *     16-channel tile) followed by a four-word header {largest |w| bits, 2^-ku, 0, 0}: ask smot_emm_tower_pack_floats — an
  *     image packed by a version-12 library has another size and layout; smot_emm_tower_form returns 3 at every track count
- *     (one form); smot_emm_predictor_fwd may use the head of its `logits` output as scratch before it writes the logits.
+ *     (one form); smot_emm_predictor_fwd may use the head of its `logits` output as scratch before it writes the logits;
+ *     smot_sr_xcorr_fused_fwd / smot_emm_track_fwd correlate on the matrix cores (no signature change: responses equal
+ *     smot_xcorr_dw_fwd's to rounding, not bit for bit).
  */
 #define SMOT_ABI_VERSION 13
 
@@ -153,8 +155,10 @@ int smot_xcorr_dw_fwd(const float* x, const float* z, float* out, int N, int C, 
  * Replaces, in EMM.forward (EMM/track_core.py:49-53): pad_feature -> SRPooler(sr) -> xcorr_depthwise.
  *   Arguments as smot_roi_align_levels_fwd (rois = sr, level_boxes = boxes) and smot_xcorr_dw_fwd
  *   (z = templates [N,C,rz,rz]); resp [N,C,Ho,Ho].  x_debug: NULL, or a [N,C,rx,rx] buffer that
- *   receives the pooled planes (tests).  Responses are bit-identical to smot_xcorr_dw_fwd applied to the
- *   pooled planes; the pooling itself is separable (fp32-rounding-level differences to ROIAlign).
+ *   receives the pooled planes (tests).  The pooling is separable (fp32-rounding-level differences to ROIAlign).  Since
+ *   ABI 13 the correlation runs on the matrix cores (two-part fp16 operands of power-of-two-scaled planes, fp32
+ *   accumulation): responses equal smot_xcorr_dw_fwd on the pooled planes to ROUNDING — within 6e-7 * sum |x||z| of an
+ *   fp64 correlation, as the fp32 FMA chain of smot_xcorr_dw_fwd itself is — not bit for bit any more.
  * SMOT_ERR_UNSUPPORTED unless rx == 30, rz == 15, sampling_ratio == 2 (35 / 7: smot_sr_xcorr_gather_fwd; otherwise the two
  * unfused calls).
  */
