@@ -1072,7 +1072,7 @@ def main():
         # arithmetic type of the path: fp32 in and out of every kernel; the towers' transform-domain GEMMs run on the fp16 matrix
         # pipe with every fp32 operand as two fp16 parts of a power-of-two-scaled value (3 of 4 part products, fp32 accumulate):
         # logits within the fp32 form's error of an fp64 evaluation (tests/test_hip_parity.py, 1.25 x bound)
-        "dtype": "f32 (towers: fp16x2 operands on MFMA, fp32 accumulate, fp32-equivalent error)",
+        "dtype": "f32 (towers and correlation: fp16x2 operands on MFMA, fp32 accumulate, fp32-equivalent error)",
         "data": "synthetic",
         "config": {
             "workload": "EMM tracker-head frame pair (EMM.forward + EMM.extract_cache) on %s FPN maps "

@@ -43,7 +43,7 @@ constexpr int XH_TZ_BYTES = XH_TZ_ODD + 2 * 15 * XH_TZ_ROW;
 constexpr int XH_TZ_FLOATS = XH_TZ_BYTES / 4;              // 976
 static_assert(XH_TZ_BYTES % 16 == 0, "zero fill by 16-byte stores");
 
-__device__ __forceinline__ float xh_wave_absmax(float v) {
+__device__ __forceinline__ float xh_wave_absmax(float v) {           // (NaN ignored: the response's plane maximum)
 #define SMOT_ROR(N) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + (N), 0xf, 0xf, false))
     v = fmaxf(v, SMOT_ROR(8));
     v = fmaxf(v, SMOT_ROR(4));
@@ -54,12 +54,31 @@ __device__ __forceinline__ float xh_wave_absmax(float v) {
     const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
     return fmaxf(fmaxf(a, b), fmaxf(c, d));
 }
-// power of two s with m * s in [2^13, 2^14) (1 for m = 0 / inf / nan; exponent clamped to +-100), and its inverse
-__device__ __forceinline__ void xh_pow2_scale(float m, float* s, float* inv) {
-    const int e = (int)((__float_as_uint(m) >> 23) & 0xffu);
+// the operands' maximum is taken over MAGNITUDE BITS (v & 0x7fffffff as unsigned): NaN > inf > every finite value, so one
+// word says both how to scale the plane and whether it holds a non-finite value at all
+__device__ __forceinline__ unsigned xh_mag(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned xh_wave_umax(unsigned v) {
+#define SMOT_ROR(N) (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x120 + (N), 0xf, 0xf, false)
+    v = max(v, SMOT_ROR(8));
+    v = max(v, SMOT_ROR(4));
+    v = max(v, SMOT_ROR(2));
+    v = max(v, SMOT_ROR(1));
+#undef SMOT_ROR
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
+}
+// power of two s with m * s in [2^13, 2^14) (exponent clamped to +-100: magnitudes 2^-87 .. 2^113 keep full precision,
+// denormal planes are lifted by 2^100) and its inverse; m = 0: 1 / 1; m = inf or NaN: 1 / NaN — a plane (or template) with a
+// non-finite value gives an all-NaN response plane (the fp16 split has no meaning for it; the reference leaves NaN / inf in
+// the outputs whose window covers the value, and the towers' GroupNorm makes a NaN track of either)
+__device__ __forceinline__ void xh_pow2_scale(unsigned mbits, float* s, float* inv) {
+    const int e = (int)(mbits >> 23);
     *s = 1.0f;
     *inv = 1.0f;
-    if (e != 0 && e != 255) {
+    if (e == 255) {
+        *inv = __uint_as_float(0x7FC00000u);
+    } else if (mbits != 0u) {
         int k = 140 - e;
         k = k < -100 ? -100 : (k > 100 ? 100 : k);
         *s = __uint_as_float((unsigned)(127 + k) << 23);
@@ -90,9 +109,9 @@ __device__ __forceinline__ float xh_template_store(const float zq[4], unsigned c
     float zv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) zv[t] = (j < 15 && r0 + 4 * t < 15) ? zq[t] : 0.0f;
-    float mz = fmaxf(fmaxf(fabsf(zv[0]), fabsf(zv[1])), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
+    const unsigned mz = max(max(xh_mag(zv[0]), xh_mag(zv[1])), max(xh_mag(zv[2]), xh_mag(zv[3])));
     float sz, isz;
-    xh_pow2_scale(xh_wave_absmax(mz), &sz, &isz);
+    xh_pow2_scale(xh_wave_umax(mz), &sz, &isz);
     {   // zeros under the rows (their pads are what windows beside the template read)
         xh_u32x4* z4 = reinterpret_cast<xh_u32x4*>(tz);
 #pragma unroll
@@ -136,17 +155,17 @@ __device__ __forceinline__ void xh_correlate(float* xs, const unsigned char* tz,
     const int c2 = lane & 15, r0 = lane >> 4;
     float* xrow = xs + r0 * XS + 2 * c2;
     xh_f32x4 xv[4];
-    float m = 0.0f;
+    unsigned m = 0u;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const bool live = c2 < 15 && (t < 7 || r0 < 2);
         const float2 v = *reinterpret_cast<const float2*>(xrow + t * 4 * XS);
         xv[t >> 1][(t & 1) * 2] = live ? v.x : 0.0f;
         xv[t >> 1][(t & 1) * 2 + 1] = live ? v.y : 0.0f;
-        m = fmaxf(m, live ? fmaxf(fabsf(v.x), fabsf(v.y)) : 0.0f);
+        m = max(m, live ? max(xh_mag(v.x), xh_mag(v.y)) : 0u);
     }
     float sx, isx;
-    xh_pow2_scale(xh_wave_absmax(m), &sx, &isx);
+    xh_pow2_scale(xh_wave_umax(m), &sx, &isx);
     unsigned* xh = reinterpret_cast<unsigned*>(xs) + r0 * XS + c2;          // row r: dwords 0..15 part 1, 16..31 part 2
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -233,9 +252,9 @@ __device__ __forceinline__ float xl_template_store(const float zq[4], unsigned c
     float zv[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) zv[t] = (j < 15 && r0 + 4 * t < 15) ? zq[t] : 0.0f;
-    float mz = fmaxf(fmaxf(fabsf(zv[0]), fabsf(zv[1])), fmaxf(fabsf(zv[2]), fabsf(zv[3])));
+    const unsigned mz = max(max(xh_mag(zv[0]), xh_mag(zv[1])), max(xh_mag(zv[2]), xh_mag(zv[3])));
     float sz, isz;
-    xh_pow2_scale(xh_wave_absmax(mz), &sz, &isz);
+    xh_pow2_scale(xh_wave_umax(mz), &sz, &isz);
     {
         xh_u32x4* z4 = reinterpret_cast<xh_u32x4*>(tz);
 #pragma unroll
@@ -273,17 +292,17 @@ __device__ __forceinline__ void xl_correlate(float* xs, const unsigned char* tz,
     const bool tail = r0 < 2;                                   // rows 28 + r0 exist
     float* xrow = xs + r0 * XS + 2 * c2;
     xh_f32x4 xv[4];
-    float m = 0.0f;
+    unsigned m = 0u;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const bool live = c2 < 15 && (t < 7 || tail);
         const float2 v = *reinterpret_cast<const float2*>((t < 7 || tail) ? xrow + t * 4 * XS : xrow);
         xv[t >> 1][(t & 1) * 2] = live ? v.x : 0.0f;
         xv[t >> 1][(t & 1) * 2 + 1] = live ? v.y : 0.0f;
-        m = fmaxf(m, live ? fmaxf(fabsf(v.x), fabsf(v.y)) : 0.0f);
+        m = max(m, live ? max(xh_mag(v.x), xh_mag(v.y)) : 0u);
     }
     float sx, isx;
-    xh_pow2_scale(xh_wave_absmax(m), &sx, &isx);
+    xh_pow2_scale(xh_wave_umax(m), &sx, &isx);
     // pair c2 of row r = r0 + 4 t: part 1 is dword c2 & 3 of chunk c2 >> 2, part 2 of chunk 4 + (c2 >> 2); chunk c of row r
     // stands at position (c + r) & 7.  (c2 >> 2) + r0 + 4 t: even t -> cb, odd t -> cb ^ 4; part 2 is always the other one.
     const int cb = ((c2 >> 2) + r0) & 7;

@@ -1166,6 +1166,38 @@ def test_fused_matrix_pipe_correlation_scales_every_plane_by_its_own_power_of_tw
         assert torch.equal(rk, r1 * (2.0 ** (k - 7))), "2^%d" % k
 
 
+def test_fused_matrix_pipe_correlation_marks_planes_with_non_finite_values(ops):
+    """A search plane or a template that holds an inf or a NaN has no power-of-two scale and no fp16 split: its response plane is
+    ALL NaN (csrc/xcorr_f16x2.h: the reference leaves NaN / inf in the outputs whose window covers the value; the towers'
+    GroupNorm makes a NaN track of either).  Every other plane of the launch is untouched."""
+    rs = np.random.RandomState(78)
+    scales = (0.25, 0.125, 0.0625, 0.03125)
+    n, c = 4, 16
+    base = [rs.standard_normal((1, c, 96 // 2 ** l, 160 // 2 ** l)).astype(np.float32) for l in range(4)]
+    wh = rs.uniform(40, 160, (n, 2))
+    xy = rs.uniform(0.2, 0.8, (n, 2)) * np.array([640.0, 384.0])
+    boxes = _d(np.concatenate([xy - wh / 2, xy + wh / 2], 1).astype(np.float32))
+    sr = ops.search_region(boxes, 512, 1.0, 0)
+    z0 = rs.standard_normal((n, c, 15, 15)).astype(np.float32)
+    clean = ops.sr_xcorr_fused([_d(f) for f in base], boxes, sr, _d(z0), 30, 15, scales, 2, 512)
+    feats = [f.copy() for f in base]
+    for f in feats:
+        f[0, 2, :, :] = np.inf              # channel 2: every cell (whatever the rois touch)
+        f[0, 9, ::3, ::2] = np.nan          # channel 9: a lattice of NaNs
+    z = z0.copy()
+    z[1, 5, 7, 7] = np.inf                  # one template of track 1
+    z[3, 11, 0, 14] = np.nan                # one template of track 3
+    r, p = ops.sr_xcorr_fused([_d(f) for f in feats], boxes, sr, _d(z), 30, 15, scales, 2, 512, return_pooled=True)
+    bad = torch.zeros((n, c), dtype=torch.bool, device=DEV)
+    bad[:, 2] = True
+    bad[:, 9] = ~torch.isfinite(p[:, 9]).reshape(n, -1).all(1)        # (a roi whose samples miss the lattice keeps a finite plane)
+    bad[1, 5] = True
+    bad[3, 11] = True
+    assert bool(bad[:, 9].any())
+    assert bool(torch.isnan(r[bad]).all()), "a plane with a non-finite operand must be all NaN"
+    assert torch.equal(r[~bad], clean[~bad]), "planes beside a non-finite one changed"
+
+
 @pytest.mark.parametrize("n", [1, 2, 30, 65, 100, 130, 260])
 def test_cost_sorted_workgroup_assignment_is_a_bijection(ops, n):
     """The pooling kernels rank the rois by window width and hand the expensive ones out first (sr_xcorr.hip
