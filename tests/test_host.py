@@ -377,3 +377,82 @@ def test_frame_args_buffer_matches_the_header_struct():
                       ("SMOT_STAGE_SOLVE", ops.STAGE_SOLVE), ("SMOT_STAGE_EXTRACT", ops.STAGE_EXTRACT),
                       ("SMOT_STAGE_CARRY", ops.STAGE_CARRY)):
         assert re.search(r"#define\s+%s\s+%d\b" % (name, val), src_c), name
+
+
+def test_matrix_pipe_correlation_operand_layout_is_the_correlation():
+    """csrc/xcorr_f16x2.h on paper (no device): the 30x30 * 15x15 -> 16x16 correlation as 15 products A_i [16 x 32] . B_i [32 x 16]
+    with B_i[c][x] = Z[i][c - x] read as FOUR ALIGNED DWORDS from an even or an odd copy of template row i.  The test rebuilds
+    both copies and every lane's window from the header's own address formulas (clamp, parity select, dword index, the value a
+    lane packs with its right neighbour's) and checks (1) window = Toeplitz definition for every lane and row, exactly,
+    (2) two fp16 parts of power-of-two-scaled operands with three part products reproduce an fp64 correlation within the
+    bound the GPU tests hold the kernel to."""
+    rs = np.random.RandomState(5)
+    X = rs.standard_normal((30, 30)).astype(np.float32) * 37.0
+    Z = rs.standard_normal((15, 15)).astype(np.float32) * 0.013
+
+    def scale_of(a):                                   # xh_pow2_scale: largest |a| * s in [2^13, 2^14)
+        e = (np.abs(a).max().view(np.uint32) >> 23) & 0xFF
+        k = int(np.clip(140 - int(e), -100, 100))
+        return np.float32(2.0) ** k
+
+    def split(a):                                      # a1 = RNE11(a), a2 = RNE11(a - a1)
+        a1 = a.astype(np.float16)
+        a2 = (a - a1.astype(np.float32)).astype(np.float16)
+        return a1, a2
+
+    sx, sz = scale_of(X), scale_of(Z)
+    x1, x2 = split(X * sx)
+    z1, z2 = split(Z * sz)
+    # ---- the template's rows as xh_template_store writes them: lane j of a row packs (Z[j], Z[j+1]) — lane 15 holds 0 and
+    # its right neighbour is lane 0 — even j -> dword (8 + j) / 2 of the even copy, odd j -> dword (7 + j) / 2 of the odd copy
+    # (lane 15 -> dword 3); rows of 16 dwords, everything else zero
+    def copies(zp):
+        even = np.zeros((15, 32), np.float16)          # halves of the even copy: local half h at index h
+        odd = np.zeros((15, 32), np.float16)           # halves of the odd copy: index h holds local half h + 1
+        for i in range(15):
+            vals = list(zp[i]) + [np.float16(0)]       # lane 15: 0
+            for j in range(16):
+                mine, nxt = vals[j], vals[(j + 1) % 16]
+                if j % 2 == 0:
+                    dw = (8 + j) >> 1
+                    even[i, 2 * dw], even[i, 2 * dw + 1] = mine, nxt
+                else:
+                    dw = 3 if j == 15 else (7 + j) >> 1
+                    odd[i, 2 * dw], odd[i, 2 * dw + 1] = mine, nxt
+        return even, odd
+
+    out = np.zeros((16, 16), np.float64)
+    ref_rows = np.zeros((15, 48), np.float64)          # the 48-half zero-padded rows of the definition: template at 16..30
+    for (zp, tag) in ((z1, 1), (z2, 2)):
+        even, odd = copies(zp)
+        ref_rows[:] = 0
+        ref_rows[:, 16:31] = zp.astype(np.float64)
+        for i in range(15):
+            B = np.zeros((32, 16), np.float64)
+            for lane in range(64):
+                x, kq = lane & 15, lane >> 4
+                sw = min(max(8 * kq - x + 16, 8), 31)
+                loc = sw - 8
+                if loc & 1:
+                    window = odd[i, 2 * ((loc - 1) >> 1): 2 * ((loc - 1) >> 1) + 8]
+                else:
+                    window = even[i, 2 * (loc >> 1): 2 * (loc >> 1) + 8]
+                assert window.shape == (8,)
+                want = ref_rows[i, 8 * kq - x + 16: 8 * kq - x + 24]          # B_i[8 kq + e][x] = Z[i][8 kq + e - x]
+                assert np.array_equal(window.astype(np.float64), want), (tag, i, lane)
+                B[8 * kq: 8 * kq + 8, x] = window
+            for (xp, xtag) in ((x1, 1), (x2, 2)):
+                if tag == 2 and xtag == 2:
+                    continue                            # x2 z2 is dropped
+                A = np.zeros((16, 32), np.float64)      # rows i .. i + 15, columns 30, 31 zero
+                A[:, :30] = xp[i:i + 16].astype(np.float64)
+                out += A @ B
+    out = out / float(sx) / float(sz)
+    ref = np.zeros((16, 16))
+    den = np.zeros((16, 16))
+    for y in range(16):
+        for x in range(16):
+            w = X[y:y + 15, x:x + 15].astype(np.float64)
+            ref[y, x] = (w * Z).sum()
+            den[y, x] = (np.abs(w) * np.abs(Z)).sum()
+    assert np.abs(out - ref).max() <= 2.5e-7 * den.max() and (np.abs(out - ref) <= 6e-7 * den).all(), np.abs((out - ref) / den).max()
