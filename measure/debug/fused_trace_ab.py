@@ -51,5 +51,12 @@ for n in counts:
                           "phase_p90": [round(float(x)) for x in np.percentile(d[ran], 90, axis=0)],
                           "phase_max": [int(x) for x in d[ran].max(0)], "span": int(end.max() - t0), "workgroups_traced": int(ran.sum()),
                           "start_percentiles(50,90,100)": [int(np.percentile(starts, q)) for q in (50, 90, 100)],
-                          "end_percentiles(50,90,99,100)": [int(np.percentile(ends, q)) for q in (50, 90, 99, 100)], "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
+                          "end_percentiles(50,90,99,100)": [int(np.percentile(ends, q)) for q in (50, 90, 99, 100)], "slowest_workgroups(roi,cgrp,total,tables,z,pool,xcorr)": [
+                              [int(i // 16), int(i % 16), int((t[:, :, 4] - t[:, :, 0]).reshape(-1)[i])] + [int(v) for v in d.reshape(-1, 4)[i]]
+                              for i in np.argsort(-(np.where(ran, t[:, :, 4] - t[:, :, 0], 0)).reshape(-1))[:10]],
+                          "head_ticks_mean(start->assigned,->level+bins,->wave0 at table barrier,->tables)": [
+                              round(float((t[:, :, 5] - t[:, :, 0])[ran].mean())), round(float((t[:, :, 6] - t[:, :, 5])[ran].mean())),
+                              round(float((t[:, :, 7] - t[:, :, 6])[ran].mean())), round(float((t[:, :, 1] - t[:, :, 7])[ran].mean()))],
+                          "total_by_roi_mean": [round(float(v)) for v in np.where(ran, t[:, :, 4] - t[:, :, 0], np.nan).mean(1)],
+                          "total_mean": round(float((t[:, :, 4] - t[:, :, 0])[ran].mean())),
                           "total_max": int((t[:, :, 4] - t[:, :, 0])[ran].max())}), flush=True)

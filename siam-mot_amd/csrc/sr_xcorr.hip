@@ -454,6 +454,14 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
     const long long t_start = S.trace ? (long long)__builtin_amdgcn_s_memtime() : 0ll;
+    // The level's map size, padding, scale and base pointer are read from the kernel-argument segment with a DYNAMIC index
+    // once the level is known: scalar loads that DEPEND on the workgroup's first memory round trip and — at a kernel's start,
+    // with the scalar cache and the XCD's L2 freshly invalidated — may miss all the way to memory.  Their three 64-byte lines
+    // (pointers; H, W; pad, scale) are requested here, with the first round trip; the values are "used" behind it (SMOT_KA_USE).
+    const int ka_h = P.H[0], ka_w = P.W[0], ka_p = P.pad[0];
+    const float ka_s = P.scale[0];
+    const unsigned long long ka_f = reinterpret_cast<unsigned long long>(P.feat[0]);
+#define SMOT_KA_USE() asm volatile("" ::"s"(ka_h), "s"(ka_w), "s"(ka_p), "s"(ka_s), "s"(ka_f))
 #ifdef SMOT_DEBUG
     // experiment (measurement library, SMOT_FUSED_ABL = 100 + k): workgroups of the second dispatch wave start 512*k
     // cycles late, so that the two workgroups of a CU pool (LDS crossbar) and correlate (VALU) in anti-phase.
@@ -515,6 +523,8 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const bool have_roi = fx_assign(P, sr, boxes, S.n_valid, RX > 15 ? S.order : 0, grid_row, grid_rows,
                                     XCORR ? S.hint_in : nullptr, lane, &n_assigned, &cg_assigned, &roi_assigned,
                                     &lvl_assigned, &k_assigned);
+    SMOT_KA_USE();
+#undef SMOT_KA_USE
     const int n = __builtin_amdgcn_readfirstlane(n_assigned);
     const int cgrp = __builtin_amdgcn_readfirstlane(cg_assigned);
     if (S.n_valid != nullptr && n >= *S.n_valid) return;         // workgroup-uniform (scalar load)
@@ -551,6 +561,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
     const float x2 = mul_rn(roi[2], scale), y2 = mul_rn(roi[3], scale);
     const float bin_h = div_rn(fmaxf(sub_rn(y2, y1), 1.0f), (float)RX);
     const float bin_w = div_rn(fmaxf(sub_rn(x2, x1), 1.0f), (float)RX);
+    FX_TRACE(6)                                   // (level parameters and bin sizes known)
     // (Measured and dropped, profiles/r02x: one workgroup per (roi, FOUR channels) for rois whose window is wider
     // than 32 columns — two waves per plane, so that they do not set the makespan — with narrow rois using every
     // second workgroup: per-workgroup spans became equal (25-32 k cycles instead of 26 k / 48 k) but 608 working
@@ -625,6 +636,7 @@ sr_xcorr_fused9_kernel(LevelParams P, int C, const float* __restrict__ sr, const
             wbound[2 * wave + 1] = mx;
         }
     }
+    FX_TRACE(7)                                   // (wave 0 at the table barrier)
     __syncthreads();
     const int ymin = hent ? hb[0] : wbound[0], ymax = hent ? hb[1] : wbound[1];
     const int xmin = hent ? hb[2] : wbound[2], xmax = hent ? hb[3] : wbound[3];
