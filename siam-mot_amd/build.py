@@ -32,6 +32,9 @@ ARCH = "gfx950"
 # 1 ulp ~ 1e-5 in the output).  FMAs are written explicitly (fmaf) where they are wanted.
 # (tower_wino.hip without -fno-slp-vectorize was measured: the packed adds hipcc then forms in the operand transform make
 # both forms of the kernel slower — fp32 main loop 40.6 k -> 42.4 k cycles, bf16 x 3 32.7 k -> 37.9 k)
+# (-mllvm -amdgpu-kernarg-preload-count=16 — leading scalar / pointer kernel arguments delivered in SGPRs with the wave
+# instead of through an s_load — was measured in round 6: the tower kernels get 4-10 dwords preloaded, kernels whose first
+# argument is a struct none; interleaved A/B of two library builds: 52.95 vs 52.75 us per frame pair WITH the flag. Not used.)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-ffp-contract=off", "--offload-arch=" + ARCH]
 
 
